@@ -1,0 +1,670 @@
+"""cpu_ref -- float64 CPU restatement of the sygnals feature-extraction hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Never imported by sygnals_amd.
+
+Every function cites the reference file:line (relative to /root/reference) whose
+behaviour it restates.  Where the reference delegates to SciPy/NumPy the same
+SciPy/NumPy routine is called here (it *is* the reference's arithmetic).  Where
+the reference delegates to librosa (not vendored, not installed; pinned only as
+``librosa>=0.10.0`` in pyproject.toml:38) the published librosa algorithm is
+restated in NumPy.
+
+PARITY STATUS
+  pinned   : design_butterworth_sos, apply_sos_filter/*_pass_filter, compute_fft,
+             compute_ifft, apply_window, compute_psd_welch, spectral_centroid,
+             spectral_bandwidth, spectral_flatness, spectral_rolloff,
+             dominant_frequency  -- checked against tests/golden/ref_*.npz, which
+             were produced by executing the reference's own functions.
+  UNPINNED : stft, mel_filterbank, power_to_db, melspectrogram, mfcc,
+             spectral_contrast, frames_to_time, cqt  ("parity unpinned": no
+             runnable librosa, no numeric golden values in the reference's
+             tests).  Anchors: librosa's documented examples (mel_frequencies,
+             hz_to_mel, mel_to_hz, fft_frequencies), closed-form KATs, and
+             scipy.signal.ShortTimeFFT / scipy.fft.dct cross-checks
+             (tests/test_oracle_*.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.fft
+import scipy.signal
+
+EPS64 = np.finfo(np.float64).eps  # frequency_domain.py:21
+
+
+# --------------------------------------------------------------------------
+# a1  STFT  (dsp.py:167-229, manager.py:184-187 -> librosa.stft)
+# --------------------------------------------------------------------------
+def fft_window(window, win_length: int, n_fft: int) -> np.ndarray:
+    """Periodic window of win_length, zero-padded (centred) to n_fft.
+
+    librosa.stft: ``get_window(window, win_length, fftbins=True)`` then
+    ``util.pad_center(.., size=n_fft)``.
+    """
+    if isinstance(window, (str, tuple, float, int)):
+        w = scipy.signal.get_window(window, win_length, fftbins=True)
+    else:
+        w = np.asarray(window, dtype=np.float64)
+        if w.shape != (win_length,):
+            raise ValueError(f"window array must have length {win_length}")
+    w = np.asarray(w, dtype=np.float64)
+    if win_length < n_fft:
+        lpad = (n_fft - win_length) // 2
+        w = np.pad(w, (lpad, n_fft - win_length - lpad))
+    return w
+
+
+def num_frames(length: int, n_fft: int, hop_length: int, center: bool) -> int:
+    """manager.py:149-157 (same rule librosa's framing yields)."""
+    if center:
+        return 1 + length // hop_length
+    if length >= n_fft:
+        return 1 + (length - n_fft) // hop_length
+    return 0
+
+
+def frame_signal(y: np.ndarray, n_fft: int, hop_length: int, center: bool,
+                 pad_mode: str = "constant") -> np.ndarray:
+    """Return frames as a (T, n_fft) float64 array (librosa.util.frame, transposed)."""
+    y = np.asarray(y, dtype=np.float64)
+    if center:
+        y = np.pad(y, n_fft // 2, mode=pad_mode)
+    if y.shape[0] < n_fft:
+        raise ValueError(f"Input is too short (n={y.shape[0]}) for frame_length={n_fft}")
+    T = 1 + (y.shape[0] - n_fft) // hop_length
+    idx = np.arange(n_fft)[None, :] + hop_length * np.arange(T)[:, None]
+    return y[idx]
+
+
+def stft(y, n_fft=2048, hop_length=None, win_length=None, window="hann",
+         center=True, pad_mode="constant") -> np.ndarray:
+    """complex128 [1 + n_fft//2, T], freq-major, like librosa.stft."""
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")  # dsp.py:211-212
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = win_length // 4
+    w = fft_window(window, win_length, n_fft)
+    frames = frame_signal(y, n_fft, hop_length, center, pad_mode)
+    return np.fft.rfft(frames * w[None, :], axis=1).T.astype(np.complex128)
+
+
+def fft_frequencies(sr, n_fft) -> np.ndarray:
+    """librosa.fft_frequencies == rfftfreq (manager.py:199)."""
+    return np.fft.rfftfreq(n_fft, 1.0 / sr)
+
+
+def frames_to_time(frames, sr, hop_length, n_fft=None) -> np.ndarray:
+    """manager.py:166-169: (i*hop + n_fft//2)/sr when n_fft is given."""
+    off = int(n_fft // 2) if n_fft is not None else 0
+    return (np.asarray(frames) * hop_length + off) / float(sr)
+
+
+# --------------------------------------------------------------------------
+# a3  mel filterbank (manager.py:219-222 -> librosa.feature.melspectrogram)
+# --------------------------------------------------------------------------
+_F_SP = 200.0 / 3
+_MIN_LOG_HZ = 1000.0
+_MIN_LOG_MEL = _MIN_LOG_HZ / _F_SP          # 15.0
+_LOGSTEP = np.log(6.4) / 27.0
+
+
+def hz_to_mel(f, htk=False):
+    f = np.asanyarray(f, dtype=np.float64)
+    if htk:
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+    m = f / _F_SP
+    big = f >= _MIN_LOG_HZ
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m = np.where(big, _MIN_LOG_MEL + np.log(np.maximum(f, 1e-300) / _MIN_LOG_HZ) / _LOGSTEP, m)
+    return m
+
+
+def mel_to_hz(m, htk=False):
+    m = np.asanyarray(m, dtype=np.float64)
+    if htk:
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    f = _F_SP * m
+    big = m >= _MIN_LOG_MEL
+    return np.where(big, _MIN_LOG_HZ * np.exp(_LOGSTEP * (m - _MIN_LOG_MEL)), f)
+
+
+def mel_frequencies(n_mels=128, fmin=0.0, fmax=11025.0, htk=False):
+    return mel_to_hz(np.linspace(hz_to_mel(fmin, htk), hz_to_mel(fmax, htk), n_mels), htk)
+
+
+def mel_filterbank(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False,
+                   norm="slaney") -> np.ndarray:
+    """float32 [n_mels, 1 + n_fft//2] exactly as librosa.filters.mel stores it.
+
+    The triangles are evaluated in float64, *stored* float32, then the Slaney
+    area normalisation multiplies the float32 values (product formed in
+    float64, rounded to float32 again) -- both roundings are reproduced.
+    """
+    if fmax is None:
+        fmax = sr / 2.0
+    F = 1 + n_fft // 2
+    freqs = fft_frequencies(sr, n_fft)
+    edges = mel_frequencies(n_mels + 2, fmin, fmax, htk)
+    width = np.diff(edges)
+    W = np.zeros((n_mels, F), dtype=np.float32)
+    for m in range(n_mels):
+        rising = (freqs - edges[m]) / width[m]
+        falling = (edges[m + 2] - freqs) / width[m + 1]
+        W[m] = np.maximum(0.0, np.minimum(rising, falling)).astype(np.float32)
+    if norm == "slaney":
+        enorm = 2.0 / (edges[2:n_mels + 2] - edges[:n_mels])
+        W = (W.astype(np.float64) * enorm[:, None]).astype(np.float32)
+    elif norm is not None:
+        raise ValueError("norm must be 'slaney' or None in this restatement")
+    return W
+
+
+def melspectrogram(S_power, sr, n_fft=None, n_mels=128, fmin=0.0, fmax=None) -> np.ndarray:
+    """[n_mels, T] float64 = basis(f32->f64) @ S_power  (einsum 'ft,mf->mt')."""
+    S_power = np.asarray(S_power, dtype=np.float64)
+    if n_fft is None or n_fft // 2 + 1 != S_power.shape[0]:
+        n_fft = 2 * (S_power.shape[0] - 1)
+    B = mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    return B.astype(np.float64) @ S_power
+
+
+# --------------------------------------------------------------------------
+# a4  power_to_db (manager.py:223)
+# --------------------------------------------------------------------------
+def power_to_db(S, ref=1.0, amin=1e-10, top_db=80.0) -> np.ndarray:
+    S = np.asarray(S, dtype=np.float64)
+    if amin <= 0:
+        raise ValueError("amin must be strictly positive")
+    ref_value = ref(S) if callable(ref) else np.abs(ref)
+    out = 10.0 * np.log10(np.maximum(amin, S))
+    out = out - 10.0 * np.log10(np.maximum(amin, ref_value))
+    if top_db is not None:
+        if top_db < 0:
+            raise ValueError("top_db must be non-negative")
+        out = np.maximum(out, out.max() - top_db)
+    return out
+
+
+# --------------------------------------------------------------------------
+# a5  MFCC (cepstral.py:20-120 -> librosa.feature.mfcc -> scipy.fft.dct)
+# --------------------------------------------------------------------------
+def mfcc(y=None, sr=None, S=None, n_mfcc=13, dct_type=2, norm="ortho", lifter=0.0,
+         **kwargs) -> np.ndarray:
+    if S is None and y is None:
+        raise ValueError("Either audio time series 'y' or Mel spectrogram 'S' must be provided.")  # cepstral.py:94-95
+    if S is None and sr is None:
+        raise ValueError("Sampling rate 'sr' must be provided when calculating MFCCs from time series 'y'.")  # :96-97
+    if S is None:
+        # librosa.feature.mfcc(y=..): power_to_db(melspectrogram(y, sr, **kw)), ref=1.0
+        n_fft = kwargs.get("n_fft", 2048)
+        hop = kwargs.get("hop_length", 512)
+        X = stft(y, n_fft=n_fft, hop_length=hop, win_length=kwargs.get("win_length"),
+                 window=kwargs.get("window", "hann"), center=kwargs.get("center", True))
+        P = np.abs(X) ** kwargs.get("power", 2.0)
+        M = melspectrogram(P, sr, n_fft, kwargs.get("n_mels", 128), kwargs.get("fmin", 0.0),
+                           kwargs.get("fmax"))
+        S = power_to_db(M)
+    S = np.asarray(S, dtype=np.float64)
+    C = scipy.fft.dct(S, axis=-2, type=dct_type, norm=norm)[..., :n_mfcc, :]
+    if lifter > 0:
+        li = np.sin(np.pi * np.arange(1, 1 + n_mfcc, dtype=np.float64) / lifter)
+        C = C * (1 + (lifter / 2) * li[:, None])
+    elif lifter < 0:
+        raise ValueError(f"MFCC lifter={lifter} must be a non-negative number")
+    return C.astype(np.float64)
+
+
+def log_mel_manager(y, sr, n_fft=2048, hop_length=512, center=True, window="hann",
+                    n_mels=128, fmin=0.0, fmax=None, power=2.0):
+    """The manager's cached chain: manager.py:177-227 (ref=np.max, top_db 80)."""
+    S_mag = np.abs(stft(y, n_fft, hop_length, n_fft, window, center))
+    M = melspectrogram(S_mag ** power, sr, n_fft, n_mels, fmin, sr / 2.0 if fmax is None else fmax)
+    return power_to_db(M, ref=np.max), S_mag
+
+
+def mfcc_manager(y, sr, n_fft=2048, hop_length=512, center=True, window="hann",
+                 n_mels=128, n_mfcc=13, fmin=0.0, fmax=None, power=2.0, lifter=0.0):
+    """[n_mfcc, T] -- the graded path a1->a2->a3->a4->a5 for one clip."""
+    L, _ = log_mel_manager(y, sr, n_fft, hop_length, center, window, n_mels, fmin, fmax, power)
+    return mfcc(S=L, sr=sr, n_mfcc=n_mfcc, lifter=lifter)
+
+
+# --------------------------------------------------------------------------
+# a6/a7/a9 per-frame spectral features (frequency_domain.py:24-386)
+# --------------------------------------------------------------------------
+def spectral_centroid(mag, freqs) -> np.float64:
+    mag = np.asarray(mag, dtype=np.float64); freqs = np.asarray(freqs, dtype=np.float64)
+    if mag.shape != freqs.shape:
+        raise ValueError(f"Spectrum shape {mag.shape} and frequencies shape {freqs.shape} must match.")
+    if mag.size == 0:
+        return np.float64(0.0)
+    mag = np.abs(mag)
+    s = np.sum(mag)
+    if s < EPS64:
+        return np.float64(0.0)
+    return np.float64(np.sum(freqs * mag) / s)
+
+
+def spectral_bandwidth(mag, freqs, centroid=None, p=2) -> np.float64:
+    mag = np.asarray(mag, dtype=np.float64); freqs = np.asarray(freqs, dtype=np.float64)
+    if mag.shape != freqs.shape:
+        raise ValueError(f"Spectrum shape {mag.shape} and frequencies shape {freqs.shape} must match.")
+    if p <= 0:
+        raise ValueError("Order 'p' for spectral bandwidth must be positive.")
+    if mag.size == 0:
+        return np.float64(0.0)
+    mag = np.abs(mag)
+    s = np.sum(mag)
+    if s < EPS64:
+        return np.float64(0.0)
+    if centroid is None:
+        centroid = spectral_centroid(mag, freqs)
+    dev = np.sum(mag * np.abs(freqs - centroid) ** p)
+    dev = max(dev, 0.0)
+    return np.float64((dev / s) ** (1.0 / p))
+
+
+def spectral_flatness(mag) -> np.float64:
+    mag = np.asarray(mag, dtype=np.float64)
+    if mag.size == 0:
+        return np.float64(0.0)
+    mag = np.abs(mag)
+    gm = np.exp(np.mean(np.log(mag + EPS64)))
+    am = np.mean(mag)
+    if am < EPS64:
+        return np.float64(0.0)
+    return np.float64(np.clip(gm / am, 0.0, 1.0))
+
+
+def spectral_rolloff(mag, freqs, roll_percent=0.85) -> np.float64:
+    mag = np.asarray(mag, dtype=np.float64); freqs = np.asarray(freqs, dtype=np.float64)
+    if mag.shape != freqs.shape:
+        raise ValueError(f"Spectrum shape {mag.shape} and frequencies shape {freqs.shape} must match.")
+    if not 0.0 <= roll_percent <= 1.0:
+        raise ValueError("roll_percent must be between 0.0 and 1.0.")
+    if mag.size == 0:
+        return np.float64(0.0)
+    pw = np.abs(mag) ** 2                       # on POWER, frequency_domain.py:325
+    tot = np.sum(pw)
+    if tot < EPS64:
+        return np.float64(freqs[-1])
+    hit = np.nonzero(np.cumsum(pw) >= roll_percent * tot)[0]
+    if hit.size == 0:
+        return np.float64(freqs[-1])
+    return np.float64(freqs[hit[0]])
+
+
+def dominant_frequency(mag, freqs) -> np.float64:
+    mag = np.asarray(mag, dtype=np.float64); freqs = np.asarray(freqs, dtype=np.float64)
+    if mag.shape != freqs.shape:
+        raise ValueError(f"Spectrum shape {mag.shape} and frequencies shape {freqs.shape} must match.")
+    if mag.size == 0:
+        return np.float64(0.0)
+    return np.float64(freqs[int(np.argmax(mag))])
+
+
+def spectral_stats_frames(S_mag, freqs, roll_percent=0.85, p=2):
+    """Vectorised a6/a7/a9 over all columns of S_mag [F, T] (same formulas).
+
+    Returns dict of [T] arrays plus 'rolloff_bin', 'rolloff_margin',
+    'dominant_bin', 'dominant_margin' (float64 decision margins used by the
+    parity gate for bin-valued outputs).
+    """
+    S = np.abs(np.asarray(S_mag, dtype=np.float64))
+    f = np.asarray(freqs, dtype=np.float64)[:, None]
+    F, T = S.shape
+    s = S.sum(axis=0)
+    ok = s >= EPS64
+    ssafe = np.where(ok, s, 1.0)
+    cen = np.where(ok, (f * S).sum(axis=0) / ssafe, 0.0)
+    bw = np.where(ok, ((S * np.abs(f - cen[None, :]) ** p).sum(axis=0) / ssafe) ** (1.0 / p), 0.0)
+    am = S.mean(axis=0)
+    gm = np.exp(np.log(S + EPS64).mean(axis=0))
+    flat = np.where(am >= EPS64, np.clip(gm / np.where(am >= EPS64, am, 1.0), 0.0, 1.0), 0.0)
+    pw = S ** 2
+    tot = pw.sum(axis=0)
+    cs = np.cumsum(pw, axis=0)
+    thr = roll_percent * tot
+    rb = np.argmax(cs >= thr[None, :], axis=0)
+    rb = np.where(tot < EPS64, F - 1, rb)
+    # decision margin: distance of the threshold from the two neighbouring cumsums
+    lo = np.where(rb > 0, cs[np.maximum(rb - 1, 0), np.arange(T)], -np.inf)
+    hi = cs[rb, np.arange(T)]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rmargin = np.minimum(hi - thr, thr - lo) / np.where(tot > 0, tot, 1.0)
+    db = np.argmax(S, axis=0)
+    top2 = np.sort(S, axis=0)[-2:, :] if F >= 2 else np.vstack([S, S])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dmargin = (top2[1] - top2[0]) / np.where(top2[1] > 0, top2[1], 1.0)
+    fr = np.asarray(freqs, dtype=np.float64)
+    return {
+        "spectral_centroid": cen, "spectral_bandwidth": bw, "spectral_flatness": flat,
+        "spectral_rolloff": fr[rb], "dominant_frequency": fr[db],
+        "rolloff_bin": rb, "rolloff_margin": rmargin, "dominant_bin": db, "dominant_margin": dmargin,
+    }
+
+
+# --------------------------------------------------------------------------
+# a8 spectral contrast (frequency_domain.py:147-212 -> librosa.feature.spectral_contrast)
+# --------------------------------------------------------------------------
+def contrast_bands(freqs, sr, n_bands=6, fmin=200.0, quantile=0.02):
+    """Per-band (bin index array, k) following librosa's band rules."""
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
+    if n_bands < 1 or int(n_bands) != n_bands:
+        raise ValueError("n_bands must be a positive integer")
+    if not 0.0 < quantile < 1.0:
+        raise ValueError("quantile must lie in the range (0, 1)")
+    if fmin <= 0:
+        raise ValueError("fmin must be a positive number")
+    octa = np.zeros(n_bands + 2)
+    octa[1:] = fmin * (2.0 ** np.arange(0, n_bands + 1))
+    if np.any(octa[:-1] >= 0.5 * sr):
+        raise ValueError("Frequency band exceeds Nyquist. Reduce either fmin or n_bands.")
+    out = []
+    for k in range(n_bands + 1):
+        sel = np.logical_and(freqs >= octa[k], freqs <= octa[k + 1])
+        idx = np.flatnonzero(sel)
+        if k > 0:
+            sel[idx[0] - 1] = True
+        if k == n_bands:
+            sel[idx[-1] + 1:] = True
+        cnt = int(np.sum(sel))
+        bins = np.flatnonzero(sel)
+        if k < n_bands:
+            bins = bins[:-1]
+        kk = int(max(np.rint(quantile * cnt), 1))
+        out.append((bins, kk))
+    return out
+
+
+def spectral_contrast(S, sr, n_bands=6, fmin=200.0, freqs=None, quantile=0.02, linear=False):
+    S = np.asarray(S, dtype=np.float64)
+    if S.ndim != 2:
+        raise ValueError("Input S must be a 2D spectrogram (frequency x time).")  # frequency_domain.py:191-192
+    S = np.abs(S)
+    if freqs is None:
+        freqs = fft_frequencies(sr, 2 * (S.shape[0] - 1))
+    freqs = np.atleast_1d(freqs)
+    if freqs.ndim != 1 or len(freqs) != S.shape[0]:
+        raise ValueError(f"freq.shape={freqs.shape} does not match dimensions of S.shape={S.shape}")
+    bands = contrast_bands(freqs, sr, n_bands, fmin, quantile)
+    T = S.shape[1]
+    valley = np.zeros((n_bands + 1, T)); peak = np.zeros((n_bands + 1, T))
+    for k, (bins, kk) in enumerate(bands):
+        srt = np.sort(S[bins, :], axis=0)
+        valley[k] = np.mean(srt[:kk], axis=0)
+        peak[k] = np.mean(srt[-kk:], axis=0)
+    if linear:
+        return peak - valley
+    return power_to_db(peak) - power_to_db(valley)
+
+
+# --------------------------------------------------------------------------
+# a10/a11 fft / ifft / window (dsp.py:40-162, 641-691)
+# --------------------------------------------------------------------------
+def apply_window(data, window_type="hann"):
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    try:
+        w = scipy.signal.get_window(window_type, data.shape[0], fftbins=False)  # symmetric, dsp.py:676
+    except ValueError as e:
+        raise ValueError(f"Invalid window type '{window_type}'.") from e
+    return data * w
+
+
+def compute_fft(data, fs=1.0, n=None, window="hann"):
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    x = apply_window(data, window) if window else data
+    if n is None:
+        n = x.shape[0]
+    return scipy.fft.fftfreq(n, d=1 / fs).astype(np.float64), scipy.fft.fft(x, n=n).astype(np.complex128)
+
+
+def compute_ifft(spectrum, n=None):
+    spectrum = np.asarray(spectrum)
+    if spectrum.ndim != 1:
+        raise ValueError("Input spectrum must be a 1D array.")
+    if n is None:
+        n = spectrum.shape[0]
+    return np.real(scipy.fft.ifft(spectrum, n=n)).astype(np.float64)
+
+
+# --------------------------------------------------------------------------
+# a12/a13 Butterworth SOS + zero-phase filtering (filters.py:22-211)
+# --------------------------------------------------------------------------
+def design_butterworth_sos(cutoff, fs, order, filter_type):
+    nyq = 0.5 * fs
+    if isinstance(cutoff, (int, float)):
+        if not 0 < cutoff < nyq:
+            raise ValueError(f"Cutoff frequency ({cutoff} Hz) must be strictly between 0 and Nyquist ({nyq} Hz).")
+        wn = cutoff / nyq
+    elif isinstance(cutoff, tuple) and len(cutoff) == 2:
+        lo, hi = cutoff
+        if not (0 < lo < nyq and 0 < hi < nyq):
+            raise ValueError(f"Both low ({lo} Hz) and high ({hi} Hz) cutoff frequencies must be strictly between 0 and Nyquist ({nyq} Hz).")
+        if lo >= hi:
+            raise ValueError(f"Low cutoff ({lo} Hz) must be less than high cutoff ({hi} Hz).")
+        wn = (lo / nyq, hi / nyq)
+    else:
+        raise TypeError("cutoff must be a float (for low/high pass) or a tuple of two floats (for band pass/stop).")
+    return scipy.signal.butter(order, wn, btype=filter_type, analog=False, output="sos").astype(np.float64)
+
+
+def sosfiltfilt_padlen(sos) -> int:
+    """scipy.signal.sosfiltfilt default edge length (padtype='odd', padlen=None)."""
+    sos = np.asarray(sos, dtype=np.float64)
+    ntaps = 2 * sos.shape[0] + 1
+    ntaps -= min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum()))
+    return 3 * ntaps
+
+
+def sosfilt_zi(sos) -> np.ndarray:
+    """Steady-state DF2T initial state per section for a unit step (scipy.signal.sosfilt_zi)."""
+    sos = np.asarray(sos, dtype=np.float64)
+    zi = np.zeros((sos.shape[0], 2))
+    scale = 1.0
+    for s in range(sos.shape[0]):
+        b = sos[s, :3] / sos[s, 3]
+        a = sos[s, 3:] / sos[s, 3]
+        # solve (I - A^T) z = b[1:] - a[1:] b0 for the DF2T companion matrix
+        IminusA = np.array([[1.0 + a[1], -1.0], [a[2], 1.0]])
+        rhs = np.array([b[1] - a[1] * b[0], b[2] - a[2] * b[0]])
+        zi[s] = scale * np.linalg.solve(IminusA, rhs)
+        scale *= b.sum() / a.sum()
+    return zi
+
+
+def sosfilt_explicit(sos, x, zi):
+    """Direct-form-II-transposed cascade, pure Python/NumPy scalar loop (small inputs only)."""
+    sos = np.asarray(sos, dtype=np.float64)
+    y = np.array(x, dtype=np.float64)
+    z = np.array(zi, dtype=np.float64)
+    for s in range(sos.shape[0]):
+        b0, b1, b2, a0, a1, a2 = sos[s]
+        b0, b1, b2, a1, a2 = b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0
+        z0, z1 = z[s]
+        for n in range(y.shape[0]):
+            xn = y[n]
+            yn = b0 * xn + z0
+            z0 = b1 * xn - a1 * yn + z1
+            z1 = b2 * xn - a2 * yn
+            y[n] = yn
+        z[s] = (z0, z1)
+    return y, z
+
+
+def sosfiltfilt_explicit(sos, x):
+    """Restatement of scipy.signal.sosfiltfilt(sos, x) (odd extension, zi-scaled, fwd+bwd)."""
+    x = np.asarray(x, dtype=np.float64)
+    edge = sosfiltfilt_padlen(sos)
+    if x.shape[0] <= edge:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+    ext = np.concatenate([2 * x[0] - x[edge:0:-1], x, 2 * x[-1] - x[-2:-(edge + 2):-1]])
+    zi = sosfilt_zi(sos)
+    y, _ = sosfilt_explicit(sos, ext, zi * ext[0])
+    y, _ = sosfilt_explicit(sos, y[::-1], zi * y[-1])
+    return y[::-1][edge:-edge]
+
+
+def apply_sos_filter(sos, data):
+    data = np.asarray(data, dtype=np.float64); sos = np.asarray(sos, dtype=np.float64)
+    if data.ndim != 1:
+        raise ValueError("Input data for filtering must be a 1D array.")
+    if sos.ndim != 2 or sos.shape[1] != 6:
+        raise ValueError("Input sos must be a 2D array with shape (n_sections, 6).")
+    return scipy.signal.sosfiltfilt(sos, data).astype(np.float64)
+
+
+def low_pass_filter(data, cutoff, fs, order=5):
+    return apply_sos_filter(design_butterworth_sos(cutoff, fs, order, "lowpass"), data)
+
+
+def high_pass_filter(data, cutoff, fs, order=5):
+    return apply_sos_filter(design_butterworth_sos(cutoff, fs, order, "highpass"), data)
+
+
+def band_pass_filter(data, low_cutoff, high_cutoff, fs, order=5):
+    return apply_sos_filter(design_butterworth_sos((low_cutoff, high_cutoff), fs, order, "bandpass"), data)
+
+
+def band_stop_filter(data, low_cutoff, high_cutoff, fs, order=5):
+    return apply_sos_filter(design_butterworth_sos((low_cutoff, high_cutoff), fs, order, "bandstop"), data)
+
+
+# --------------------------------------------------------------------------
+# a14 Welch (dsp.py:495-560 -> scipy.signal.welch)
+# --------------------------------------------------------------------------
+def compute_psd_welch(x, fs=1.0, window="hann", nperseg=None, noverlap=None, nfft=None,
+                      detrend="constant", scaling="density"):
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    f, p = scipy.signal.welch(x, fs=fs, window=window, nperseg=nperseg, noverlap=noverlap, nfft=nfft,
+                              detrend=detrend, return_onesided=True, scaling=scaling)
+    return f.astype(np.float64), p.astype(np.float64)
+
+
+def welch_explicit(x, fs=1.0, window="hann", nperseg=256, noverlap=None, nfft=None,
+                   detrend="constant", scaling="density"):
+    """Explicit restatement of scipy.signal.welch for 1-D real x (validates the SciPy call)."""
+    x = np.asarray(x, dtype=np.float64)
+    if nperseg > x.shape[0]:
+        nperseg = x.shape[0]
+    if noverlap is None:
+        noverlap = nperseg // 2
+    if nfft is None:
+        nfft = nperseg
+    step = nperseg - noverlap
+    w = scipy.signal.get_window(window, nperseg)  # periodic (fftbins=True default)
+    nseg = (x.shape[0] - noverlap) // step
+    idx = np.arange(nperseg)[None, :] + step * np.arange(nseg)[:, None]
+    seg = x[idx]
+    if detrend == "constant":
+        seg = seg - seg.mean(axis=1, keepdims=True)
+    elif detrend == "linear":
+        seg = scipy.signal.detrend(seg, axis=1, type="linear")
+    X = np.fft.rfft(seg * w[None, :], n=nfft, axis=1)
+    scale = 1.0 / (fs * (w * w).sum()) if scaling == "density" else 1.0 / w.sum() ** 2
+    P = (np.abs(X) ** 2) * scale
+    if nfft % 2:
+        P[:, 1:] *= 2
+    else:
+        P[:, 1:-1] *= 2
+    return np.fft.rfftfreq(nfft, 1 / fs), P.mean(axis=0)
+
+
+# --------------------------------------------------------------------------
+# a16 extract_features orchestration (manager.py:78-445), dict_of_arrays form
+# --------------------------------------------------------------------------
+SPECTRUM_FEATURES = ("spectral_centroid", "spectral_bandwidth", "spectral_flatness",
+                     "spectral_rolloff", "dominant_frequency")
+KNOWN_FEATURES = set(SPECTRUM_FEATURES) | {"spectral_contrast", "mfcc"}
+
+
+def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=True,
+                     window="hann", feature_params=None, per_frame_loop=False):
+    """Oracle for the spectrum / spectrogram / mel feature groups (dict_of_arrays).
+
+    ``per_frame_loop=True`` drives a6/a7/a9 one frame at a time exactly as
+    manager.py:304-316 does (used for the 'reference-equivalent' CPU timing).
+    """
+    feature_params = feature_params or {}
+    y = np.asarray(y, dtype=np.float64)
+    unknown = [f for f in features if f not in KNOWN_FEATURES]
+    if unknown:
+        raise ValueError(f"Unknown feature(s) requested: {unknown}.")
+    if y.ndim != 1:
+        raise ValueError("Input audio signal 'y' must be a 1D array.")
+    T = num_frames(len(y), frame_length, hop_length, center)
+    if T <= 0:
+        return {"time": np.array([], dtype=np.float64)}
+    res = {"time": frames_to_time(np.arange(T), sr, hop_length, frame_length if center else None).astype(np.float64)}
+    S_mag = np.abs(stft(y, frame_length, hop_length, frame_length, window, center))
+    freqs = fft_frequencies(sr, frame_length)
+    stats = None
+    for name in features:
+        p = feature_params.get(name, {})
+        if name in SPECTRUM_FEATURES:
+            if per_frame_loop:
+                fn = {"spectral_centroid": spectral_centroid, "spectral_bandwidth": spectral_bandwidth,
+                      "spectral_flatness": spectral_flatness, "spectral_rolloff": spectral_rolloff,
+                      "dominant_frequency": dominant_frequency}[name]
+                if name == "spectral_flatness":
+                    vals = [fn(S_mag[:, i]) for i in range(S_mag.shape[1])]
+                else:
+                    vals = [fn(S_mag[:, i], freqs, **p) for i in range(S_mag.shape[1])]
+                res[name] = np.array(vals, dtype=np.float64)
+            else:
+                if stats is None:
+                    stats = spectral_stats_frames(
+                        S_mag, freqs,
+                        roll_percent=feature_params.get("spectral_rolloff", {}).get("roll_percent", 0.85),
+                        p=feature_params.get("spectral_bandwidth", {}).get("p", 2))
+                res[name] = stats[name]
+        elif name == "spectral_contrast":
+            C = spectral_contrast(S_mag, sr, freqs=freqs, **p)
+            for i in range(C.shape[0] - 1):
+                res[f"contrast_band_{i}"] = C[i]
+            res["contrast_delta"] = C[-1]
+        elif name == "mfcc":
+            mp = feature_params.get("mfcc", {})
+            M = melspectrogram(S_mag ** mp.get("power", 2.0), sr, frame_length, mp.get("n_mels", 128),
+                               mp.get("fmin", 0.0), mp.get("fmax", sr / 2.0))
+            Ldb = power_to_db(M, ref=np.max)
+            C = mfcc(S=Ldb, sr=sr, n_mfcc=mp.get("n_mfcc", 13), dct_type=mp.get("dct_type", 2),
+                     norm=mp.get("norm", "ortho"), lifter=mp.get("lifter", 0.0))
+            for i in range(C.shape[0]):
+                res[f"mfcc_{i}"] = C[i]
+    return res
+
+
+# --------------------------------------------------------------------------
+# batched helpers + the synthetic workload of SURVEY section 8d
+# --------------------------------------------------------------------------
+def synth_clips(n_clips, length=48000, sr=48000, seed=20250523, dtype=np.float32):
+    """3 random sines + white noise per clip, peak <= 0.9 (SURVEY 8d recipe)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(length, dtype=np.float64) / sr
+    out = np.empty((n_clips, length), dtype=dtype)
+    for i in range(n_clips):
+        f = rng.uniform(50.0, 20000.0 if sr >= 44100 else 0.45 * sr, 3)
+        a = rng.uniform(0.05, 0.3, 3)
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        y = (a[:, None] * np.sin(2 * np.pi * f[:, None] * t[None, :] + ph[:, None])).sum(axis=0)
+        y += rng.normal(0.0, 0.05, length)
+        y *= 0.9 / max(np.abs(y).max(), 1e-12) if np.abs(y).max() > 0.9 else 1.0
+        out[i] = y.astype(dtype)
+    return out
+
+
+def mfcc_batch(Y, sr, n_fft=2048, hop_length=512, n_mels=40, n_mfcc=13, center=True, window="hann",
+               fmin=0.0, fmax=None, lifter=0.0):
+    """[B, n_mfcc, T] float64 -- config C2 for a batch of clips, one clip at a time."""
+    return np.stack([mfcc_manager(np.asarray(y, dtype=np.float64), sr, n_fft, hop_length, center, window,
+                                  n_mels, n_mfcc, fmin, fmax, 2.0, lifter) for y in Y])

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by EXECUTING the reference's own functions.
+
+Run once in the build container (needs /root/reference; never runs on the GPU
+box):   python tests/golden/make_golden.py
+
+What is executed: the SciPy/NumPy-backed functions of
+  sygnals/core/filters.py                      (loads as-is)
+  sygnals/core/dsp.py                          (compute_fft/ifft, apply_window, compute_psd_welch)
+  sygnals/core/features/frequency_domain.py    (the five per-frame functions)
+loaded BY FILE PATH (``sygnals/core/__init__.py`` pulls pandasql/soundfile,
+which are not installed).  dsp.py and frequency_domain.py have a top-level
+``import librosa``; librosa is not installed, so an EMPTY placeholder module is
+registered under that name only to let the import statement pass.  The
+placeholder defines nothing: any reference function that would touch librosa
+raises AttributeError, and none of those is used below -- every number written
+here comes out of the reference's code running on the real SciPy/NumPy.
+
+Only inputs and outputs (data) are stored; no reference source is copied.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference/sygnals/core"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_signal(rng, n, fs):
+    t = np.arange(n) / fs
+    f = rng.uniform(0.01 * fs, 0.4 * fs, 3)
+    a = rng.uniform(0.1, 0.5, 3)
+    ph = rng.uniform(0, 2 * np.pi, 3)
+    y = (a[:, None] * np.sin(2 * np.pi * f[:, None] * t[None, :] + ph[:, None])).sum(0)
+    return y + rng.normal(0, 0.05, n)
+
+
+def main():
+    if "librosa" not in sys.modules:
+        sys.modules["librosa"] = types.ModuleType("librosa")  # empty placeholder, see docstring
+    filters = load("ref_filters", "filters.py")
+    dsp = load("ref_dsp", "dsp.py")
+    fd = load("ref_freq", "features/frequency_domain.py")
+    rng = np.random.default_rng(20250523)
+
+    # ---- filters.py -----------------------------------------------------
+    g = {}
+    designs = [
+        ("bp4_48k", (300.0, 3400.0), 48000.0, 4, "bandpass"),
+        ("lp5_1k", 100.0, 1000.0, 5, "lowpass"),
+        ("hp5_1k", 100.0, 1000.0, 5, "highpass"),
+        ("bs5_1k", (100.0, 200.0), 1000.0, 5, "bandstop"),
+        ("lp8_1k", 100.0, 1000.0, 8, "lowpass"),
+        ("bp2_16k", (500.0, 2000.0), 16000.0, 2, "bandpass"),
+    ]
+    for name, cutoff, fs, order, kind in designs:
+        sos = filters.design_butterworth_sos(cutoff, fs, order, kind)
+        x = test_signal(rng, 3000 if fs > 2000 else 2000, fs)
+        g[f"{name}_sos"] = sos
+        g[f"{name}_x"] = x
+        g[f"{name}_y"] = filters.apply_sos_filter(sos, x)
+    x = test_signal(rng, 6000, 48000.0)
+    g["conv_x"] = x
+    g["conv_bp"] = filters.band_pass_filter(x, 300.0, 3400.0, 48000.0, order=4)
+    g["conv_lp"] = filters.low_pass_filter(x, 4000.0, 48000.0)
+    g["conv_hp"] = filters.high_pass_filter(x, 4000.0, 48000.0)
+    g["conv_bs"] = filters.band_stop_filter(x, 1000.0, 5000.0, 48000.0)
+    np.savez_compressed(os.path.join(OUT, "ref_filters.npz"), **g)
+
+    # ---- dsp.py ---------------------------------------------------------
+    g = {}
+    x = test_signal(rng, 1000, 1000.0)
+    g["x1000"] = x
+    for win in ("hann", "hamming", "blackman", None):
+        for n in (None, 1024, 512, 1500):
+            fr, sp = dsp.compute_fft(x, fs=1000.0, n=n, window=win)
+            key = f"fft_{win}_{n}"
+            g[key + "_f"] = fr
+            g[key + "_s"] = sp
+    fr, sp = dsp.compute_fft(x, fs=1000.0, window=None)
+    g["ifft_none"] = dsp.compute_ifft(sp)
+    g["ifft_n768"] = dsp.compute_ifft(sp, n=768)
+    g["ifft_n1200"] = dsp.compute_ifft(sp, n=1200)
+    x2 = test_signal(rng, 4096, 48000.0)
+    g["x4096"] = x2
+    fr, sp = dsp.compute_fft(x2, fs=48000.0)
+    g["fft4096_f"], g["fft4096_s"] = fr, sp
+    for w in ("hann", "hamming", "blackman", "bartlett", "boxcar"):
+        g[f"win_{w}"] = dsp.apply_window(x, w)
+    x3 = test_signal(rng, 20000, 48000.0) + 0.3  # DC offset exercises detrend
+    g["x20000"] = x3
+    for tag, kw in (("w4096", dict(nperseg=4096)), ("w256", dict(nperseg=256)),
+                    ("w1024o768", dict(nperseg=1024, noverlap=768)),
+                    ("w512nfft1024", dict(nperseg=512, nfft=1024)),
+                    ("w1024spec", dict(nperseg=1024, scaling="spectrum")),
+                    ("w1024nodet", dict(nperseg=1024, detrend=False)),
+                    ("w1024hamming", dict(nperseg=1024, window="hamming"))):
+        f, p = dsp.compute_psd_welch(x3, fs=48000.0, **kw)
+        g[f"welch_{tag}_f"], g[f"welch_{tag}_p"] = f, p
+    np.savez_compressed(os.path.join(OUT, "ref_dsp.npz"), **g)
+
+    # ---- frequency_domain.py -------------------------------------------
+    g = {}
+    F = 1025
+    freqs = np.fft.rfftfreq(2048, 1 / 48000.0)
+    spectra = np.abs(rng.normal(0, 1, (24, F))) * np.exp(-np.linspace(0, rng.uniform(1, 6), F))[None, :]
+    spectra[3] = 0.0                       # all-zero frame
+    spectra[4] = 0.0; spectra[4, 100] = 1.0  # single peak
+    spectra[5] = 1.0                       # flat
+    spectra[6] *= 1e-9                     # tiny but non-zero
+    g["freqs"] = freqs
+    g["spectra"] = spectra
+    g["centroid"] = np.array([fd.spectral_centroid(s, freqs) for s in spectra])
+    g["bandwidth"] = np.array([fd.spectral_bandwidth(s, freqs) for s in spectra])
+    g["bandwidth_p1"] = np.array([fd.spectral_bandwidth(s, freqs, p=1) for s in spectra])
+    g["bandwidth_c"] = np.array([fd.spectral_bandwidth(s, freqs, centroid=np.float64(5000.0)) for s in spectra])
+    g["flatness"] = np.array([fd.spectral_flatness(s) for s in spectra])
+    g["rolloff85"] = np.array([fd.spectral_rolloff(s, freqs) for s in spectra])
+    g["rolloff50"] = np.array([fd.spectral_rolloff(s, freqs, roll_percent=0.5) for s in spectra])
+    g["rolloff100"] = np.array([fd.spectral_rolloff(s, freqs, roll_percent=1.0) for s in spectra])
+    g["rolloff0"] = np.array([fd.spectral_rolloff(s, freqs, roll_percent=0.0) for s in spectra])
+    g["dominant"] = np.array([fd.dominant_frequency(s, freqs) for s in spectra])
+    e = np.array([], dtype=np.float64)
+    g["empty"] = np.array([fd.spectral_centroid(e, e), fd.spectral_bandwidth(e, e), fd.spectral_flatness(e),
+                           fd.spectral_rolloff(e, e), fd.dominant_frequency(e, e)])
+    np.savez_compressed(os.path.join(OUT, "ref_freq.npz"), **g)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,148 @@
+"""Pin the oracle against golden vectors produced by the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+from oracle import cpu_ref as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gf():
+    return np.load(os.path.join(G, "ref_filters.npz"))
+
+
+@pytest.fixture(scope="module")
+def gd():
+    return np.load(os.path.join(G, "ref_dsp.npz"))
+
+
+@pytest.fixture(scope="module")
+def gq():
+    return np.load(os.path.join(G, "ref_freq.npz"))
+
+
+DESIGNS = [("bp4_48k", (300.0, 3400.0), 48000.0, 4, "bandpass"), ("lp5_1k", 100.0, 1000.0, 5, "lowpass"),
+           ("hp5_1k", 100.0, 1000.0, 5, "highpass"), ("bs5_1k", (100.0, 200.0), 1000.0, 5, "bandstop"),
+           ("lp8_1k", 100.0, 1000.0, 8, "lowpass"), ("bp2_16k", (500.0, 2000.0), 16000.0, 2, "bandpass")]
+
+
+@pytest.mark.parametrize("name,cutoff,fs,order,kind", DESIGNS)
+def test_butterworth_design_and_filtfilt(gf, name, cutoff, fs, order, kind):
+    sos = O.design_butterworth_sos(cutoff, fs, order, kind)
+    assert_array_equal(sos, gf[f"{name}_sos"])
+    y = O.apply_sos_filter(sos, gf[f"{name}_x"])
+    assert_array_equal(y, gf[f"{name}_y"])
+
+
+@pytest.mark.parametrize("name", ["bp4_48k", "lp5_1k", "bs5_1k"])
+def test_filtfilt_explicit_restatement(gf, name):
+    """The explicit odd-extension / zi / fwd-bwd restatement reproduces the reference output."""
+    y = O.sosfiltfilt_explicit(gf[f"{name}_sos"], gf[f"{name}_x"])
+    ref = gf[f"{name}_y"]
+    assert np.max(np.abs(y - ref)) <= 1e-11 * np.max(np.abs(ref))
+
+
+def test_padlen_c3_filter(gf):
+    assert O.sosfiltfilt_padlen(gf["bp4_48k_sos"]) == 27
+    assert gf["bp4_48k_sos"].shape == (4, 6)
+
+
+def test_convenience_filters(gf):
+    x = gf["conv_x"]
+    assert_array_equal(O.band_pass_filter(x, 300.0, 3400.0, 48000.0, order=4), gf["conv_bp"])
+    assert_array_equal(O.low_pass_filter(x, 4000.0, 48000.0), gf["conv_lp"])
+    assert_array_equal(O.high_pass_filter(x, 4000.0, 48000.0), gf["conv_hp"])
+    assert_array_equal(O.band_stop_filter(x, 1000.0, 5000.0, 48000.0), gf["conv_bs"])
+
+
+def test_filter_error_strings():
+    # strings pinned by reference tests/test_filters.py:73-87
+    with pytest.raises(ValueError, match="strictly between 0 and Nyquist"):
+        O.design_butterworth_sos(500.0, 1000.0, 4, "lowpass")
+    with pytest.raises(ValueError, match="Low cutoff .* must be less than high cutoff"):
+        O.design_butterworth_sos((200.0, 100.0), 1000.0, 4, "bandpass")
+    with pytest.raises(TypeError, match="cutoff must be a float .* or a tuple"):
+        O.design_butterworth_sos([100.0], 1000.0, 4, "lowpass")
+
+
+@pytest.mark.parametrize("win", ["hann", "hamming", "blackman", None])
+@pytest.mark.parametrize("n", [None, 1024, 512, 1500])
+def test_compute_fft(gd, win, n):
+    f, s = O.compute_fft(gd["x1000"], fs=1000.0, n=n, window=win)
+    assert_array_equal(f, gd[f"fft_{win}_{n}_f"])
+    assert_array_equal(s, gd[f"fft_{win}_{n}_s"])
+    assert s.dtype == np.complex128 and f.dtype == np.float64
+
+
+def test_compute_ifft(gd):
+    _, sp = O.compute_fft(gd["x1000"], fs=1000.0, window=None)
+    assert_array_equal(O.compute_ifft(sp), gd["ifft_none"])
+    assert_array_equal(O.compute_ifft(sp, n=768), gd["ifft_n768"])
+    assert_array_equal(O.compute_ifft(sp, n=1200), gd["ifft_n1200"])
+    assert_allclose(gd["ifft_none"], gd["x1000"], atol=1e-9, rtol=1e-7)  # reference tests/test_dsp.py:69-76
+
+
+@pytest.mark.parametrize("w", ["hann", "hamming", "blackman", "bartlett", "boxcar"])
+def test_apply_window(gd, w):
+    assert_array_equal(O.apply_window(gd["x1000"], w), gd[f"win_{w}"])
+
+
+def test_apply_window_bad_name():
+    with pytest.raises(ValueError, match="Invalid window type 'nope'"):
+        O.apply_window(np.ones(8), "nope")
+
+
+WELCH = [("w4096", dict(nperseg=4096)), ("w256", dict(nperseg=256)), ("w1024o768", dict(nperseg=1024, noverlap=768)),
+         ("w512nfft1024", dict(nperseg=512, nfft=1024)), ("w1024spec", dict(nperseg=1024, scaling="spectrum")),
+         ("w1024nodet", dict(nperseg=1024, detrend=False)), ("w1024hamming", dict(nperseg=1024, window="hamming"))]
+
+
+@pytest.mark.parametrize("tag,kw", WELCH)
+def test_welch(gd, tag, kw):
+    f, p = O.compute_psd_welch(gd["x20000"], fs=48000.0, **kw)
+    assert_array_equal(f, gd[f"welch_{tag}_f"])
+    assert_array_equal(p, gd[f"welch_{tag}_p"])
+    f2, p2 = O.welch_explicit(gd["x20000"], fs=48000.0, **{"nperseg": 256, **kw})
+    assert_allclose(f2, f, rtol=0, atol=1e-9)
+    assert np.max(np.abs(p2 - p)) <= 1e-12 * np.max(np.abs(p))
+
+
+def test_per_frame_spectral_functions(gq):
+    S, fr = gq["spectra"], gq["freqs"]
+    assert_array_equal(np.array([O.spectral_centroid(s, fr) for s in S]), gq["centroid"])
+    assert_array_equal(np.array([O.spectral_bandwidth(s, fr) for s in S]), gq["bandwidth"])
+    assert_array_equal(np.array([O.spectral_bandwidth(s, fr, p=1) for s in S]), gq["bandwidth_p1"])
+    assert_array_equal(np.array([O.spectral_bandwidth(s, fr, centroid=5000.0) for s in S]), gq["bandwidth_c"])
+    assert_array_equal(np.array([O.spectral_flatness(s) for s in S]), gq["flatness"])
+    assert_array_equal(np.array([O.spectral_rolloff(s, fr) for s in S]), gq["rolloff85"])
+    assert_array_equal(np.array([O.spectral_rolloff(s, fr, roll_percent=0.5) for s in S]), gq["rolloff50"])
+    assert_array_equal(np.array([O.spectral_rolloff(s, fr, roll_percent=1.0) for s in S]), gq["rolloff100"])
+    assert_array_equal(np.array([O.spectral_rolloff(s, fr, roll_percent=0.0) for s in S]), gq["rolloff0"])
+    assert_array_equal(np.array([O.dominant_frequency(s, fr) for s in S]), gq["dominant"])
+
+
+def test_per_frame_edge_cases(gq):
+    e = np.array([], dtype=np.float64)
+    got = np.array([O.spectral_centroid(e, e), O.spectral_bandwidth(e, e), O.spectral_flatness(e),
+                    O.spectral_rolloff(e, e), O.dominant_frequency(e, e)])
+    assert_array_equal(got, gq["empty"])
+    # all-zero frame (reference tests/test_features_freq.py:95-101 etc.)
+    z, fr = gq["spectra"][3], gq["freqs"]
+    assert O.spectral_centroid(z, fr) == 0.0 and O.spectral_bandwidth(z, fr) == 0.0
+    assert O.spectral_flatness(z) == 0.0 and O.spectral_rolloff(z, fr) == fr[-1]
+    assert O.dominant_frequency(z, fr) == fr[0]
+
+
+def test_vectorised_stats_match_per_frame(gq):
+    S, fr = gq["spectra"], gq["freqs"]
+    st = O.spectral_stats_frames(S.T, fr)
+    assert_allclose(st["spectral_centroid"], gq["centroid"], rtol=1e-13, atol=1e-9)
+    assert_allclose(st["spectral_bandwidth"], gq["bandwidth"], rtol=1e-12, atol=1e-9)
+    assert_allclose(st["spectral_flatness"], gq["flatness"], rtol=1e-12, atol=1e-15)
+    assert_array_equal(st["spectral_rolloff"], gq["rolloff85"])
+    assert_array_equal(st["dominant_frequency"], gq["dominant"])

@@ -1,0 +1,182 @@
+"""Anchors for the librosa-backed rows of the oracle ("parity unpinned": librosa is
+neither vendored under the reference nor installed).  librosa's documented examples,
+closed-form known answers and independent SciPy cross-checks.  CPU only."""
+import numpy as np
+import pytest
+import scipy.fft
+import scipy.signal
+from numpy.testing import assert_allclose, assert_array_equal
+
+from oracle import cpu_ref as O
+
+# librosa documentation example: librosa.mel_frequencies(n_mels=40)
+DOC_MEL_FREQS_40 = np.array([
+    0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49,
+    1024.856, 1119.114, 1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393,
+    2470.47, 2697.686, 2945.799, 3216.731, 3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621,
+    5955.205, 6502.92, 7101.009, 7754.107, 8467.272, 9246.028, 10096.408, 11025.])
+
+
+def test_doc_mel_frequencies():
+    assert_allclose(O.mel_frequencies(40), DOC_MEL_FREQS_40, atol=6e-4, rtol=0)
+
+
+def test_doc_hz_mel_conversions():
+    assert_allclose(O.hz_to_mel(60), 0.9, rtol=1e-12)
+    assert_allclose(O.hz_to_mel([110, 220, 440]), [1.65, 3.3, 6.6], rtol=1e-12)
+    assert_allclose(O.mel_to_hz(3), 200.0, rtol=1e-12)
+    assert_allclose(O.mel_to_hz([1, 2, 3, 4, 5]), [66.667, 133.333, 200., 266.667, 333.333], atol=6e-4)
+    f = np.array([10., 999., 1000., 1001., 8000., 24000.])
+    assert_allclose(O.mel_to_hz(O.hz_to_mel(f)), f, rtol=1e-12)
+
+
+def test_doc_fft_frequencies():
+    assert_allclose(O.fft_frequencies(22050, 16),
+                    [0., 1378.125, 2756.25, 4134.375, 5512.5, 6890.625, 8268.75, 9646.875, 11025.])
+
+
+def test_frames_to_time_rule():
+    # reference manager.py:166-169 semantics
+    assert_allclose(O.frames_to_time(np.arange(3), 48000, 512, 2048), (np.arange(3) * 512 + 1024) / 48000)
+    assert_allclose(O.frames_to_time(np.arange(3), 48000, 512, None), np.arange(3) * 512 / 48000)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 512), (512, 100), (256, 64)])
+def test_stft_vs_scipy_stft(n_fft, hop):
+    rng = np.random.default_rng(1)
+    y = rng.normal(size=6000)
+    X = O.stft(y, n_fft, hop)
+    w = scipy.signal.get_window("hann", n_fft)
+    _, _, Z = scipy.signal.stft(y, window="hann", nperseg=n_fft, noverlap=n_fft - hop, boundary="zeros",
+                                padded=False, scaling="spectrum")
+    assert X.shape == (1 + n_fft // 2, 1 + len(y) // hop) and X.dtype == np.complex128
+    assert np.abs(Z * w.sum() - X).max() <= 1e-12 * np.abs(X).max()
+
+
+def test_stft_frame_counts_reference_cases():
+    # reference tests/test_features_manager.py:183-220
+    assert O.stft(np.ones(512), 1024, 256).shape[1] == 3
+    assert O.stft(np.ones(100), 2048, 512).shape[1] == 1
+    assert O.num_frames(48000, 2048, 512, True) == 94
+    assert O.num_frames(160000, 2048, 512, True) == 313
+    assert O.num_frames(100, 2048, 512, False) == 0
+    assert O.stft(np.ones(4096), 1024, 256, center=False).shape[1] == 13
+
+
+def test_stft_closed_form():
+    n = 2048
+    imp = np.zeros(4096); imp[1024] = 1.0
+    X = O.stft(imp, n, 512)
+    assert_allclose(np.abs(X[:, 2]), 1.0, rtol=1e-12)       # impulse at window centre -> flat |X| = w[n/2] = 1
+    t = np.arange(8192)
+    X = O.stft(np.cos(2 * np.pi * 100 * t / n), n, 512, center=False)
+    assert_allclose(np.abs(X[100, 1]), n / 4, rtol=1e-12)   # N/2 * mean(hann)
+    assert_allclose(np.abs(X[99, 1]), n / 8, rtol=1e-10)
+    assert np.abs(X[103:, 1]).max() < 1e-9
+
+
+def test_stft_short_window_is_centre_padded():
+    rng = np.random.default_rng(2)
+    y = rng.normal(size=3000)
+    X = O.stft(y, 512, 128, win_length=256)
+    w = np.zeros(512); w[128:384] = scipy.signal.get_window("hann", 256)
+    fr = O.frame_signal(y, 512, 128, True)
+    assert_allclose(X, np.fft.rfft(fr * w, axis=1).T)
+
+
+def test_mel_filterbank_structure():
+    W = O.mel_filterbank(48000, 2048, 40)
+    assert W.dtype == np.float32 and W.shape == (40, 1025)
+    assert (W >= 0).all() and ((W > 0).sum(axis=0) <= 2).all()
+    area = W.astype(np.float64).sum(axis=1) * 48000 / 2048      # Slaney normalisation: unit area
+    assert_allclose(area[12:], 1.0, atol=5e-3)
+    # each row is a triangle peaking between its neighbours' peaks
+    pk = W.argmax(axis=1)
+    assert (np.diff(pk) > 0).all()
+    W128 = O.mel_filterbank(16000, 2048)                        # C1 defaults: 128 mels, fmax = sr/2
+    assert W128.shape == (128, 1025)
+    # float32 storage is part of librosa's behaviour (dtype=np.float32 default)
+    W64 = O.mel_filterbank(48000, 2048, 40).astype(np.float64)
+    assert (W64 == W).all()
+
+
+def test_power_to_db():
+    S = np.array([[1.0, 10.0, 1e-12], [100.0, 1e-9, 0.0]])
+    d = O.power_to_db(S, ref=1.0, top_db=None)
+    assert_allclose(d, [[0, 10, -100], [20, -90, -100]])
+    d = O.power_to_db(S, ref=np.max)
+    assert_allclose(d, [[-20, -10, -80], [0, -80, -80]])          # clamp at max-80
+    d = O.power_to_db(S, ref=np.max, top_db=30.0)
+    assert_allclose(d, [[-20, -10, -30], [0, -30, -30]])
+    assert_allclose(O.power_to_db(np.zeros((2, 2)), ref=np.max), 0.0)  # all-zero clip: amin/amin
+
+
+def test_mfcc_dct_and_lifter():
+    rng = np.random.default_rng(3)
+    S = rng.normal(-40, 10, (40, 7))
+    C = O.mfcc(S=S, n_mfcc=13)
+    M = 40
+    k = np.arange(13)[:, None]; n = np.arange(M)[None, :]
+    D = np.sqrt(2.0 / M) * np.cos(np.pi * k * (2 * n + 1) / (2 * M)); D[0] = np.sqrt(1.0 / M)
+    assert_allclose(C, D @ S, atol=1e-11)
+    assert_allclose(O.mfcc(S=np.full((M, 3), -3.0))[0], np.sqrt(M) * -3.0)
+    assert_allclose(O.mfcc(S=np.full((M, 3), -3.0))[1:], 0.0, atol=1e-12)
+    # first 13 of 20 == 13 (reference tests/test_features_cepstral.py:94-117)
+    assert_allclose(O.mfcc(S=S, n_mfcc=20)[:13], C, atol=1e-12)
+    L = O.mfcc(S=S, n_mfcc=13, lifter=22.0)
+    assert_allclose(L, C * (1 + 11.0 * np.sin(np.pi * np.arange(1, 14) / 22.0))[:, None])
+    with pytest.raises(ValueError):
+        O.mfcc(S=S, lifter=-1.0)
+    with pytest.raises(ValueError, match="Either audio time series 'y' or Mel spectrogram 'S' must be provided."):
+        O.mfcc()
+    with pytest.raises(ValueError, match="Sampling rate 'sr' must be provided"):
+        O.mfcc(y=np.zeros(10))
+
+
+def test_contrast_band_rules():
+    fr = O.fft_frequencies(48000, 2048)
+    bands = O.contrast_bands(fr, 48000)
+    assert len(bands) == 7
+    # band 0: 0..200 Hz inclusive = bins 0..8, top bin dropped, k = rint(.02*9)=0 -> 1
+    assert_array_equal(bands[0][0], np.arange(0, 8)); assert bands[0][1] == 1
+    # band 1: [200,400] = bins 9..17 plus the bin below (8), minus top -> 8..16
+    assert_array_equal(bands[1][0], np.arange(8, 17))
+    # last band extends to Nyquist and keeps its top bin
+    assert bands[6][0][-1] == 1024 and bands[6][0][0] == 273
+    assert bands[6][1] == int(np.rint(0.02 * (1024 - 273 + 1)))
+    with pytest.raises(ValueError, match="Nyquist"):
+        O.contrast_bands(O.fft_frequencies(8000, 512), 8000)
+
+
+def test_spectral_contrast_known_answer():
+    fr = O.fft_frequencies(48000, 2048)
+    S = np.ones((1025, 3))
+    C = O.spectral_contrast(S, 48000, freqs=fr)
+    assert C.shape == (7, 3)
+    assert_allclose(C, 0.0, atol=1e-12)                      # flat spectrum: peak == valley
+    S2 = np.ones((1025, 2)); S2[300, :] = 1000.0             # one strong bin in the top band
+    bands = O.contrast_bands(fr, 48000)
+    k = bands[6][1]
+    C2 = O.spectral_contrast(S2, 48000, freqs=fr)
+    assert_allclose(C2[6], 10 * np.log10((1000.0 + (k - 1)) / k), rtol=1e-12)
+    assert_allclose(C2[:6], 0.0, atol=1e-12)
+    with pytest.raises(ValueError, match="Input S must be a 2D spectrogram"):
+        O.spectral_contrast(np.ones(5), 48000)
+
+
+def test_extract_features_names_and_shapes():
+    y = O.synth_clips(1, 16000, 16000, seed=5)[0].astype(np.float64)
+    r = O.extract_features(y, 16000, ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"])
+    T = 1 + 16000 // 512
+    assert set(r) == {"time", *[f"mfcc_{i}" for i in range(13)], "spectral_centroid", "spectral_rolloff",
+                      *[f"contrast_band_{i}" for i in range(6)], "contrast_delta"}
+    assert all(v.shape == (T,) and v.dtype == np.float64 for v in r.values())
+    r2 = O.extract_features(y, 16000, ["spectral_centroid", "spectral_rolloff", "spectral_bandwidth",
+                                       "spectral_flatness", "dominant_frequency"], per_frame_loop=True)
+    r3 = O.extract_features(y, 16000, ["spectral_centroid", "spectral_rolloff", "spectral_bandwidth",
+                                       "spectral_flatness", "dominant_frequency"])
+    for k in r2:
+        assert_allclose(r2[k], r3[k], rtol=1e-11, atol=1e-9)
+    with pytest.raises(ValueError, match="Unknown feature"):
+        O.extract_features(y, 16000, ["nope"])
+    assert O.extract_features(np.zeros(100), 16000, ["mfcc"], center=False)["time"].size == 0
