@@ -1,0 +1,58 @@
+"""ctypes binding of libsygnals_hip.so (the C ABI declared in include/sygnals_hip.h).
+
+The product path has NO CPU fallback: `lib()` raises if the shared library has not been
+built, and every op raises if no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsygnals_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+_d = C.c_double
+
+# name -> (restype, argtypes); must list every symbol declared in include/sygnals_hip.h
+SIGNATURES = {
+    "syg_abi_version": (_i, []),
+    "syg_last_error": (C.c_char_p, []),
+    "syg_stft2048_mel_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p, _i, _p, _f, _f, _f, _p, _p, _p, _p]),
+    "syg_stft2048_c2c_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p]),
+    "syg_logmel_dct_f32": (_i, [_p, _l, _i, _l, _p, _i, _p, _f, _f, _i, _f, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class SygnalsHipError(RuntimeError):
+    """Raised when the HIP library is missing or a C-ABI call reports an error."""
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SygnalsHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(sygnals_amd has no CPU fallback)")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        ver = h.syg_abi_version()
+        if ver != 1:
+            raise SygnalsHipError(f"libsygnals_hip.so ABI version {ver} != 1")
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().syg_last_error()
+        raise SygnalsHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

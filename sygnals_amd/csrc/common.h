@@ -1,0 +1,86 @@
+// Shared helpers for the sygnals_hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/sygnals_hip.h"
+
+namespace syg {
+
+// thread-local last-error string, defined in capi.hip
+void set_error(const char* fmt, ...);
+
+#define SYG_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      syg::set_error(__VA_ARGS__);             \
+      return SYG_E_INVALID;                    \
+    }                                          \
+  } while (0)
+
+#define SYG_CHECK_LAUNCH(what)                                               \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      syg::set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e_)); \
+      return SYG_E_LAUNCH;                                                   \
+    }                                                                        \
+  } while (0)
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(-a.y, b.y, a.x * b.x), fmaf(a.y, b.x, a.x * b.y));
+}
+// a * conj(b)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+  return make_float2(fmaf(a.y, b.y, a.x * b.x), fmaf(a.y, b.x, -a.x * b.y));
+}
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+
+// Forward radix-4 butterfly: o[q] = sum_p a[p] * (-i)^(p*q)
+__device__ __forceinline__ void bfly4(float2 a0, float2 a1, float2 a2, float2 a3, float2& o0, float2& o1,
+                                      float2& o2, float2& o3) {
+  float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
+  o0 = cadd(t0, t2);
+  o2 = csub(t0, t2);
+  o1 = make_float2(t1.x + t3.y, t1.y - t3.x);
+  o3 = make_float2(t1.x - t3.y, t1.y + t3.x);
+}
+
+// In-register forward 16-point DFT, natural order in and out (radix-4 x radix-4).
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
+  float2 s[16];  // s[i + 4q]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bfly4(v[i], v[i + 4], v[i + 8], v[i + 12], s[i], s[i + 4], s[i + 8], s[i + 12]);
+  // twiddle s[i + 4q] *= W16^(i*q)
+  s[1 + 4] = cmul(s[1 + 4], make_float2(C1, -S1));   // e=1
+  s[2 + 4] = cmul(s[2 + 4], make_float2(R, -R));     // e=2
+  s[3 + 4] = cmul(s[3 + 4], make_float2(S1, -C1));   // e=3
+  s[1 + 8] = cmul(s[1 + 8], make_float2(R, -R));     // e=2
+  s[2 + 8] = mul_mi(s[2 + 8]);                       // e=4
+  s[3 + 8] = cmul(s[3 + 8], make_float2(-R, -R));    // e=6
+  s[1 + 12] = cmul(s[1 + 12], make_float2(S1, -C1)); // e=3
+  s[2 + 12] = cmul(s[2 + 12], make_float2(-R, -R));  // e=6
+  s[3 + 12] = cmul(s[3 + 12], make_float2(-C1, S1)); // e=9
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    bfly4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3], v[q], v[q + 4], v[q + 8], v[q + 12]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace syg

@@ -1,0 +1,98 @@
+// power_to_db (per-clip ref=max, amin, top_db clamp) + DCT-II (+ lifter).
+//
+// Reproduces librosa.power_to_db(S_mel, ref=np.max) (manager.py:223) and
+// librosa.feature.mfcc(S=..) -> scipy.fft.dct(type=2, norm='ortho')[:n_mfcc] (cepstral.py:106-115).
+// One workgroup per clip.  The clip's [M, T] mel matrix (15 KB at the headline config) is
+// L2-resident from the producing kernel; the DCT is the 16x16x4 f32 MFMA with the DCT rows
+// as the A operand and 16 frames as the B operand.
+#include "common.h"
+
+namespace syg {
+namespace {
+
+constexpr int NT = 256;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NT) void logmel_dct_kernel(float* __restrict__ mel, int M, int64_t T,
+                                                         const float* __restrict__ dct, int K,
+                                                         const float* __restrict__ lifter, float amin, float top_db,
+                                                         int ref_is_max, float ref_value, float* __restrict__ logmel,
+                                                         float* __restrict__ mfcc) {
+  __shared__ float red[NT / 64];
+  __shared__ float s_floor, s_refdb;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t b = blockIdx.x;
+  float* src = mel + b * (int64_t)M * T;
+  float* dst = logmel ? logmel + b * (int64_t)M * T : src;
+  const int64_t n = (int64_t)M * T;
+
+  // ---- per-clip maximum (ref=np.max and the top_db floor both need it)
+  float mx = 0.f;  // power is non-negative
+  for (int64_t i = tid; i < n; i += NT) mx = fmaxf(mx, src[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float m = red[0];
+    for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, red[i]);
+    const float ref = ref_is_max ? m : fabsf(ref_value);
+    const float refdb = 10.f * log10f(fmaxf(amin, ref));
+    s_refdb = refdb;
+    // log_spec.max() - top_db, with log_spec monotone in the power
+    s_floor = (top_db >= 0.f) ? (10.f * log10f(fmaxf(amin, m)) - refdb) - top_db : -3.4e38f;
+  }
+  __syncthreads();
+  const float refdb = s_refdb, flo = s_floor;
+  for (int64_t i = tid; i < n; i += NT) {
+    float v = 10.f * log10f(fmaxf(amin, src[i])) - refdb;
+    dst[i] = fmaxf(v, flo);
+  }
+  if (mfcc == nullptr) return;
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- DCT: out[k, t] = sum_m dct[k, m] * dB[m, t]   (16x16 output tiles on the MFMA)
+  const int ktiles = (K + 15) / 16;
+  const int ttiles = (int)((T + 15) / 16);
+  const int f = lane & 15, g = lane >> 4;
+  for (int tile = w; tile < ktiles * ttiles; tile += NT / 64) {
+    const int kt = tile / ttiles, tt = tile % ttiles;
+    const int krow = kt * 16 + f;          // A operand row
+    const int64_t tcol = (int64_t)tt * 16 + f;  // B operand column
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int m0 = 0; m0 < M; m0 += 4) {
+      const int m = m0 + g;
+      const float a = (krow < K && m < M) ? dct[krow * M + m] : 0.f;
+      const float bv = (tcol < T && m < M) ? dst[(int64_t)m * T + tcol] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + 4 * g + r;
+      if (k < K && tcol < T) {
+        float v = acc[r];
+        if (lifter) v *= lifter[k];
+        mfcc[(b * K + k) * T + tcol] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace syg
+
+using namespace syg;
+
+extern "C" int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const float* dct, int K,
+                                  const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
+                                  float* logmel_out, float* mfcc_out, void* stream) {
+  SYG_REQUIRE(mel, "logmel_dct: null mel pointer");
+  SYG_REQUIRE(B >= 1 && M >= 1 && T >= 1, "logmel_dct: need B, M, T >= 1");
+  SYG_REQUIRE(amin > 0.f, "logmel_dct: amin must be strictly positive");
+  if (mfcc_out) SYG_REQUIRE(dct && K >= 1 && K <= M, "logmel_dct: need dct and 1 <= K <= M (K=%d M=%d)", K, M);
+  SYG_REQUIRE(B < (int64_t)0x7fffffff, "logmel_dct: batch too large");
+  hipLaunchKernelGGL(logmel_dct_kernel, dim3((unsigned)B), dim3(NT), 0, (hipStream_t)stream, mel, M, T, dct, K,
+                     lifter, amin, top_db, ref_is_max, ref_value, logmel_out, mfcc_out);
+  SYG_CHECK_LAUNCH("logmel_dct");
+  return SYG_OK;
+}

@@ -1,0 +1,201 @@
+"""Batched device operators: thin Python over the C ABI.
+
+torch is used only as the device-array container (allocation, H2D/D2H, streams); every
+arithmetic step runs in libsygnals_hip.so.  All functions take/return CUDA(ROCm) float32
+tensors with a leading batch axis; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _tables as T
+from ._lib import SygnalsHipError, check, lib
+
+
+# ------------------------------------------------------------------ device plumbing
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise SygnalsHipError("sygnals_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def to_device_f32(x, device=None) -> torch.Tensor:
+    """Host array / tensor -> contiguous float32 device tensor (2-D: [B, L])."""
+    device = device or require_gpu()
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=device, dtype=torch.float32)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(device)
+    return t.contiguous()
+
+
+_dev_cache: dict = {}
+
+
+def _cached(key, builder):
+    dev = torch.cuda.current_device()
+    k = (dev,) + key
+    v = _dev_cache.get(k)
+    if v is None:
+        v = builder()
+        _dev_cache[k] = v
+    return v
+
+
+def _dev(arr: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(require_gpu())
+
+
+def _window_key(window, win_length, n_fft):
+    if isinstance(window, (np.ndarray, list)):
+        a = np.asarray(window, dtype=np.float64)
+        return ("arr", a.tobytes(), win_length, n_fft)
+    return (window, win_length, n_fft)
+
+
+def window_dev(window, win_length, n_fft) -> torch.Tensor:
+    return _cached(("win",) + _window_key(window, win_length, n_fft),
+                   lambda: _dev(T.analysis_window(window, win_length, n_fft).astype(np.float32)))
+
+
+def twiddle_dev(n) -> torch.Tensor:
+    return _cached(("tw", n), lambda: _dev(T.twiddles(n)))
+
+
+def num_frames(L: int, n_fft: int, hop: int, center: bool) -> int:
+    """Frame-count rule of sygnals/core/features/manager.py:149-157."""
+    if center:
+        return 1 + L // hop
+    return 1 + (L - n_fft) // hop if L >= n_fft else 0
+
+
+# ------------------------------------------------------------------ fused 2048 path
+class MelConfig:
+    """Device tables for one (sr, n_fft, n_mels, fmin, fmax) mel front end."""
+
+    def __init__(self, sr, n_fft, n_mels, fmin, fmax):
+        basis = T.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+        self.basis_host = basis
+        self.n_mels = n_mels
+        if n_fft == 2048 and n_mels <= 16 * T.WAVES:
+            wp, plan = T.pack_mel_plan(basis)
+            self.wpacked = _dev(wp)
+            self.plan = np.ascontiguousarray(plan, dtype=np.int32)
+        else:
+            self.wpacked = None
+            self.plan = None
+        self.basis = _dev(basis)
+
+
+def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> MelConfig:
+    fmax = sr / 2.0 if fmax is None else fmax
+    return _cached(("mel", float(sr), n_fft, n_mels, float(fmin), float(fmax)),
+                   lambda: MelConfig(sr, n_fft, n_mels, fmin, fmax))
+
+
+def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
+                 win_length: int = 2048, n_mels: int = 128, fmin: float = 0.0, fmax=None,
+                 want_stats: bool = False, roll_percent: float = 0.85, bw_p: float = 2.0,
+                 contrast: Optional[np.ndarray] = None):
+    """Fused STFT(2048) -> power -> mel.  Returns (mel [B, M, T], stats [B, 8, T] | None,
+    contrast_pv [B, 2, R, T] | None)."""
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    B, L = y.shape
+    Tn = num_frames(L, 2048, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    cfg = mel_config(sr, 2048, n_mels, fmin, fmax)
+    if cfg.wpacked is None:
+        raise SygnalsHipError(f"fused path supports n_mels <= {16 * T.WAVES}")
+    win = window_dev(window, win_length, 2048)
+    tw = twiddle_dev(2048)
+    mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
+    stats = torch.empty((B, 8, Tn), dtype=torch.float32, device=y.device) if want_stats else None
+    cpv = None
+    cplan_p = None
+    if contrast is not None:
+        cplan = np.ascontiguousarray(contrast, dtype=np.int32)
+        cpv = torch.empty((B, 2, int(cplan[0]), Tn), dtype=torch.float32, device=y.device)
+        cplan_p = cplan.ctypes.data_as(C.c_void_p)
+    rc = lib().syg_stft2048_mel_f32(
+        _ptr(y), B, L, y.stride(0), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(cfg.wpacked),
+        cfg.plan.ctypes.data_as(C.c_void_p), n_mels, _ptr(mel), float(sr), float(roll_percent), float(bw_p),
+        _ptr(stats), cplan_p, _ptr(cpv), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft2048_mel_f32")
+    return mel, stats, cpv
+
+
+def stft2048_c2c(y: torch.Tensor, hop: int = 512, center: bool = True, window="hann", win_length: int = 2048):
+    """Complex STFT, frame-major [B, T, 1025, 2] float32."""
+    require_gpu()
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    B, L = y.shape
+    Tn = num_frames(L, 2048, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    win = window_dev(window, win_length, 2048)
+    tw = twiddle_dev(2048)
+    out = torch.empty((B, Tn, 1025, 2), dtype=torch.float32, device=y.device)
+    rc = lib().syg_stft2048_c2c_f32(_ptr(y), B, L, y.stride(0), hop, int(center), Tn, _ptr(win), _ptr(tw),
+                                    _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft2048_c2c_f32")
+    return out
+
+
+def logmel_dct(mel: torch.Tensor, n_mfcc: Optional[int] = 13, dct_type: int = 2, norm="ortho", lifter: float = 0.0,
+               amin: float = 1e-10, top_db: Optional[float] = 80.0, ref="max", keep_mel: bool = False):
+    """power_to_db (ref = per-clip max or a scalar) then DCT.  Returns (logmel [B,M,T], mfcc [B,K,T] | None).
+
+    `mel` is converted to dB in place unless keep_mel=True.
+    """
+    require_gpu()
+    B, M, Tn = mel.shape
+    if amin <= 0:
+        raise ValueError("amin must be strictly positive")
+    if top_db is not None and top_db < 0:
+        raise ValueError("top_db must be non-negative")
+    logmel = torch.empty_like(mel) if keep_mel else None
+    mf = dct = lif = None
+    K = 0
+    if n_mfcc is not None:
+        K = int(n_mfcc)
+        dct = _cached(("dct", K, M, dct_type, norm), lambda: _dev(T.dct_matrix(K, M, dct_type, norm)))
+        lw = T.lifter_weights(K, float(lifter))
+        lif = _dev(lw) if lw is not None else None
+        mf = torch.empty((B, K, Tn), dtype=torch.float32, device=mel.device)
+    ref_is_max = 1 if (ref == "max" or ref is np.max) else 0
+    ref_value = 1.0 if ref_is_max else float(ref)
+    rc = lib().syg_logmel_dct_f32(_ptr(mel), B, M, Tn, _ptr(dct), K, _ptr(lif), float(amin),
+                                  float(top_db) if top_db is not None else -1.0, ref_is_max, ref_value,
+                                  _ptr(logmel), _ptr(mf), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_logmel_dct_f32")
+    return (logmel if keep_mel else mel), mf
+
+
+def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_mels: int = 128, n_mfcc: int = 13,
+               center: bool = True, window="hann", fmin: float = 0.0, fmax=None, lifter: float = 0.0):
+    """Config C2: [B, L] clips -> MFCC [B, n_mfcc, T] (manager path a1..a5), all on device."""
+    if n_fft != 2048:
+        raise SygnalsHipError("mfcc_batch: only n_fft=2048 has a fused path; use features.extract_features_batch")
+    mel, _, _ = stft2048_mel(y, sr, hop, center, window, 2048, n_mels, fmin, fmax)
+    _, mf = logmel_dct(mel, n_mfcc, lifter=lifter)
+    return mf

@@ -1,0 +1,176 @@
+"""GPU parity of the fused STFT(2048)->mel->MFCC path against the float64 oracle.
+Calls go through the C ABI (sygnals_amd.ops -> libsygnals_hip.so)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import cpu_ref as O
+from tests.gpu_util import assert_parity, peak_rel
+
+TOL = 1e-5  # fp32 parity tolerance stated by BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sygnals_amd import ops
+    ops.require_gpu()
+    return ops
+
+
+@pytest.fixture(scope="module")
+def clips():
+    return O.synth_clips(8, 48000, 48000, seed=0)
+
+
+def kat_clips(L=48000, sr=48000):
+    t = np.arange(L) / sr
+    z = np.zeros(L, np.float32)
+    imp = z.copy(); imp[L // 2] = 1.0
+    dc = np.full(L, 0.5, np.float32)
+    sine = (0.9 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
+    return np.stack([z, imp, dc, sine])
+
+
+def test_stft_complex_matches_oracle(ops, clips):
+    y = ops.to_device_f32(clips)
+    X = ops.stft2048_c2c(y, hop=512).cpu().numpy()
+    X = X[..., 0] + 1j * X[..., 1]                       # [B, T, F]
+    for i in range(clips.shape[0]):
+        ref = O.stft(clips[i].astype(np.float64), 2048, 512).T
+        assert_parity(X[i].real, ref.real, TOL * np.abs(ref).max() / max(np.abs(ref.real).max(), 1e-300), f"stft re clip {i}")
+        assert peak_rel(X[i], ref) <= TOL
+
+
+def test_mel_power_matches_oracle(ops, clips):
+    y = ops.to_device_f32(clips)
+    mel, _, _ = ops.stft2048_mel(y, 48000, n_mels=40)
+    mel = mel.cpu().numpy()
+    for i in range(clips.shape[0]):
+        S = np.abs(O.stft(clips[i].astype(np.float64), 2048, 512)) ** 2
+        ref = O.melspectrogram(S, 48000, 2048, 40)
+        assert_parity(mel[i], ref, TOL, f"mel clip {i}")
+
+
+@pytest.mark.parametrize("n_mels,n_mfcc", [(40, 13), (128, 13), (64, 20), (24, 24)])
+def test_mfcc_c2_matches_oracle(ops, clips, n_mels, n_mfcc):
+    y = ops.to_device_f32(clips)
+    out = ops.mfcc_batch(y, 48000, n_mels=n_mels, n_mfcc=n_mfcc).cpu().numpy()
+    ref = O.mfcc_batch(clips, 48000, n_mels=n_mels, n_mfcc=n_mfcc)
+    assert out.shape == ref.shape == (8, n_mfcc, 94)
+    for i in range(8):
+        assert_parity(out[i], ref[i], TOL, f"mfcc clip {i}")
+
+
+def test_mfcc_degenerate_clips(ops):
+    K = kat_clips()
+    out = ops.mfcc_batch(ops.to_device_f32(K), 48000, n_mels=40).cpu().numpy()
+    ref = O.mfcc_batch(K, 48000, n_mels=40)
+    assert_parity(out[0], ref[0], TOL, "all-zero clip")   # amin/amin -> 0 dB everywhere
+    assert_parity(out[1], ref[1], TOL, "impulse")
+    assert_parity(out[2], ref[2], TOL, "dc")
+    # pure sine: bands far below the peak sit at the fp32 noise floor before the 80 dB clamp
+    assert_parity(out[3], ref[3], 5e-4, "sine (fp32 floor vs float64 floor under top_db)")
+
+
+@pytest.mark.parametrize("L,hop,center", [(100, 512, True), (2048, 512, False), (5000, 160, True),
+                                          (4999, 441, True), (48000, 512, False), (3000, 1, False)])
+def test_ragged_lengths_and_hops(ops, L, hop, center):
+    rng = np.random.default_rng(L + hop)
+    Y = rng.normal(0, 0.2, (3, L)).astype(np.float32)
+    out = ops.mfcc_batch(ops.to_device_f32(Y), 16000, hop=hop, n_mels=40, center=center).cpu().numpy()
+    ref = np.stack([O.mfcc_manager(y.astype(np.float64), 16000, 2048, hop, center, "hann", 40, 13) for y in Y])
+    assert out.shape == ref.shape
+    assert_parity(out, ref, TOL, f"L={L} hop={hop} center={center}")
+
+
+def test_c1_single_clip_10s_16k(ops):
+    y = O.synth_clips(1, 160000, 16000, seed=3)
+    out = ops.mfcc_batch(ops.to_device_f32(y), 16000, n_mels=128).cpu().numpy()
+    ref = O.mfcc_batch(y, 16000, n_mels=128)
+    assert out.shape == (1, 13, 313)
+    assert_parity(out, ref, TOL, "C1")
+
+
+def test_window_and_lifter_variants(ops, clips):
+    y = ops.to_device_f32(clips[:2])
+    for window in ("hamming", "blackman"):
+        mel, _, _ = ops.stft2048_mel(y, 48000, window=window, n_mels=40)
+        _, mf = ops.logmel_dct(mel, 13, lifter=22.0)
+        ref = np.stack([O.mfcc_manager(c.astype(np.float64), 48000, window=window, n_mels=40, lifter=22.0)
+                        for c in clips[:2]])
+        assert_parity(mf.cpu().numpy(), ref, TOL, f"window={window} lifter=22")
+
+
+def test_strided_batch_rows(ops, clips):
+    """Row stride (ldy) larger than L and a non-8-byte-aligned view exercise the scalar load path."""
+    big = np.zeros((4, 48000 + 7), np.float32)
+    big[:, 3:48003] = clips[:4]
+    t = ops.to_device_f32(big)[:, 3:48003]
+    out = ops.mfcc_batch(t, 48000, n_mels=40).cpu().numpy()
+    ref = O.mfcc_batch(clips[:4], 48000, n_mels=40)
+    assert_parity(out, ref, TOL, "strided rows")
+
+
+def test_spectral_stats_match_oracle(ops, clips):
+    y = ops.to_device_f32(clips)
+    _, st, _ = ops.stft2048_mel(y, 48000, n_mels=40, want_stats=True)
+    st = st.cpu().numpy()
+    fr = O.fft_frequencies(48000, 2048)
+    flips = 0
+    for i in range(clips.shape[0]):
+        S = np.abs(O.stft(clips[i].astype(np.float64), 2048, 512))
+        ref = O.spectral_stats_frames(S, fr)
+        assert_parity(st[i, 0], ref["spectral_centroid"], TOL, "centroid")
+        assert_parity(st[i, 1], ref["spectral_bandwidth"], TOL, "bandwidth")
+        assert_parity(st[i, 2], ref["spectral_flatness"], TOL, "flatness")
+        rb = st[i, 3].astype(int); db = st[i, 4].astype(int)
+        # bin-valued outputs: identical wherever the float64 decision margin exceeds 1e-6
+        sure = ref["rolloff_margin"] > 1e-6
+        assert (rb[sure] == ref["rolloff_bin"][sure]).all()
+        assert (np.abs(rb - ref["rolloff_bin"]) <= 1).all()
+        flips += int((rb != ref["rolloff_bin"]).sum())
+        sure = ref["dominant_margin"] > 1e-6
+        assert (db[sure] == ref["dominant_bin"][sure]).all()
+    print("rolloff bins differing inside the 1e-6 margin:", flips)
+
+
+def test_spectral_stats_degenerate(ops):
+    K = kat_clips()
+    _, st, _ = ops.stft2048_mel(ops.to_device_f32(K), 48000, n_mels=40, want_stats=True)
+    st = st.cpu().numpy()
+    # all-zero frames: centroid 0, bandwidth 0, flatness 0, rolloff = last bin, dominant = bin 0
+    assert (st[0, 0] == 0).all() and (st[0, 1] == 0).all() and (st[0, 2] == 0).all()
+    assert (st[0, 3] == 1024).all() and (st[0, 4] == 0).all()
+    # 1 kHz sine: dominant bin = round(1000/23.4375) = 43 on interior frames
+    assert (st[3, 4, 4:-4] == 43).all()
+
+
+def test_spectral_contrast_matches_oracle(ops, clips):
+    from sygnals_amd import _tables as T
+    fr = O.fft_frequencies(48000, 2048)
+    plan = T.contrast_plan(fr, 48000)
+    y = ops.to_device_f32(clips)
+    _, _, pv = ops.stft2048_mel(y, 48000, n_mels=40, contrast=plan)
+    pv = pv.cpu().numpy()
+    for i in range(clips.shape[0]):
+        S = np.abs(O.stft(clips[i].astype(np.float64), 2048, 512))
+        bands = O.contrast_bands(fr, 48000)
+        for k, (bins, kk) in enumerate(bands):
+            srt = np.sort(S[bins], axis=0)
+            assert_parity(pv[i, 1, k], srt[:kk].mean(axis=0), TOL, f"valley band {k}")
+            assert_parity(pv[i, 0, k], srt[-kk:].mean(axis=0), TOL, f"peak band {k}")
+
+
+def test_large_batch_consistency(ops):
+    """Full C2 batch size: every clip of a 1024-clip batch equals the same clip run alone
+    (size-independent property; the oracle is only run on a sample)."""
+    Y = O.synth_clips(16, 48000, 48000, seed=11)
+    big = np.tile(Y, (64, 1))
+    out = ops.mfcc_batch(ops.to_device_f32(big), 48000, n_mels=40).cpu().numpy()
+    assert out.shape == (1024, 13, 94)
+    small = ops.mfcc_batch(ops.to_device_f32(Y), 48000, n_mels=40).cpu().numpy()
+    assert np.array_equal(out.reshape(64, 16, 13, 94), np.broadcast_to(small, (64, 16, 13, 94)))
+    ref = O.mfcc_batch(Y[:4], 48000, n_mels=40)
+    assert_parity(small[:4], ref, TOL, "sample of the large batch")

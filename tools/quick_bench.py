@@ -1,0 +1,22 @@
+"""Quick on-GPU timing of the fused path (development aid)."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from sygnals_amd import ops
+from oracle import cpu_ref as O
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+Y = O.synth_clips(32, 48000, 48000, seed=1)
+y = ops.to_device_f32(np.tile(Y, (B // 32, 1)))
+for _ in range(3):
+    ops.mfcc_batch(y, 48000, n_mels=40)
+torch.cuda.synchronize()
+for name, fn in (("mfcc", lambda: ops.mfcc_batch(y, 48000, n_mels=40)),
+                 ("mel only", lambda: ops.stft2048_mel(y, 48000, n_mels=40)),
+                 ("mel+stats", lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=True))):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"{name}: {ms*1e3:.1f} us/step  {B*48000/ms/1e3:.0f} Msamples/s  roofline {B*196888/ms/1e-3/8e12*100:.2f}%")
