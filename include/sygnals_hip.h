@@ -93,6 +93,68 @@ int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const float* dct
                        const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
                        float* logmel_out, float* mfcc_out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Generic batched power-of-two FFT in LDS (n = 2^k, 2 <= n <= 8192): scipy.fft.fft /
+ * ifft as called by compute_fft / compute_ifft, sygnals/core/dsp.py:104, 151.
+ *   in/out   [batch, n] complex64 (may alias); inverse != 0 scales by 1/n
+ *   twiddle  [n] complex W_n^k = exp(-2*pi*i*k/n)
+ * ------------------------------------------------------------------------------- */
+int syg_fft_pow2_c2c_f32(const float* in, float* out, int64_t batch, int n, int inverse,
+                         const float* twiddle, void* stream);
+
+/* Generic framed STFT for any power-of-two n_fft in [8, 16384] (slow path of
+ * compute_stft and of extract_features for frame lengths other than 2048).
+ *   twiddle [n_fft + n_fft/2] complex: W_nfft^k (k < n_fft) followed by W_{nfft/2}^k
+ *   out [B, T, 1 + n_fft/2] complex64, frame-major. */
+int syg_stft_pow2_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
+                          int64_t T, const float* window, const float* twiddle, float* out, void* stream);
+
+/* Elementwise helpers on frame-major spectra: out[i] = |X[i]|^power (power 1 or 2). */
+int syg_cabs_pow_f32(const float* x_c64, int64_t n, int power, float* out, void* stream);
+
+/* Dense mel projection for the generic path: mel[b, m, t] = sum_f basis[m, f] * P[b, t, f]. */
+int syg_mel_dense_f32(const float* P, int64_t B, int64_t T, int F, const float* basis, int M,
+                      float* mel_out, void* stream);
+
+/* Per-frame spectral statistics of frame-major magnitude spectra mag [N, F] with bin
+ * frequencies freqs [F] (frequency_domain.py:24-386).  stats_out [SYG_NSTAT, N]. */
+int syg_spectral_stats_f32(const float* mag, int64_t N, int F, const float* freqs, float roll_percent,
+                           float bw_p, float* stats_out, void* stream);
+
+/* Spectral-contrast peak/valley means of frame-major magnitude spectra mag [N, F]:
+ * for each band row r: mean of the k[r] smallest / largest values of bins lo[r]..hi[r]-1.
+ *   out [2, n_rows, N] (peak then valley). */
+int syg_contrast_pv_f32(const float* mag, int64_t N, int F, const int32_t* cplan_host, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Zero-phase SOS filtering: scipy.signal.sosfiltfilt(sos, x) (padtype='odd') as called by
+ * apply_sos_filter, sygnals/core/filters.py:85-115.
+ *   x, y        [B, L] float32 (row strides ldx, ldy); y may alias x
+ *   sos_host    HOST float64 [n_sections, 6]
+ *   zi_host     HOST float64 [n_sections, 2]  sosfilt_zi(sos)
+ *   padlen      edge extension length (3*ntaps rule), must be < L
+ *   work        device workspace of syg_sosfiltfilt_work_bytes(B, L, padlen, n_sections) bytes
+ * ------------------------------------------------------------------------------- */
+int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, int n_sections);
+int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const double* sos_host,
+                        const double* zi_host, int n_sections, int padlen, float* y, int64_t ldy,
+                        void* work, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Welch PSD: scipy.signal.welch(..., return_onesided=True) as called by
+ * compute_psd_welch, sygnals/core/dsp.py:545-555.  nfft power of two in [8, 16384],
+ * nperseg <= nfft.  twiddle as for syg_stft_pow2_c2c_f32 ([nfft + nfft/2] complex).
+ *   x        [B, L] float32
+ *   window   [nperseg] float32
+ *   detrend  0 none, 1 constant (per-segment mean removal)
+ *   scale    density: 1/(fs*sum(w^2)); spectrum: 1/sum(w)^2   (computed by the caller)
+ *   psd_out  [B, 1 + nfft/2] float32 ; partial sums in work (syg_welch_work_bytes)
+ * ------------------------------------------------------------------------------- */
+int64_t syg_welch_work_bytes(int64_t B, int nfft);
+int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg, int step, int nfft,
+                  const float* window, const float* twiddle, int detrend, double scale, float* psd_out,
+                  void* work, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

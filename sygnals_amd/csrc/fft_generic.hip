@@ -1,0 +1,318 @@
+// Generic power-of-two FFT in LDS (Stockham autosort, radix 4 with a radix-2 tail) and the
+// kernels built on it: batched c2c FFT/IFFT, framed STFT for any power-of-two n_fft, Welch PSD.
+//
+// Reference behaviour reproduced:
+//   scipy.fft.fft / ifft            (compute_fft / compute_ifft, sygnals/core/dsp.py:104, 151)
+//   librosa.stft                    (compute_stft, sygnals/core/dsp.py:216-224)
+//   scipy.signal.welch              (compute_psd_welch, sygnals/core/dsp.py:545-555)
+// One workgroup per transform; the two ping-pong buffers live in LDS (<= 128 KiB for
+// n = 8192), so every transform reads its input once and writes its output once.
+#include "common.h"
+
+namespace syg {
+namespace {
+
+constexpr int MAX_N = 8192;
+
+// Forward complex FFT of N points held in LDS buffer `x` (scratch `y`), N a power of two >= 2.
+// tw[k] = W_N^k.  Returns the buffer that holds the result (natural order).
+__device__ float2* block_fft(float2* x, float2* y, int N, const float2* __restrict__ tw, int tid, int nt) {
+  int n = N, s = 1;
+  while (n >= 4) {
+    const int q4 = n >> 2;
+    for (int i = tid; i < (N >> 2); i += nt) {
+      const int p = i / s, q = i - p * s;
+      const float2 a = x[q + s * p], b = x[q + s * (p + q4)], c = x[q + s * (p + 2 * q4)],
+                   d = x[q + s * (p + 3 * q4)];
+      float2 o0, o1, o2, o3;
+      bfly4(a, b, c, d, o0, o1, o2, o3);
+      const int e = p * s;  // W_n^p = W_N^(p*s)
+      y[q + s * (4 * p)] = o0;
+      y[q + s * (4 * p + 1)] = cmul(o1, tw[e]);
+      y[q + s * (4 * p + 2)] = cmul(o2, tw[2 * e]);
+      y[q + s * (4 * p + 3)] = cmul(o3, tw[3 * e]);
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+    n >>= 2; s <<= 2;
+  }
+  if (n == 2) {
+    for (int i = tid; i < (N >> 1); i += nt) {
+      const float2 a = x[i], b = x[i + s];   // p = 0, q = i, s = N/2
+      y[i] = cadd(a, b);
+      y[i + s] = csub(a, b);
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+  }
+  return x;
+}
+
+// Real-input split: Z = FFT_M(z), z[m] = x[2m] + i x[2m+1]; returns X[k], k in [0, M].
+// tw2[k] = W_{2M}^k.
+__device__ __forceinline__ float2 rfft_bin(const float2* Z, int M, int k, const float2* __restrict__ tw2) {
+  const float2 zk = Z[k & (M - 1)], zm = Z[(M - k) & (M - 1)];
+  const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);
+  const float2 O = make_float2(zk.y + zm.y, zm.x - zk.x);
+  const float2 wO = cmul(tw2[k], O);
+  return make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
+}
+
+// ---------------------------------------------------------------------------------
+__global__ void fft_pow2_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n, int inverse,
+                                const float2* __restrict__ tw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* x = reinterpret_cast<float2*>(lds);
+  float2* y = x + n;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int64_t base = (int64_t)blockIdx.x * n;
+  // inverse via conj(FFT(conj(x))) / n
+  for (int i = tid; i < n; i += nt) {
+    float2 v = in[base + i];
+    if (inverse) v.y = -v.y;
+    x[i] = v;
+  }
+  __syncthreads();
+  float2* r = block_fft(x, y, n, tw, tid, nt);
+  const float sc = inverse ? 1.0f / (float)n : 1.0f;
+  for (int i = tid; i < n; i += nt) {
+    float2 v = r[i];
+    out[base + i] = inverse ? make_float2(v.x * sc, -v.y * sc) : v;
+  }
+}
+
+// Framed STFT, one workgroup per frame; tw = W_{n_fft}^k (n_fft entries).
+__global__ void stft_pow2_kernel(const float* __restrict__ y, int64_t L, int64_t ldy, int n_fft, int hop, int pad,
+                                 int64_t T, const float* __restrict__ win, const float2* __restrict__ tw,
+                                 float2* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int M = n_fft >> 1;
+  float2* x = reinterpret_cast<float2*>(lds);
+  float2* z = x + M;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int64_t b = blockIdx.x / T, t = blockIdx.x % T;
+  const float* yb = y + b * ldy;
+  const int64_t s0 = t * (int64_t)hop - pad;
+  for (int m = tid; m < M; m += nt) {
+    const int64_t s = s0 + 2 * m;
+    const float a = (s >= 0 && s < L) ? yb[s] * win[2 * m] : 0.f;
+    const float c = (s + 1 >= 0 && s + 1 < L) ? yb[s + 1] * win[2 * m + 1] : 0.f;
+    x[m] = make_float2(a, c);
+  }
+  __syncthreads();
+  // the M-point transform uses W_M^k = W_{n_fft}^{2k}: pass a stride-2 view via index doubling
+  // (block_fft indexes tw[e], e < M) -> precomputed separate table region: tw + n_fft holds W_M^k
+  float2* Z = block_fft(x, z, M, tw + n_fft, tid, nt);
+  float2* o = out + (b * T + t) * (int64_t)(M + 1);
+  for (int k = tid; k <= M; k += nt) o[k] = rfft_bin(Z, M, k, tw);
+}
+
+__global__ void cabs_pow_kernel(const float2* __restrict__ x, int64_t n, int power, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float2 v = x[i];
+    const float p = fmaf(v.x, v.x, v.y * v.y);
+    out[i] = (power == 2) ? p : sqrtf(p);
+  }
+}
+
+// mel[b, m, t] = sum_f basis[m, f] * P[b, t, f]; one workgroup per (b, t), one wave per mel row.
+__global__ void mel_dense_kernel(const float* __restrict__ P, int64_t T, int F, const float* __restrict__ basis,
+                                 int M, float* __restrict__ mel) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int64_t b = blockIdx.x / T, t = blockIdx.x % T;
+  const float* row = P + (b * T + t) * (int64_t)F;
+  for (int f = tid; f < F; f += blockDim.x) lds[f] = row[f];
+  __syncthreads();
+  for (int m = w; m < M; m += nw) {
+    const float* br = basis + (int64_t)m * F;
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s = fmaf(br[f], lds[f], s);
+    s = wave_sum(s);
+    if (lane == 0) mel[(b * M + m) * T + t] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Welch: grid (nblk, B); workgroup loops over segments blockIdx.x, += gridDim.x and keeps
+// per-bin partial sums in registers; a second kernel combines the partials in fixed order.
+constexpr int WELCH_NT = 256;
+constexpr int WELCH_MAXACC = (MAX_N / 2 + 1 + WELCH_NT - 1) / WELCH_NT;  // 17
+
+__global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
+    const float* __restrict__ x, int64_t L, int64_t ldx, int nperseg, int step, int nfft, int64_t nseg,
+    const float* __restrict__ win, const float2* __restrict__ tw, int detrend, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[WELCH_NT / 64];
+  const int M = nfft >> 1;
+  float2* xa = reinterpret_cast<float2*>(lds);
+  float2* xb = xa + M;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t b = blockIdx.y;
+  const float* xr = x + b * ldx;
+  float acc[WELCH_MAXACC];
+#pragma unroll
+  for (int j = 0; j < WELCH_MAXACC; ++j) acc[j] = 0.f;
+  for (int64_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+    const float* seg = xr + sg * (int64_t)step;
+    float mean = 0.f;
+    if (detrend) {
+      float s = 0.f;
+      for (int i = tid; i < nperseg; i += WELCH_NT) s += seg[i];
+      s = wave_sum(s);
+      if (lane == 0) red[w] = s;
+      __syncthreads();
+      s = 0.f;
+#pragma unroll
+      for (int i = 0; i < WELCH_NT / 64; ++i) s += red[i];
+      mean = s / (float)nperseg;
+    }
+    for (int m = tid; m < M; m += WELCH_NT) {
+      const int i0 = 2 * m, i1 = 2 * m + 1;
+      const float a = (i0 < nperseg) ? (seg[i0] - mean) * win[i0] : 0.f;
+      const float c = (i1 < nperseg) ? (seg[i1] - mean) * win[i1] : 0.f;
+      xa[m] = make_float2(a, c);
+    }
+    __syncthreads();
+    float2* Z = block_fft(xa, xb, M, tw + nfft, tid, WELCH_NT);
+#pragma unroll
+    for (int j = 0; j < WELCH_MAXACC; ++j) {
+      const int k = tid + j * WELCH_NT;
+      if (k <= M) {
+        const float2 X = rfft_bin(Z, M, k, tw);
+        acc[j] += fmaf(X.x, X.x, X.y * X.y);
+      }
+    }
+    __syncthreads();
+  }
+  float* po = partial + ((int64_t)b * gridDim.x + blockIdx.x) * (int64_t)(M + 1);
+#pragma unroll
+  for (int j = 0; j < WELCH_MAXACC; ++j) {
+    const int k = tid + j * WELCH_NT;
+    if (k <= M) po[k] = acc[j];
+  }
+}
+
+__global__ void welch_final_kernel(const float* __restrict__ partial, int nblk, int F, int64_t nseg, double scale,
+                                   int odd_nfft, float* __restrict__ psd) {
+  const int64_t b = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= F) return;
+  double s = 0.0;
+  for (int j = 0; j < nblk; ++j) s += (double)partial[((int64_t)b * nblk + j) * F + k];
+  s = s * scale / (double)nseg;
+  if (k > 0 && (odd_nfft || k < F - 1)) s *= 2.0;  // one-sided: double all but DC (and Nyquist)
+  psd[b * (int64_t)F + k] = (float)s;
+}
+
+bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
+int fft_threads(int n) { int t = n / 4; if (t < 64) t = 64; if (t > 1024) t = 1024; return t; }
+
+int set_lds(const void* fn, size_t bytes, const char* what) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      set_error("%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
+      return SYG_E_LAUNCH;
+    }
+  }
+  return SYG_OK;
+}
+
+constexpr int WELCH_NBLK = 64;
+
+}  // namespace
+}  // namespace syg
+
+using namespace syg;
+
+extern "C" int syg_fft_pow2_c2c_f32(const float* in, float* out, int64_t batch, int n, int inverse,
+                                    const float* twiddle, void* stream) {
+  SYG_REQUIRE(in && out && twiddle, "fft_pow2: null pointer argument");
+  SYG_REQUIRE(is_pow2(n) && n <= MAX_N, "fft_pow2: n must be a power of two in [2, %d] (got %d)", MAX_N, n);
+  SYG_REQUIRE(batch >= 1 && batch < (int64_t)0x7fffffff, "fft_pow2: bad batch %lld", (long long)batch);
+  const size_t lds = (size_t)n * 2 * sizeof(float2);
+  int rc = set_lds((const void*)fft_pow2_kernel, lds, "fft_pow2");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fft_pow2_kernel, dim3((unsigned)batch), dim3(fft_threads(n)), lds, (hipStream_t)stream,
+                     (const float2*)in, (float2*)out, n, inverse, (const float2*)twiddle);
+  SYG_CHECK_LAUNCH("fft_pow2");
+  return SYG_OK;
+}
+
+extern "C" int syg_stft_pow2_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop,
+                                     int center, int64_t T, const float* window, const float* twiddle, float* out,
+                                     void* stream) {
+  SYG_REQUIRE(y && window && twiddle && out, "stft_pow2: null pointer argument");
+  SYG_REQUIRE(is_pow2(n_fft) && n_fft >= 8 && n_fft <= 2 * MAX_N,
+              "stft_pow2: n_fft must be a power of two in [8, %d] (got %d)", 2 * MAX_N, n_fft);
+  SYG_REQUIRE(B >= 1 && L >= 1 && ldy >= L && hop >= 1, "stft_pow2: bad B/L/ldy/hop");
+  const int64_t Texp = center ? 1 + L / hop : (L >= n_fft ? 1 + (L - n_fft) / hop : 0);
+  SYG_REQUIRE(T >= 1 && T == Texp, "stft_pow2: T=%lld does not match the framing rule (%lld)", (long long)T,
+              (long long)Texp);
+  SYG_REQUIRE(B * T < (int64_t)0x7fffffff, "stft_pow2: grid too large");
+  const int M = n_fft / 2;
+  const size_t lds = (size_t)M * 2 * sizeof(float2);
+  int rc = set_lds((const void*)stft_pow2_kernel, lds, "stft_pow2");
+  if (rc) return rc;
+  hipLaunchKernelGGL(stft_pow2_kernel, dim3((unsigned)(B * T)), dim3(fft_threads(M)), lds, (hipStream_t)stream, y, L,
+                     ldy, n_fft, hop, center ? n_fft / 2 : 0, T, window, (const float2*)twiddle, (float2*)out);
+  SYG_CHECK_LAUNCH("stft_pow2");
+  return SYG_OK;
+}
+
+extern "C" int syg_cabs_pow_f32(const float* x_c64, int64_t n, int power, float* out, void* stream) {
+  SYG_REQUIRE(x_c64 && out, "cabs_pow: null pointer argument");
+  SYG_REQUIRE(n >= 0 && (power == 1 || power == 2), "cabs_pow: power must be 1 or 2");
+  if (n == 0) return SYG_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048 * 8) blocks = 2048 * 8;
+  hipLaunchKernelGGL(cabs_pow_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)x_c64, n, power, out);
+  SYG_CHECK_LAUNCH("cabs_pow");
+  return SYG_OK;
+}
+
+extern "C" int syg_mel_dense_f32(const float* P, int64_t B, int64_t T, int F, const float* basis, int M,
+                                 float* mel_out, void* stream) {
+  SYG_REQUIRE(P && basis && mel_out, "mel_dense: null pointer argument");
+  SYG_REQUIRE(B >= 1 && T >= 1 && F >= 1 && F <= 16385 && M >= 1, "mel_dense: bad shape");
+  SYG_REQUIRE(B * T < (int64_t)0x7fffffff, "mel_dense: grid too large");
+  const size_t lds = (size_t)F * sizeof(float);
+  int rc = set_lds((const void*)mel_dense_kernel, lds, "mel_dense");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mel_dense_kernel, dim3((unsigned)(B * T)), dim3(256), lds, (hipStream_t)stream, P, T, F, basis,
+                     M, mel_out);
+  SYG_CHECK_LAUNCH("mel_dense");
+  return SYG_OK;
+}
+
+extern "C" int64_t syg_welch_work_bytes(int64_t B, int nfft) {
+  if (B < 1 || nfft < 2) return -1;
+  return B * (int64_t)WELCH_NBLK * (nfft / 2 + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg, int step, int nfft,
+                             const float* window, const float* twiddle, int detrend, double scale, float* psd_out,
+                             void* work, void* stream) {
+  SYG_REQUIRE(x && window && twiddle && psd_out && work, "welch: null pointer argument");
+  SYG_REQUIRE(is_pow2(nfft) && nfft >= 8 && nfft <= 2 * MAX_N, "welch: nfft must be a power of two in [8, %d]",
+              2 * MAX_N);
+  SYG_REQUIRE(nperseg >= 1 && nperseg <= nfft && step >= 1 && step <= nperseg, "welch: bad nperseg/step");
+  SYG_REQUIRE(B >= 1 && B <= 65535 && L >= nperseg && ldx >= L, "welch: bad B/L/ldx");
+  SYG_REQUIRE(detrend == 0 || detrend == 1, "welch: detrend must be 0 (none) or 1 (constant)");
+  const int64_t nseg = (L - (nperseg - step)) / step;
+  SYG_REQUIRE(nseg >= 1, "welch: no complete segment");
+  const int M = nfft / 2, F = M + 1;
+  const size_t lds = (size_t)M * 2 * sizeof(float2);
+  int rc = set_lds((const void*)welch_partial_kernel, lds, "welch");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(welch_partial_kernel, dim3(WELCH_NBLK, (unsigned)B), dim3(WELCH_NT), lds, st, x, L, ldx, nperseg,
+                     step, nfft, nseg, window, (const float2*)twiddle, detrend, (float*)work);
+  SYG_CHECK_LAUNCH("welch_partial");
+  hipLaunchKernelGGL(welch_final_kernel, dim3((F + 255) / 256, (unsigned)B), dim3(256), 0, st, (const float*)work,
+                     WELCH_NBLK, F, nseg, scale, 0, psd_out);
+  SYG_CHECK_LAUNCH("welch_final");
+  return SYG_OK;
+}

@@ -36,15 +36,17 @@ __global__ __launch_bounds__(NT) void logmel_dct_kernel(float* __restrict__ mel,
     float m = red[0];
     for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, red[i]);
     const float ref = ref_is_max ? m : fabsf(ref_value);
-    const float refdb = 10.f * log10f(fmaxf(amin, ref));
-    s_refdb = refdb;
+    // dB values are formed as 10*(log10 x - log10 ref): the difference of logs is exact (0) when
+    // x == ref, whatever the compiler contracts into FMAs
+    const float reflog = log10f(fmaxf(amin, ref));
+    s_refdb = reflog;
     // log_spec.max() - top_db, with log_spec monotone in the power
-    s_floor = (top_db >= 0.f) ? (10.f * log10f(fmaxf(amin, m)) - refdb) - top_db : -3.4e38f;
+    s_floor = (top_db >= 0.f) ? 10.f * (log10f(fmaxf(amin, m)) - reflog) - top_db : -3.4e38f;
   }
   __syncthreads();
-  const float refdb = s_refdb, flo = s_floor;
+  const float reflog = s_refdb, flo = s_floor;
   for (int64_t i = tid; i < n; i += NT) {
-    float v = 10.f * log10f(fmaxf(amin, src[i])) - refdb;
+    float v = 10.f * (log10f(fmaxf(amin, src[i])) - reflog);
     dst[i] = fmaxf(v, flo);
   }
   if (mfcc == nullptr) return;

@@ -199,3 +199,146 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
     mel, _, _ = stft2048_mel(y, sr, hop, center, window, 2048, n_mels, fmin, fmax)
     _, mf = logmel_dct(mel, n_mfcc, lifter=lifter)
     return mf
+
+
+# ------------------------------------------------------------------ generic pow2 kernels
+def is_pow2(n: int) -> bool:
+    return n >= 2 and (n & (n - 1)) == 0
+
+
+def twiddle_rfft_dev(n_fft) -> torch.Tensor:
+    """[n_fft + n_fft/2, 2]: W_nfft^k followed by W_{nfft/2}^k (layout of stft_pow2 / welch)."""
+    return _cached(("twr", n_fft), lambda: _dev(np.concatenate([T.twiddles(n_fft), T.twiddles(n_fft // 2)], axis=0)))
+
+
+def fft_pow2(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """Batched complex FFT of x [batch, n, 2] float32, n a power of two <= 8192."""
+    require_gpu()
+    if x.dim() != 3 or x.shape[2] != 2 or x.dtype != torch.float32:
+        raise ValueError("x must be float32 [batch, n, 2]")
+    x = x.contiguous()
+    batch, n, _ = x.shape
+    out = torch.empty_like(x)
+    rc = lib().syg_fft_pow2_c2c_f32(_ptr(x), _ptr(out), batch, n, int(inverse), _ptr(twiddle_dev(n)),
+                                    C.c_void_p(_stream_ptr()))
+    check(rc, "syg_fft_pow2_c2c_f32")
+    return out
+
+
+def stft_pow2(y: torch.Tensor, n_fft: int, hop: int, center: bool = True, window="hann", win_length=None):
+    """Generic framed STFT, frame-major complex [B, T, 1 + n_fft/2, 2]."""
+    require_gpu()
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    B, L = y.shape
+    win_length = n_fft if win_length is None else win_length
+    Tn = num_frames(L, n_fft, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    win = window_dev(window, win_length, n_fft)
+    out = torch.empty((B, Tn, n_fft // 2 + 1, 2), dtype=torch.float32, device=y.device)
+    rc = lib().syg_stft_pow2_c2c_f32(_ptr(y), B, L, y.stride(0), n_fft, hop, int(center), Tn, _ptr(win),
+                                     _ptr(twiddle_rfft_dev(n_fft)), _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_pow2_c2c_f32")
+    return out
+
+
+def stft_any(y, n_fft, hop, center=True, window="hann", win_length=None):
+    """Complex STFT [B, T, F, 2]: the wave-FFT kernel for n_fft = 2048, the LDS Stockham kernel otherwise."""
+    if n_fft == 2048:
+        return stft2048_c2c(y, hop, center, window, 2048 if win_length is None else win_length)
+    if not is_pow2(n_fft) or n_fft < 8 or n_fft > 16384:
+        raise SygnalsHipError(f"n_fft={n_fft}: only powers of two in [8, 16384] are implemented on the device")
+    return stft_pow2(y, n_fft, hop, center, window, win_length)
+
+
+def cabs_pow(x: torch.Tensor, power: int = 1) -> torch.Tensor:
+    """|x|^power (power 1 or 2) of an interleaved complex tensor [..., 2] -> [...]."""
+    require_gpu()
+    x = x.contiguous()
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    rc = lib().syg_cabs_pow_f32(_ptr(x), out.numel(), int(power), _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_cabs_pow_f32")
+    return out
+
+
+def mel_dense(P: torch.Tensor, basis: torch.Tensor) -> torch.Tensor:
+    """mel [B, M, T] from frame-major power P [B, T, F] and a dense basis [M, F]."""
+    require_gpu()
+    P = P.contiguous()
+    B, Tn, F = P.shape
+    M = basis.shape[0]
+    out = torch.empty((B, M, Tn), dtype=torch.float32, device=P.device)
+    rc = lib().syg_mel_dense_f32(_ptr(P), B, Tn, F, _ptr(basis), M, _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_mel_dense_f32")
+    return out
+
+
+def spectral_stats(mag: torch.Tensor, freqs: torch.Tensor, roll_percent: float = 0.85, bw_p: float = 2.0):
+    """Per-frame statistics of frame-major magnitudes mag [N, F]; returns [8, N] (SYG_STAT_* rows)."""
+    require_gpu()
+    if not 0.0 <= roll_percent <= 1.0:
+        raise ValueError("roll_percent must be between 0.0 and 1.0.")
+    if bw_p <= 0:
+        raise ValueError("Order 'p' for spectral bandwidth must be positive.")
+    mag = mag.contiguous()
+    N, F = mag.shape
+    out = torch.empty((8, N), dtype=torch.float32, device=mag.device)
+    rc = lib().syg_spectral_stats_f32(_ptr(mag), N, F, _ptr(freqs), float(roll_percent), float(bw_p), _ptr(out),
+                                      C.c_void_p(_stream_ptr()))
+    check(rc, "syg_spectral_stats_f32")
+    return out
+
+
+def contrast_pv(mag: torch.Tensor, cplan: np.ndarray) -> torch.Tensor:
+    """Peak / valley tail means [2, R, N] of frame-major magnitudes mag [N, F]."""
+    require_gpu()
+    mag = mag.contiguous()
+    N, F = mag.shape
+    cplan = np.ascontiguousarray(cplan, dtype=np.int32)
+    out = torch.empty((2, int(cplan[0]), N), dtype=torch.float32, device=mag.device)
+    rc = lib().syg_contrast_pv_f32(_ptr(mag), N, F, cplan.ctypes.data_as(C.c_void_p), _ptr(out),
+                                   C.c_void_p(_stream_ptr()))
+    check(rc, "syg_contrast_pv_f32")
+    return out
+
+
+def sosfiltfilt(x: torch.Tensor, sos: np.ndarray, zi: np.ndarray, padlen: int) -> torch.Tensor:
+    """Batched zero-phase SOS filtering of x [B, L] (scipy.signal.sosfiltfilt semantics)."""
+    require_gpu()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B, L = x.shape
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    zi = np.ascontiguousarray(zi, dtype=np.float64)
+    S = sos.shape[0]
+    if L <= padlen:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {padlen}.")
+    nbytes = lib().syg_sosfiltfilt_work_bytes(B, L, padlen, S)
+    if nbytes < 0:
+        raise SygnalsHipError(f"sosfiltfilt: unsupported configuration (sections={S}, max 8)")
+    work = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+    y = torch.empty((B, L), dtype=torch.float32, device=x.device)
+    rc = lib().syg_sosfiltfilt_f32(_ptr(x), B, L, x.stride(0), sos.ctypes.data_as(C.c_void_p),
+                                   zi.ctypes.data_as(C.c_void_p), S, int(padlen), _ptr(y), y.stride(0), _ptr(work),
+                                   C.c_void_p(_stream_ptr()))
+    check(rc, "syg_sosfiltfilt_f32")
+    return y
+
+
+def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: np.ndarray, detrend: bool,
+          scale: float) -> torch.Tensor:
+    """Welch PSD [B, 1 + nfft/2] of x [B, L]."""
+    require_gpu()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B, L = x.shape
+    win = _dev(np.asarray(window_host, dtype=np.float32))
+    nbytes = lib().syg_welch_work_bytes(B, nfft)
+    work = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((B, nfft // 2 + 1), dtype=torch.float32, device=x.device)
+    rc = lib().syg_welch_f32(_ptr(x), B, L, x.stride(0), nperseg, nperseg - noverlap, nfft, _ptr(win),
+                             _ptr(twiddle_rfft_dev(nfft)), int(bool(detrend)), float(scale), _ptr(out), _ptr(work),
+                             C.c_void_p(_stream_ptr()))
+    check(rc, "syg_welch_f32")
+    return out

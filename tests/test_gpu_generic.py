@@ -1,0 +1,176 @@
+"""GPU parity of the generic kernels (pow2 FFT, generic STFT, dense mel, stand-alone spectral
+statistics / contrast, sosfiltfilt, Welch) against the oracle and against golden vectors that
+were produced by the reference's own functions (tests/golden/ref_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import cpu_ref as O
+from tests.gpu_util import assert_parity, peak_rel
+
+TOL = 1e-5
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sygnals_amd import ops
+    ops.require_gpu()
+    return ops
+
+
+def c2n(t):
+    a = t.cpu().numpy()
+    return a[..., 0] + 1j * a[..., 1]
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_fft_pow2_forward_inverse(ops, n):
+    rng = np.random.default_rng(n)
+    x = (rng.normal(size=(5, n)) + 1j * rng.normal(size=(5, n))).astype(np.complex64)
+    xd = torch.from_numpy(np.stack([x.real, x.imag], -1).copy()).cuda()
+    X = c2n(ops.fft_pow2(xd))
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    assert peak_rel(X, ref) <= TOL
+    xi = c2n(ops.fft_pow2(xd, inverse=True))
+    assert peak_rel(xi, np.fft.ifft(x.astype(np.complex128), axis=1)) <= TOL
+    back = c2n(ops.fft_pow2(ops.fft_pow2(xd), inverse=True))
+    assert peak_rel(back, x) <= TOL
+
+
+@pytest.mark.parametrize("n_fft,hop,win_length,center", [(64, 16, None, True), (256, 64, None, True),
+                                                         (512, 128, 400, True), (1024, 256, None, True),
+                                                         (1024, 256, None, False), (4096, 1024, None, True),
+                                                         (8192, 4096, None, True), (2048, 512, None, True)])
+def test_stft_pow2_matches_oracle(ops, n_fft, hop, win_length, center):
+    Y = O.synth_clips(3, 20000, 16000, seed=n_fft)
+    if n_fft == 2048:
+        X = c2n(ops.stft_pow2(ops.to_device_f32(Y), n_fft, hop, center, "hann", win_length))
+        X2 = c2n(ops.stft2048_c2c(ops.to_device_f32(Y), hop, center))
+        assert peak_rel(X2, X) <= 2e-6          # the two device kernels agree
+    else:
+        X = c2n(ops.stft_any(ops.to_device_f32(Y), n_fft, hop, center, "hann", win_length))
+    for i in range(3):
+        ref = O.stft(Y[i].astype(np.float64), n_fft, hop, win_length, "hann", center).T
+        assert X[i].shape == ref.shape
+        assert peak_rel(X[i], ref) <= TOL
+
+
+def test_reference_shape_cases(ops):
+    """Frame counts pinned by reference tests/test_features_manager.py:183-220."""
+    assert ops.stft_any(ops.to_device_f32(np.ones((1, 512), np.float32)), 1024, 256).shape[1] == 3
+    assert ops.stft_any(ops.to_device_f32(np.ones((1, 100), np.float32)), 2048, 512).shape[1] == 1
+
+
+def test_mel_dense_and_cabs(ops):
+    from sygnals_amd import _tables as T
+    Y = O.synth_clips(2, 16000, 16000, seed=9)
+    X = ops.stft_any(ops.to_device_f32(Y), 1024, 256)
+    P = ops.cabs_pow(X, 2)
+    Mg = ops.cabs_pow(X, 1)
+    basis = T.mel_filterbank(16000, 1024, 64)
+    mel = ops.mel_dense(P, torch.from_numpy(basis).cuda()).cpu().numpy()
+    for i in range(2):
+        S = np.abs(O.stft(Y[i].astype(np.float64), 1024, 256))
+        assert_parity(Mg[i].cpu().numpy().T, S, TOL, "magnitude")
+        assert_parity(mel[i], O.melspectrogram(S ** 2, 16000, 1024, 64), TOL, "dense mel")
+
+
+def test_spectral_stats_vs_reference_golden(ops):
+    """Stand-alone statistics kernel against the REFERENCE's own per-frame outputs."""
+    g = np.load(os.path.join(G, "ref_freq.npz"))
+    S, fr = g["spectra"], g["freqs"]
+    st = ops.spectral_stats(torch.from_numpy(S.astype(np.float32)).cuda(),
+                            torch.from_numpy(fr.astype(np.float32)).cuda()).cpu().numpy()
+    assert_parity(st[0], g["centroid"], TOL, "centroid")
+    assert_parity(st[1], g["bandwidth"], TOL, "bandwidth")
+    assert_parity(st[2], g["flatness"], 2e-5, "flatness")   # geometric mean over 1025 logs in fp32
+    ref = O.spectral_stats_frames(S.astype(np.float32).astype(np.float64).T, fr)
+    sure = ref["rolloff_margin"] > 1e-6
+    assert (fr[st[3].astype(int)][sure] == g["rolloff85"][sure]).all()
+    assert (np.abs(st[3].astype(int) - ref["rolloff_bin"]) <= 1).all()
+    sure = ref["dominant_margin"] > 1e-6
+    assert (fr[st[4].astype(int)][sure] == g["dominant"][sure]).all()
+    for rp, key in ((0.5, "rolloff50"), (0.0, "rolloff0")):
+        s2 = ops.spectral_stats(torch.from_numpy(S.astype(np.float32)).cuda(),
+                                torch.from_numpy(fr.astype(np.float32)).cuda(), roll_percent=rp).cpu().numpy()
+        r2 = O.spectral_stats_frames(S.astype(np.float32).astype(np.float64).T, fr, roll_percent=rp)
+        sure = r2["rolloff_margin"] > 1e-6
+        assert (fr[s2[3].astype(int)][sure] == g[key][sure]).all()
+    s3 = ops.spectral_stats(torch.from_numpy(S.astype(np.float32)).cuda(),
+                            torch.from_numpy(fr.astype(np.float32)).cuda(), bw_p=1.0).cpu().numpy()
+    assert_parity(s3[1], g["bandwidth_p1"], TOL, "bandwidth p=1")
+
+
+def test_contrast_standalone(ops):
+    from sygnals_amd import _tables as T
+    rng = np.random.default_rng(4)
+    S = np.abs(rng.normal(size=(37, 513))).astype(np.float32)
+    fr = O.fft_frequencies(22050, 1024)
+    plan = T.contrast_plan(fr, 22050)
+    pv = ops.contrast_pv(torch.from_numpy(S).cuda(), plan).cpu().numpy()
+    for k, (bins, kk) in enumerate(O.contrast_bands(fr, 22050)):
+        srt = np.sort(S.astype(np.float64)[:, bins], axis=1)
+        assert_parity(pv[1, k], srt[:, :kk].mean(axis=1), TOL, f"valley {k}")
+        assert_parity(pv[0, k], srt[:, -kk:].mean(axis=1), TOL, f"peak {k}")
+    # ties and constant rows
+    S2 = np.ones((3, 513), np.float32); S2[1, 100:200] = 5.0; S2[2] = 0.0
+    pv = ops.contrast_pv(torch.from_numpy(S2).cuda(), plan).cpu().numpy()
+    for k, (bins, kk) in enumerate(O.contrast_bands(fr, 22050)):
+        srt = np.sort(S2.astype(np.float64)[:, bins], axis=1)
+        assert_parity(pv[1, k], srt[:, :kk].mean(axis=1), TOL, "valley ties")
+        assert_parity(pv[0, k], srt[:, -kk:].mean(axis=1), TOL, "peak ties")
+
+
+DESIGNS = ["bp4_48k", "lp5_1k", "hp5_1k", "bs5_1k", "lp8_1k", "bp2_16k"]
+
+
+@pytest.mark.parametrize("name", DESIGNS)
+def test_sosfiltfilt_vs_reference_golden(ops, name):
+    """Device zero-phase filtering against outputs of the REFERENCE's apply_sos_filter."""
+    g = np.load(os.path.join(G, "ref_filters.npz"))
+    sos, x, yref = g[f"{name}_sos"], g[f"{name}_x"], g[f"{name}_y"]
+    xb = np.stack([x, -0.5 * x, x[::-1]]).astype(np.float32)
+    y = ops.sosfiltfilt(ops.to_device_f32(xb), sos, O.sosfilt_zi(sos), O.sosfiltfilt_padlen(sos)).cpu().numpy()
+    assert_parity(y[0], yref, TOL, name)
+    assert_parity(y[1], -0.5 * yref, TOL, name + " (linearity)")
+    assert_parity(y[2], O.apply_sos_filter(sos, xb[2].astype(np.float64)), TOL, name + " (reversed)")
+
+
+def test_sosfiltfilt_c3_clips(ops):
+    sos = O.design_butterworth_sos((300.0, 3400.0), 48000.0, 4, "bandpass")
+    Y = O.synth_clips(6, 48000, 48000, seed=21)
+    y = ops.sosfiltfilt(ops.to_device_f32(Y), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
+    for i in range(6):
+        assert_parity(y[i], O.apply_sos_filter(sos, Y[i].astype(np.float64)), TOL, f"C3 clip {i}")
+    # ragged: shortest legal input (L = padlen + 1) and a non-multiple of the chunk size
+    for L in (28, 257, 1000):
+        x = Y[:2, :L].copy()
+        y = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
+        assert_parity(y, np.stack([O.apply_sos_filter(sos, r.astype(np.float64)) for r in x]), TOL, f"L={L}")
+    with pytest.raises(ValueError, match="greater than padlen, which is 27"):
+        ops.sosfiltfilt(ops.to_device_f32(Y[:1, :27]), sos, O.sosfilt_zi(sos), 27)
+
+
+WELCH = [("w4096", dict(nperseg=4096)), ("w256", dict(nperseg=256)), ("w1024o768", dict(nperseg=1024, noverlap=768)),
+         ("w512nfft1024", dict(nperseg=512, nfft=1024)), ("w1024spec", dict(nperseg=1024, scaling="spectrum")),
+         ("w1024nodet", dict(nperseg=1024, detrend=False)), ("w1024hamming", dict(nperseg=1024, window="hamming"))]
+
+
+@pytest.mark.parametrize("tag,kw", WELCH)
+def test_welch_vs_reference_golden(ops, tag, kw):
+    import scipy.signal
+    g = np.load(os.path.join(G, "ref_dsp.npz"))
+    x = g["x20000"]
+    nperseg = kw["nperseg"]; nfft = kw.get("nfft", nperseg); nov = kw.get("noverlap", nperseg // 2)
+    w = scipy.signal.get_window(kw.get("window", "hann"), nperseg)
+    scale = 1.0 / (48000.0 * (w * w).sum()) if kw.get("scaling", "density") == "density" else 1.0 / w.sum() ** 2
+    xb = np.stack([x, 2 * x]).astype(np.float32)
+    p = ops.welch(ops.to_device_f32(xb), nperseg, nov, nfft, w, kw.get("detrend", "constant") == "constant",
+                  scale).cpu().numpy()
+    assert_parity(p[0], g[f"welch_{tag}_p"], TOL, tag)
+    assert_parity(p[1], 4 * g[f"welch_{tag}_p"], TOL, tag + " (x2 -> x4)")
