@@ -85,7 +85,8 @@ int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int 
  *   mel        [B, M, T] mel power; converted to dB IN PLACE unless logmel_out given
  *   dct        [K, M] DCT matrix rows (orthonormal DCT-II rows for the default)
  *   lifter     optional [K] multiplicative lifter (NULL = none)
- *   ref_is_max 1: ref = max over the clip's [M, T] (ref=np.max); 0: ref = ref_value
+ *   ref_is_max 1: ref = max over the clip's [M, T] (ref=np.max); 0: ref = ref_value;
+ *              2: `mel` already holds dB values (mfcc(S=log_mel)): DCT only, mel untouched
  *   top_db     < 0 disables the clamp
  *   mfcc_out   [B, K, T]  (NULL: only the dB conversion)
  * ------------------------------------------------------------------------------- */
@@ -101,6 +102,23 @@ int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const float* dct
  * ------------------------------------------------------------------------------- */
 int syg_fft_pow2_c2c_f32(const float* in, float* out, int64_t batch, int n, int inverse,
                          const float* twiddle, void* stream);
+
+/* Strided form used to compose transforms longer than 8192 points (four-step) and Bluestein
+ * for arbitrary n (scipy.fft.fft(x, n) accepts any n, dsp.py:104).  Element e of transform
+ * (o, b) is at in[o*in_os + b*in_bs + e*in_es] (complex elements); if bign > 0 output k of
+ * transform b is multiplied by W_bign^(b*k); every output is multiplied by `scale`.  in != out. */
+int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t outer, int64_t batch, int n, int inverse,
+                                 const float* twiddle, int64_t in_os, int64_t in_bs, int64_t in_es,
+                                 int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale,
+                                 void* stream);
+
+/* out[i] = a[i] * b[i mod nb] (complex64; conj_b != 0 multiplies by conj(b)); may be in place. */
+int syg_cmul_c64(const float* a, const float* b, float* out, int64_t na, int64_t nb, int conj_b, void* stream);
+
+/* Real rows -> zero-padded / truncated complex rows with an optional window (apply_window,
+ * dsp.py:641-691, then the implicit pad/truncate of fft(x, n)): out [rows, n] complex64. */
+int syg_pack_real_c64(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window, float* out,
+                      int64_t n, void* stream);
 
 /* Generic framed STFT for any power-of-two n_fft in [8, 16384] (slow path of
  * compute_stft and of extract_features for frame lengths other than 2048).
@@ -125,6 +143,12 @@ int syg_spectral_stats_f32(const float* mag, int64_t N, int F, const float* freq
  * for each band row r: mean of the k[r] smallest / largest values of bins lo[r]..hi[r]-1.
  *   out [2, n_rows, N] (peak then valley). */
 int syg_contrast_pv_f32(const float* mag, int64_t N, int F, const int32_t* cplan_host, float* out, void* stream);
+
+/* contrast[b, r, t] = power_to_db(peak) - power_to_db(valley) (ref 1, amin, top_db clamp per
+ * [R, T] matrix), the last step of librosa.feature.spectral_contrast (frequency_domain.py:200-207).
+ *   pv [B, 2, R, T] (peak, valley) -> out [B, R, T]; top_db < 0 disables the clamp. */
+int syg_contrast_db_f32(const float* pv, int64_t B, int R, int64_t T, float amin, float top_db, float* out,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Zero-phase SOS filtering: scipy.signal.sosfiltfilt(sos, x) (padtype='odd') as called by

@@ -25,11 +25,15 @@ SIGNATURES = {
     "syg_stft2048_c2c_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p]),
     "syg_logmel_dct_f32": (_i, [_p, _l, _i, _l, _p, _i, _p, _f, _f, _i, _f, _p, _p, _p]),
     "syg_fft_pow2_c2c_f32": (_i, [_p, _p, _l, _i, _i, _p, _p]),
+    "syg_fft_pow2_strided_c2c_f32": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _l, _l, _l, _l, _l, _l, _f, _p]),
+    "syg_cmul_c64": (_i, [_p, _p, _p, _l, _l, _i, _p]),
+    "syg_pack_real_c64": (_i, [_p, _l, _l, _l, _p, _p, _l, _p]),
     "syg_stft_pow2_c2c_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _l, _p, _p, _p, _p]),
     "syg_cabs_pow_f32": (_i, [_p, _l, _i, _p, _p]),
     "syg_mel_dense_f32": (_i, [_p, _l, _l, _i, _p, _i, _p, _p]),
     "syg_spectral_stats_f32": (_i, [_p, _l, _i, _p, _f, _f, _p, _p]),
     "syg_contrast_pv_f32": (_i, [_p, _l, _i, _p, _p, _p]),
+    "syg_contrast_db_f32": (_i, [_p, _l, _i, _l, _f, _f, _p, _p]),
     "syg_sosfiltfilt_work_bytes": (_l, [_l, _l, _i, _i]),
     "syg_sosfiltfilt_f32": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _p, _l, _p, _p]),
     "syg_welch_work_bytes": (_l, [_l, _i]),

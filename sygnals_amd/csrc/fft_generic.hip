@@ -205,6 +205,61 @@ __global__ void welch_final_kernel(const float* __restrict__ partial, int nblk, 
   psd[b * (int64_t)F + k] = (float)s;
 }
 
+
+// Strided variant used to compose large transforms (four-step) on the host side:
+// element e of transform (o, b) lives at in[o*in_os + b*in_bs + e*in_es]; the output may be
+// multiplied by the four-step twiddle W_bign^(b*k) (conjugated for the inverse).
+__global__ void fft_pow2_strided_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n, int inverse,
+                                        const float2* __restrict__ tw, int64_t in_os, int64_t in_bs, int64_t in_es,
+                                        int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* x = reinterpret_cast<float2*>(lds);
+  float2* y = x + n;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int64_t b = blockIdx.x, o = blockIdx.y;
+  const float2* ip = in + o * in_os + b * in_bs;
+  float2* op = out + o * out_os + b * out_bs;
+  for (int i = tid; i < n; i += nt) {
+    float2 v = ip[(int64_t)i * in_es];
+    if (inverse) v.y = -v.y;
+    x[i] = v;
+  }
+  __syncthreads();
+  float2* r = block_fft(x, y, n, tw, tid, nt);
+  for (int k = tid; k < n; k += nt) {
+    float2 v = r[k];
+    if (bign > 0) {
+      const int64_t e = (b * (int64_t)k) % bign;
+      double sn, cs;
+      sincospi(-2.0 * (double)e / (double)bign, &sn, &cs);
+      v = cmul(v, make_float2((float)cs, (float)sn));
+    }
+    v.x *= scale; v.y *= scale;
+    if (inverse) v.y = -v.y;
+    op[(int64_t)k * out_es] = v;
+  }
+}
+
+// out[i] = a[i] * b[i mod nb]   (conj_b: multiply by conj(b))
+__global__ void cmul_kernel(const float2* __restrict__ a, const float2* __restrict__ b, float2* __restrict__ out,
+                            int64_t na, int64_t nb, int conj_b) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < na; i += (int64_t)gridDim.x * blockDim.x) {
+    const float2 u = a[i], v = b[i % nb];
+    out[i] = conj_b ? cmulc(u, v) : cmul(u, v);
+  }
+}
+
+// out[r, i] = (i < len ? x[r, i] * (win ? win[i] : 1) : 0, 0) for i < n : real -> zero-padded complex rows
+__global__ void pack_real_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, const float* __restrict__ win,
+                                 float2* __restrict__ out, int64_t n) {
+  const int64_t r = blockIdx.y;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i < len) v = win ? x[r * ldx + i] * win[i] : x[r * ldx + i];
+    out[r * n + i] = make_float2(v, 0.f);
+  }
+}
+
 bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
 int fft_threads(int n) { int t = n / 4; if (t < 64) t = 64; if (t > 1024) t = 1024; return t; }
 
@@ -314,5 +369,48 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
   hipLaunchKernelGGL(welch_final_kernel, dim3((F + 255) / 256, (unsigned)B), dim3(256), 0, st, (const float*)work,
                      WELCH_NBLK, F, nseg, scale, 0, psd_out);
   SYG_CHECK_LAUNCH("welch_final");
+  return SYG_OK;
+}
+
+extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t outer, int64_t batch, int n,
+                                            int inverse, const float* twiddle, int64_t in_os, int64_t in_bs,
+                                            int64_t in_es, int64_t out_os, int64_t out_bs, int64_t out_es,
+                                            int64_t bign, float scale, void* stream) {
+  SYG_REQUIRE(in && out && twiddle, "fft_pow2_strided: null pointer argument");
+  SYG_REQUIRE(is_pow2(n) && n <= MAX_N, "fft_pow2_strided: n must be a power of two in [2, %d] (got %d)", MAX_N, n);
+  SYG_REQUIRE(batch >= 1 && batch < (int64_t)0x7fffffff && outer >= 1 && outer <= 65535,
+              "fft_pow2_strided: bad batch/outer");
+  SYG_REQUIRE(in != out, "fft_pow2_strided: in-place operation is not supported");
+  const size_t lds = (size_t)n * 2 * sizeof(float2);
+  int rc = set_lds((const void*)fft_pow2_strided_kernel, lds, "fft_pow2_strided");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fft_pow2_strided_kernel, dim3((unsigned)batch, (unsigned)outer), dim3(fft_threads(n)), lds,
+                     (hipStream_t)stream, (const float2*)in, (float2*)out, n, inverse, (const float2*)twiddle, in_os,
+                     in_bs, in_es, out_os, out_bs, out_es, bign, scale);
+  SYG_CHECK_LAUNCH("fft_pow2_strided");
+  return SYG_OK;
+}
+
+extern "C" int syg_cmul_c64(const float* a, const float* b, float* out, int64_t na, int64_t nb, int conj_b,
+                            void* stream) {
+  SYG_REQUIRE(a && b && out, "cmul: null pointer argument");
+  SYG_REQUIRE(na >= 1 && nb >= 1, "cmul: bad sizes");
+  int64_t blocks = (na + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(cmul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float2*)a,
+                     (const float2*)b, (float2*)out, na, nb, conj_b);
+  SYG_CHECK_LAUNCH("cmul");
+  return SYG_OK;
+}
+
+extern "C" int syg_pack_real_c64(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window,
+                                 float* out, int64_t n, void* stream) {
+  SYG_REQUIRE(x && out, "pack_real: null pointer argument");
+  SYG_REQUIRE(rows >= 1 && rows <= 65535 && len >= 0 && n >= 1 && ldx >= len, "pack_real: bad sizes");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_real_kernel, dim3((unsigned)blocks, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x,
+                     len < n ? len : n, ldx, window, (float2*)out, n);
+  SYG_CHECK_LAUNCH("pack_real");
   return SYG_OK;
 }

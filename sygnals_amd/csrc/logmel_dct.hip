@@ -24,8 +24,13 @@ __global__ __launch_bounds__(NT) void logmel_dct_kernel(float* __restrict__ mel,
   const int64_t b = blockIdx.x;
   float* src = mel + b * (int64_t)M * T;
   float* dst = logmel ? logmel + b * (int64_t)M * T : src;
+  const int ktiles = (K + 15) / 16;
+  const int ttiles = (int)((T + 15) / 16);
+  const int f = lane & 15, g = lane >> 4;
   const int64_t n = (int64_t)M * T;
 
+  if (ref_is_max == 2) goto dct_stage;  // input is already in dB: DCT only
+  {
   // ---- per-clip maximum (ref=np.max and the top_db floor both need it)
   float mx = 0.f;  // power is non-negative
   for (int64_t i = tid; i < n; i += NT) mx = fmaxf(mx, src[i]);
@@ -49,14 +54,14 @@ __global__ __launch_bounds__(NT) void logmel_dct_kernel(float* __restrict__ mel,
     float v = 10.f * (log10f(fmaxf(amin, src[i])) - reflog);
     dst[i] = fmaxf(v, flo);
   }
+  }
   if (mfcc == nullptr) return;
   __threadfence_block();
   __syncthreads();
+dct_stage:
+  if (ref_is_max == 2) dst = src;
 
   // ---- DCT: out[k, t] = sum_m dct[k, m] * dB[m, t]   (16x16 output tiles on the MFMA)
-  const int ktiles = (K + 15) / 16;
-  const int ttiles = (int)((T + 15) / 16);
-  const int f = lane & 15, g = lane >> 4;
   for (int tile = w; tile < ktiles * ttiles; tile += NT / 64) {
     const int kt = tile / ttiles, tt = tile % ttiles;
     const int krow = kt * 16 + f;          // A operand row
@@ -90,7 +95,9 @@ extern "C" int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const
                                   float* logmel_out, float* mfcc_out, void* stream) {
   SYG_REQUIRE(mel, "logmel_dct: null mel pointer");
   SYG_REQUIRE(B >= 1 && M >= 1 && T >= 1, "logmel_dct: need B, M, T >= 1");
-  SYG_REQUIRE(amin > 0.f, "logmel_dct: amin must be strictly positive");
+  SYG_REQUIRE(ref_is_max >= 0 && ref_is_max <= 2, "logmel_dct: ref_is_max must be 0, 1 or 2");
+  SYG_REQUIRE(ref_is_max == 2 || amin > 0.f, "logmel_dct: amin must be strictly positive");
+  SYG_REQUIRE(ref_is_max != 2 || mfcc_out, "logmel_dct: DCT-only mode needs mfcc_out");
   if (mfcc_out) SYG_REQUIRE(dct && K >= 1 && K <= M, "logmel_dct: need dct and 1 <= K <= M (K=%d M=%d)", K, M);
   SYG_REQUIRE(B < (int64_t)0x7fffffff, "logmel_dct: batch too large");
   hipLaunchKernelGGL(logmel_dct_kernel, dim3((unsigned)B), dim3(NT), 0, (hipStream_t)stream, mel, M, T, dct, K,

@@ -155,6 +155,33 @@ __global__ __launch_bounds__(256) void contrast_pv_kernel(const float* __restric
   }
 }
 
+
+// contrast[b, r, t] = power_to_db(peak)[r, t] - power_to_db(valley)[r, t], each power_to_db with
+// ref = 1, amin, and the top_db clamp relative to the maximum of its own [R, T] matrix
+// (librosa.feature.spectral_contrast, linear=False).  One workgroup per clip.
+__global__ __launch_bounds__(256) void contrast_db_kernel(const float* __restrict__ pv, int R, int64_t T, float amin,
+                                                          float top_db, float* __restrict__ out) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t b = blockIdx.x, n = (int64_t)R * T;
+  const float* pk = pv + (b * 2 + 0) * n;
+  const float* vl = pv + (b * 2 + 1) * n;
+  float m0 = 0.f, m1 = 0.f;
+  for (int64_t i = tid; i < n; i += 256) { m0 = fmaxf(m0, pk[i]); m1 = fmaxf(m1, vl[i]); }
+  m0 = wave_max(m0); m1 = wave_max(m1);
+  if (lane == 0) { red[0][w] = m0; red[1][w] = m1; }
+  __syncthreads();
+  m0 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  m1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  const float f0 = (top_db >= 0.f) ? 10.f * log10f(fmaxf(amin, m0)) - top_db : -3.4e38f;
+  const float f1 = (top_db >= 0.f) ? 10.f * log10f(fmaxf(amin, m1)) - top_db : -3.4e38f;
+  for (int64_t i = tid; i < n; i += 256) {
+    const float a = fmaxf(10.f * log10f(fmaxf(amin, pk[i])), f0);
+    const float c = fmaxf(10.f * log10f(fmaxf(amin, vl[i])), f1);
+    out[b * n + i] = a - c;
+  }
+}
+
 }  // namespace
 }  // namespace syg
 
@@ -192,5 +219,16 @@ extern "C" int syg_contrast_pv_f32(const float* mag, int64_t N, int F, const int
   hipLaunchKernelGGL(contrast_pv_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mag, N, F,
                      cp, out);
   SYG_CHECK_LAUNCH("contrast_pv");
+  return SYG_OK;
+}
+
+extern "C" int syg_contrast_db_f32(const float* pv, int64_t B, int R, int64_t T, float amin, float top_db,
+                                   float* out, void* stream) {
+  SYG_REQUIRE(pv && out, "contrast_db: null pointer argument");
+  SYG_REQUIRE(B >= 1 && B < (int64_t)0x7fffffff && R >= 1 && T >= 1, "contrast_db: bad shape");
+  SYG_REQUIRE(amin > 0.f, "contrast_db: amin must be strictly positive");
+  hipLaunchKernelGGL(contrast_db_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, pv, R, T, amin, top_db,
+                     out);
+  SYG_CHECK_LAUNCH("contrast_db");
   return SYG_OK;
 }

@@ -1,0 +1,99 @@
+"""Minimal signal I/O either side of the hot path (host only).
+
+Follows sygnals/core/data_handler.py: read_data :74 (audio -> (float64 data, sr); CSV with a
+'value' column; NPZ with a 'data' key) and save_data :183-303 (CSV written with index=False --
+which drops the 'time' index of a feature DataFrame, :248 -- NPZ via np.savez with the dict's own
+keys, a single array under 'data').  Audio decoding uses scipy.io.wavfile (the reference goes
+through librosa/soundfile, not installed here): PCM16/24/32 are scaled by 2^(bits-1).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, Tuple, Union
+
+import numpy as np
+import pandas as pd
+
+AUDIO_EXT = {".wav"}
+
+
+def read_audio(path) -> Tuple[np.ndarray, int]:
+    from scipy.io import wavfile
+    sr, data = wavfile.read(str(path))
+    if data.dtype.kind == "i":
+        data = data.astype(np.float64) / float(2 ** (8 * data.dtype.itemsize - 1))
+    elif data.dtype.kind == "u":
+        data = (data.astype(np.float64) - 128.0) / 128.0
+    else:
+        data = data.astype(np.float64)
+    if data.ndim == 2:
+        data = data.T                       # (channels, samples) like librosa.load(mono=False)
+        if data.shape[0] == 1:
+            data = data[0]
+    return data, int(sr)
+
+
+def read_data(path) -> Union[pd.DataFrame, Dict[str, np.ndarray], Tuple[np.ndarray, int]]:
+    p = Path(path)
+    ext = p.suffix.lower()
+    if not p.exists():
+        raise FileNotFoundError(str(p))
+    if ext in AUDIO_EXT:
+        return read_audio(p)
+    if ext == ".csv":
+        return pd.read_csv(p)
+    if ext == ".npz":
+        with np.load(p, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    raise ValueError(f"Unsupported input file format: '{ext}'.")
+
+
+def signal_from(result, column: str = "value", key: str = "data") -> Tuple[np.ndarray, Union[int, None]]:
+    """1-D float64 signal (+ sr if known) from whatever read_data returned."""
+    if isinstance(result, tuple):
+        return np.asarray(result[0], dtype=np.float64), int(result[1])
+    if isinstance(result, pd.DataFrame):
+        if column not in result.columns:
+            raise ValueError(f"CSV input needs a '{column}' column.")
+        return result[column].to_numpy(dtype=np.float64), None
+    if isinstance(result, dict):
+        if key not in result:
+            raise ValueError(f"NPZ input needs a '{key}' array.")
+        sr = int(result["sr"]) if "sr" in result else (int(result["fs"]) if "fs" in result else None)
+        return np.asarray(result[key], dtype=np.float64), sr
+    raise TypeError(f"Unsupported data type: {type(result)}")
+
+
+def save_data(data, output_path, sr=None) -> None:
+    p = Path(output_path).resolve()
+    ext = p.suffix.lower()
+    p.parent.mkdir(parents=True, exist_ok=True)
+    if isinstance(data, pd.DataFrame):
+        if ext == ".csv":
+            data.to_csv(p, index=False)
+        elif ext == ".npz":
+            np.savez(p, **{c: data[c].values for c in data.columns})
+        else:
+            raise ValueError(f"Cannot save DataFrame to core format '{ext}'.")
+    elif isinstance(data, np.ndarray):
+        if ext == ".npz":
+            np.savez(p, data=data)
+        elif ext == ".csv":
+            if data.ndim == 1:
+                pd.DataFrame(data, columns=["value"]).to_csv(p, index=False)
+            elif data.ndim == 2:
+                pd.DataFrame(data).to_csv(p, index=False, header=False)
+            else:
+                raise ValueError("Cannot save NumPy array with >2 dimensions as CSV.")
+        else:
+            raise ValueError(f"Cannot save single NumPy array directly to core format '{ext}'. Use NPZ or CSV.")
+    elif isinstance(data, dict) and all(isinstance(v, np.ndarray) for v in data.values()):
+        if ext != ".npz":
+            raise ValueError(f"Cannot save dictionary of NumPy arrays to core format '{ext}'. Use NPZ.")
+        np.savez(p, **data)
+    elif isinstance(data, tuple) and len(data) == 2 and ext == ".wav":
+        from scipy.io import wavfile
+        x = np.clip(np.asarray(data[0], dtype=np.float64), -1.0, 1.0)
+        wavfile.write(str(p), int(sr or data[1]), np.round(x * 32767.0).astype(np.int16))
+    else:
+        raise TypeError(f"Unsupported data type for core saving handlers: {type(data)}.")

@@ -182,8 +182,12 @@ def logmel_dct(mel: torch.Tensor, n_mfcc: Optional[int] = 13, dct_type: int = 2,
         lw = T.lifter_weights(K, float(lifter))
         lif = _dev(lw) if lw is not None else None
         mf = torch.empty((B, K, Tn), dtype=torch.float32, device=mel.device)
-    ref_is_max = 1 if (ref == "max" or ref is np.max) else 0
-    ref_value = 1.0 if ref_is_max else float(ref)
+    if isinstance(ref, str) and ref == "db":
+        ref_is_max, ref_value = 2, 1.0          # input already in dB: DCT only
+    elif (isinstance(ref, str) and ref == "max") or ref is np.max:
+        ref_is_max, ref_value = 1, 1.0
+    else:
+        ref_is_max, ref_value = 0, float(ref)
     rc = lib().syg_logmel_dct_f32(_ptr(mel), B, M, Tn, _ptr(dct), K, _ptr(lif), float(amin),
                                   float(top_db) if top_db is not None else -1.0, ref_is_max, ref_value,
                                   _ptr(logmel), _ptr(mf), C.c_void_p(_stream_ptr()))
@@ -342,3 +346,113 @@ def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: 
                              C.c_void_p(_stream_ptr()))
     check(rc, "syg_welch_f32")
     return out
+
+
+def contrast_db(pv: torch.Tensor, amin: float = 1e-10, top_db: Optional[float] = 80.0) -> torch.Tensor:
+    """pv [B, 2, R, T] (peak, valley means) -> spectral contrast in dB [B, R, T]."""
+    require_gpu()
+    pv = pv.contiguous()
+    B, two, R, Tn = pv.shape
+    out = torch.empty((B, R, Tn), dtype=torch.float32, device=pv.device)
+    rc = lib().syg_contrast_db_f32(_ptr(pv), B, R, Tn, float(amin), float(top_db) if top_db is not None else -1.0,
+                                   _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_contrast_db_f32")
+    return out
+
+
+# ------------------------------------------------------------------ arbitrary-length FFT
+MAX_LDS_FFT = 8192
+
+
+def _fft_strided(x, out, outer, batch, n, inverse, strides, bign=0, scale=1.0):
+    in_os, in_bs, in_es, out_os, out_bs, out_es = strides
+    rc = lib().syg_fft_pow2_strided_c2c_f32(_ptr(x), _ptr(out), outer, batch, n, int(inverse), _ptr(twiddle_dev(n)),
+                                            in_os, in_bs, in_es, out_os, out_bs, out_es, bign, float(scale),
+                                            C.c_void_p(_stream_ptr()))
+    check(rc, "syg_fft_pow2_strided_c2c_f32")
+
+
+def fft_pow2_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """Complex FFT of rows of x [rows, n, 2], n any power of two up to 2^26 (four-step above 8192)."""
+    rows, n, _ = x.shape
+    if n <= MAX_LDS_FFT:
+        return fft_pow2(x, inverse)
+    lg = n.bit_length() - 1
+    n1 = 1 << (lg // 2)
+    n2 = n // n1
+    if n2 > MAX_LDS_FFT:
+        raise SygnalsHipError(f"FFT length {n} exceeds the supported maximum 2^26")
+    if rows > 65535:
+        raise SygnalsHipError("too many rows for the four-step FFT")
+    x = x.contiguous()
+    tmp = torch.empty_like(x)
+    out = torch.empty_like(x)
+    # step A: N2 transforms of length N1 over n1 (input stride N2), twiddle W_N^(n2*k1), stored [n2][k1]
+    _fft_strided(x, tmp, rows, n2, n1, inverse, (n, 1, n2, n, n1, 1), bign=n)
+    # step B: N1 transforms of length N2 over n2 (input stride N1), output X[k1 + N1*k2]
+    _fft_strided(tmp, out, rows, n1, n2, inverse, (n, 1, n1, n, 1, n1), scale=(1.0 / n if inverse else 1.0))
+    return out
+
+
+def cmul(a: torch.Tensor, b: torch.Tensor, conj_b: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a [.., na, 2] * b [nb, 2] broadcast over i mod nb."""
+    a = a.contiguous(); b = b.contiguous()
+    out = torch.empty_like(a) if out is None else out
+    rc = lib().syg_cmul_c64(_ptr(a), _ptr(b), _ptr(out), a.numel() // 2, b.numel() // 2, int(conj_b),
+                            C.c_void_p(_stream_ptr()))
+    check(rc, "syg_cmul_c64")
+    return out
+
+
+def pack_real(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Real rows [rows, len] -> complex rows [rows, n, 2], windowed, zero-padded / truncated to n."""
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, ln = x.shape
+    out = torch.empty((rows, n, 2), dtype=torch.float32, device=x.device)
+    rc = lib().syg_pack_real_c64(_ptr(x), rows, ln, x.stride(0), _ptr(window), _ptr(out), n,
+                                 C.c_void_p(_stream_ptr()))
+    check(rc, "syg_pack_real_c64")
+    return out
+
+
+def _bluestein_tables(n: int):
+    """Host float64 tables for the chirp-z form of an n-point DFT, forward and inverse.
+
+    w[k] = exp(-i*pi*k^2/n); forward: X = w * IFFT_M(FFT_M(x*w) * FFT_M(wrap(conj w)));
+    the inverse uses the conjugate chirp and folds the 1/n into the final multiply.
+    """
+    m = 1
+    while m < 2 * n - 1:
+        m <<= 1
+    k = np.arange(n, dtype=np.int64)
+    w = np.exp(-1j * np.pi * ((k * k) % (2 * n)).astype(np.float64) / n)
+
+    def wrapped_fft(c):
+        b = np.zeros(m, dtype=np.complex128)
+        b[:n] = c
+        b[m - n + 1:] = c[1:][::-1]
+        return np.fft.fft(b)
+
+    as2 = lambda z: _dev(np.stack([z.real, z.imag], axis=-1).astype(np.float32))
+    fwd = (as2(w), as2(wrapped_fft(np.conj(w))), as2(w))
+    inv = (as2(np.conj(w)), as2(wrapped_fft(w)), as2(np.conj(w) / n))
+    return m, fwd, inv
+
+
+def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """Complex FFT / IFFT of rows of x [rows, n, 2] for ANY n >= 1 (Bluestein when n is not a power of two)."""
+    require_gpu()
+    rows, n, _ = x.shape
+    if n == 1:
+        return x.clone()
+    if is_pow2(n):
+        return fft_pow2_any(x, inverse)
+    m, fwd, inv = _cached(("blue", n), lambda: _bluestein_tables(n))
+    w_in, bf, w_out = inv if inverse else fwd
+    a = torch.zeros((rows, m, 2), dtype=torch.float32, device=x.device)
+    a[:, :n].copy_(cmul(x, w_in))                 # zero-padded copy (data movement)
+    A = fft_pow2_any(a, False)
+    cmul(A, bf, out=A)
+    c = fft_pow2_any(A, True)
+    return cmul(c[:, :n].contiguous(), w_out)

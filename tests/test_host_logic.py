@@ -1,0 +1,187 @@
+"""Host-side logic of the product (tables, plans, validation) -- CPU only, no GPU calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.fft
+import scipy.signal
+from numpy.testing import assert_allclose, assert_array_equal
+
+from oracle import cpu_ref as O
+from sygnals_amd import _tables as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mels", [(48000, 2048, 40), (16000, 2048, 128), (22050, 2048, 128),
+                                             (48000, 1024, 64), (8000, 512, 20)])
+def test_mel_filterbank_bit_identical_to_oracle(sr, n_fft, n_mels):
+    a, b = T.mel_filterbank(sr, n_fft, n_mels), O.mel_filterbank(sr, n_fft, n_mels)
+    assert a.dtype == np.float32 and a.shape == b.shape
+    assert_array_equal(a, b)
+    assert_array_equal(T.mel_filterbank(sr, n_fft, n_mels, 100.0, sr / 4), O.mel_filterbank(sr, n_fft, n_mels, 100.0, sr / 4))
+
+
+@pytest.mark.parametrize("n_mels", [1, 13, 16, 40, 64, 100, 128])
+def test_mel_plan_reconstructs_dense_basis(n_mels):
+    W = T.mel_filterbank(48000, 2048, n_mels)
+    wp, plan = T.pack_mel_plan(W)
+    nt = plan[0]; tile = plan[1:9]; k0 = plan[9:17]; ns = plan[17:25]; wo = plan[25:33]
+    assert nt == (n_mels + 15) // 16 and wp.dtype == np.float32 and wp.shape[1] == 64
+    R = np.zeros((16 * nt, 1032), np.float64)
+    lane = np.arange(64)
+    for w in range(8):
+        assert k0[w] + 4 * ns[w] <= 1025 + 3
+        for i in range(ns[w]):
+            R[tile[w] * 16 + (lane & 15), k0[w] + 4 * i + (lane >> 4)] += wp[wo[w] + i]
+    assert_array_equal(R[:n_mels, :1025], W.astype(np.float64))
+    assert not R[n_mels:].any() and not R[:, 1025:].any()
+    # every tile is covered by consecutive, non-overlapping wave segments
+    assert sorted(set(tile[tile >= 0])) == list(range(nt))
+
+
+def test_mel_plan_rejects_too_many_mels():
+    with pytest.raises(ValueError, match="max n_mels 128"):
+        T.pack_mel_plan(np.ones((129, 1025), np.float32))
+
+
+def test_dct_matrix_and_lifter():
+    rng = np.random.default_rng(0)
+    S = rng.normal(size=(40, 9))
+    D = T.dct_matrix(13, 40)
+    assert_allclose(D.astype(np.float64) @ S, scipy.fft.dct(S, axis=0, type=2, norm="ortho")[:13], atol=1e-5)
+    assert_allclose(T.dct_matrix(20, 40, norm=None).astype(np.float64) @ S, scipy.fft.dct(S, axis=0, type=2)[:20],
+                    rtol=1e-5, atol=1e-4)
+    with pytest.raises(ValueError):
+        T.dct_matrix(41, 40)
+    assert T.lifter_weights(13, 0.0) is None
+    assert_allclose(T.lifter_weights(13, 22.0), 1 + 11 * np.sin(np.pi * np.arange(1, 14) / 22), rtol=1e-6)
+    with pytest.raises(ValueError, match="non-negative"):
+        T.lifter_weights(13, -1.0)
+
+
+@pytest.mark.parametrize("sr,n_fft", [(48000, 2048), (16000, 2048), (22050, 1024)])
+def test_contrast_plan_matches_oracle_bands(sr, n_fft):
+    fr = np.fft.rfftfreq(n_fft, 1 / sr)
+    plan = T.contrast_plan(fr, sr)
+    bands = O.contrast_bands(fr, sr)
+    assert plan[0] == len(bands) == 7
+    for b, (bins, kk) in enumerate(bands):
+        assert plan[1 + b] == bins[0] and plan[1 + 16 + b] == bins[-1] + 1 and plan[1 + 32 + b] == kk
+        assert_array_equal(bins, np.arange(bins[0], bins[-1] + 1))
+
+
+def test_contrast_plan_errors():
+    fr = np.fft.rfftfreq(512, 1 / 8000)
+    with pytest.raises(ValueError, match="Nyquist"):
+        T.contrast_plan(fr, 8000)
+    with pytest.raises(ValueError, match="quantile"):
+        T.contrast_plan(fr, 48000, quantile=1.5)
+    with pytest.raises(ValueError, match="fmin"):
+        T.contrast_plan(fr, 48000, fmin=0.0)
+
+
+def test_window_and_twiddles():
+    assert_array_equal(T.analysis_window("hann", 2048, 2048), scipy.signal.get_window("hann", 2048, fftbins=True))
+    w = T.analysis_window("hamming", 400, 512)
+    assert w.shape == (512,) and (w[:56] == 0).all() and (w[456:] == 0).all()
+    assert_array_equal(w, O.fft_window("hamming", 400, 512))
+    with pytest.raises(ValueError):
+        T.analysis_window("hann", 600, 512)
+    tw = T.twiddles(2048)
+    k = np.arange(2048)
+    assert_allclose(tw[:, 0] + 1j * tw[:, 1], np.exp(-2j * np.pi * k / 2048), atol=1e-7)
+
+
+def test_filters_host_side_matches_reference_behaviour():
+    from sygnals_amd.core import filters as F
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_filters.npz"))
+    assert_array_equal(F.design_butterworth_sos((300.0, 3400.0), 48000.0, 4, "bandpass"), g["bp4_48k_sos"])
+    assert_array_equal(F.design_butterworth_sos(100.0, 1000.0, 5, "lowpass"), g["lp5_1k_sos"])
+    for name in ("bp4_48k", "lp5_1k", "hp5_1k", "bs5_1k", "lp8_1k", "bp2_16k"):
+        sos = g[f"{name}_sos"]
+        assert_allclose(F._steady_state(sos), scipy.signal.sosfilt_zi(sos), rtol=1e-9, atol=1e-12)
+        assert T.butter_padlen(sos) == O.sosfiltfilt_padlen(sos)
+    # error strings pinned by the reference's tests/test_filters.py:73-87
+    with pytest.raises(ValueError, match="strictly between 0 and Nyquist"):
+        F.design_butterworth_sos(500.0, 1000.0, 4, "lowpass")
+    with pytest.raises(ValueError, match="strictly between 0 and Nyquist"):
+        F.design_butterworth_sos(600.0, 1000.0, 4, "lowpass")
+    with pytest.raises(ValueError, match="Low cutoff .* must be less than high cutoff"):
+        F.design_butterworth_sos((200.0, 100.0), 1000.0, 4, "bandpass")
+    with pytest.raises(TypeError, match="cutoff must be a float .* or a tuple"):
+        F.design_butterworth_sos([100.0], 1000.0, 4, "lowpass")
+    with pytest.raises(ValueError, match="must be a 1D array"):
+        F.apply_sos_filter(g["lp5_1k_sos"], np.zeros((2, 100)))
+    with pytest.raises(ValueError, match=r"shape \(n_sections, 6\)"):
+        F.apply_sos_filter(np.zeros((2, 5)), np.zeros(100))
+
+
+def test_api_validation_without_gpu():
+    """Argument errors are raised before any device work (same messages as the reference)."""
+    from sygnals_amd.core import dsp as D
+    from sygnals_amd.core.features import cepstral, frequency_domain as fd, manager
+    with pytest.raises(ValueError, match="Input data must be a 1D array."):
+        D.compute_fft(np.zeros((2, 8)))
+    with pytest.raises(ValueError, match="Input spectrum must be a 1D array."):
+        D.compute_ifft(np.zeros((2, 8), complex))
+    with pytest.raises(ValueError, match="Input data must be a 1D array."):
+        D.compute_stft(np.zeros((2, 8)))
+    with pytest.raises(ValueError, match="Input data must be a 1D array."):
+        D.compute_psd_welch(np.zeros((2, 8)))
+    with pytest.raises(ValueError, match="Invalid window type 'nope'"):
+        D.apply_window(np.zeros(8), "nope")
+    with pytest.raises(ValueError, match="Invalid window type 'nope'"):
+        D.compute_fft(np.zeros(8), window="nope")
+    with pytest.raises(ValueError, match="Either audio time series 'y' or Mel spectrogram 'S' must be provided."):
+        cepstral.mfcc()
+    with pytest.raises(ValueError, match="Sampling rate 'sr' must be provided"):
+        cepstral.mfcc(y=np.zeros(100))
+    with pytest.raises(ValueError, match="must match"):
+        fd.spectral_centroid(np.zeros(4), np.zeros(5))
+    with pytest.raises(ValueError, match="roll_percent must be between 0.0 and 1.0."):
+        fd.spectral_rolloff(np.ones(4), np.ones(4), roll_percent=1.5)
+    with pytest.raises(ValueError, match="must be positive"):
+        fd.spectral_bandwidth(np.ones(4), np.ones(4), p=0)
+    with pytest.raises(ValueError, match="Input S must be a 2D spectrogram"):
+        fd.spectral_contrast(np.ones(5), 48000)
+    e = np.array([], dtype=np.float64)     # empty-input constants, reference tests/test_features_freq.py
+    assert fd.spectral_centroid(e, e) == 0.0 and fd.spectral_bandwidth(e, e) == 0.0
+    assert fd.spectral_flatness(e) == 0.0 and fd.spectral_rolloff(e, e) == 0.0 and fd.dominant_frequency(e, e) == 0.0
+    with pytest.raises(ValueError, match=r"Unknown feature\(s\) requested: \['nope'\]"):
+        manager.extract_features(np.zeros(4096), 16000, ["nope"])
+    with pytest.raises(ValueError, match="must be a 1D array"):
+        manager.extract_features(np.zeros((2, 4096)), 16000, ["mfcc"])
+    out = manager.extract_features(np.zeros(100), 16000, ["mfcc"], center=False, output_format="dict_of_arrays")
+    assert set(out) == {"time"} and out["time"].size == 0
+    assert manager.extract_features(np.zeros(100), 16000, ["mfcc"], center=False).empty
+
+
+def test_frame_count_rule():
+    from sygnals_amd import ops
+    for L, n, h, c in [(48000, 2048, 512, True), (160000, 2048, 512, True), (512, 1024, 256, True), (100, 2048, 512, True),
+                       (100, 2048, 512, False), (4096, 1024, 256, False)]:
+        assert ops.num_frames(L, n, h, c) == O.num_frames(L, n, h, c)
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (or any CPU fallback)."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|cpu_ref", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sygnals_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f"{f} references the oracle"
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sygnals_amd import ops
+    from sygnals_amd._lib import SygnalsHipError
+    with pytest.raises(SygnalsHipError, match="no CPU fallback"):
+        ops.require_gpu()
+    from sygnals_amd.core import dsp as D
+    with pytest.raises(SygnalsHipError):
+        D.compute_fft(np.zeros(64))

@@ -1,0 +1,120 @@
+"""Plugin registration through the reference's registry API and the CLI surface (CPU only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+from click.testing import CliRunner
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeRegistry:
+    """Implements the PluginRegistry methods the plugin calls (sygnals/plugins/api.py:173-246)."""
+    def __init__(self):
+        self.filters, self.transforms, self.features, self.cli = {}, {}, {}, []
+    def add_filter(self, n, f): self.filters[n] = f
+    def add_transform(self, n, f): self.transforms[n] = f
+    def add_feature(self, n, f): self.features[n] = f
+    def add_cli_command(self, c): self.cli.append(c)
+
+
+def _run_hooks(plugin, reg):
+    # hook order of sygnals/plugins/loader.py:266-274
+    plugin.setup({})
+    for hook in ("register_filters", "register_transforms", "register_feature_extractors", "register_visualizations",
+                 "register_audio_effects", "register_augmenters", "register_data_readers", "register_data_writers",
+                 "register_cli_commands"):
+        getattr(plugin, hook)(reg)
+
+
+def _check_registered(filters, transforms, features, cli_names):
+    assert {"apply_sos_filter", "low_pass_filter", "high_pass_filter", "band_pass_filter", "band_stop_filter"} <= set(filters)
+    assert {"compute_fft", "compute_ifft", "compute_stft", "compute_psd_welch", "apply_window"} <= set(transforms)
+    assert {"spectral_centroid", "spectral_bandwidth", "spectral_flatness", "spectral_rolloff", "dominant_frequency",
+            "spectral_contrast", "mfcc", "extract_features"} <= set(features)
+    assert {"features", "dsp", "filter"} <= set(cli_names)
+
+
+def test_plugin_registers_into_fake_registry():
+    from sygnals_amd.plugins import SygnalsAmdPlugin
+    p, reg = SygnalsAmdPlugin(), FakeRegistry()
+    assert p.name == "sygnals-amd" and p.version
+    _run_hooks(p, reg)
+    _check_registered(reg.filters, reg.transforms, reg.features, [c.name for c in reg.cli])
+    p.teardown()
+
+
+def test_plugin_against_the_reference_registry_when_present():
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "sygnals", "plugins")):
+        pytest.skip("reference checkout not present on this box")
+    sys.path.insert(0, ref)
+    try:
+        from sygnals.plugins.api import PluginRegistry, SygnalsPluginBase
+        import importlib
+        import sygnals_amd.plugins.plugin as mod
+        mod = importlib.reload(mod)
+        p, reg = mod.SygnalsAmdPlugin(), PluginRegistry()
+        assert isinstance(p, SygnalsPluginBase)
+        _run_hooks(p, reg)
+        _check_registered(reg.list_filters(), reg.list_transforms(), reg.list_features(),
+                          [c.name for c in reg.get_cli_commands()])
+        assert reg.get_feature("mfcc") is not None and reg.get_filter("band_pass_filter") is not None
+    finally:
+        sys.path.remove(ref)
+
+
+def test_manifest_has_the_required_fields():
+    import tomli
+    m = tomli.load(open(os.path.join(ROOT, "sygnals_amd", "plugins", "plugin.toml"), "rb"))
+    assert {"name", "version", "sygnals_api", "entry_point"} <= set(m)       # loader.py:72
+    from packaging.specifiers import SpecifierSet
+    from packaging.version import Version
+    assert Version("1.0.0") in SpecifierSet(m["sygnals_api"])                # loader.py:85-103, version.py:8
+    mod, cls = m["entry_point"].split(":")
+    import importlib
+    assert hasattr(importlib.import_module(mod), cls)
+
+
+def test_cli_surface():
+    from sygnals_amd.cli.main import cli
+    r = CliRunner()
+    out = r.invoke(cli, ["features", "extract", "--help"]).output
+    for opt in ("-o, --output", "-f, --feature", "--frame-length", "--hop-length", "2048", "512"):
+        assert opt in out
+    out = r.invoke(cli, ["dsp", "--help"]).output
+    for c in ("fft", "ifft", "psd-welch", "stft"):
+        assert c in out
+    out = r.invoke(cli, ["filter", "apply", "--help"]).output
+    for opt in ("--type", "--cutoff", "--fs", "--order", "-o, --output"):
+        assert opt in out
+    res = r.invoke(cli, ["features", "extract", "/nonexistent.wav", "-o", "x.npz", "-f", "mfcc"])
+    assert res.exit_code == 2                                                # click usage error
+
+
+def test_io_roundtrip(tmp_path):
+    from scipy.io import wavfile
+    from sygnals_amd import io as sio
+    import pandas as pd
+    x = (np.sin(np.arange(1600) * 0.1) * 20000).astype(np.int16)
+    wavfile.write(str(tmp_path / "a.wav"), 16000, x)
+    y, sr = sio.read_data(tmp_path / "a.wav")
+    assert sr == 16000 and y.dtype == np.float64 and np.allclose(y, x / 32768.0)
+    st = np.stack([x, x // 2], axis=1)
+    wavfile.write(str(tmp_path / "s.wav"), 16000, st)
+    y2, _ = sio.read_data(tmp_path / "s.wav")
+    assert y2.shape == (2, 1600)
+    # feature table: CSV is written WITHOUT the time index (reference data_handler.py:248), NPZ keeps 'time'
+    df = pd.DataFrame({"mfcc_0": [1.0, 2.0]}, index=pd.to_timedelta([0.0, 0.1], unit="s")); df.index.name = "time"
+    sio.save_data(df, tmp_path / "f.csv")
+    assert list(pd.read_csv(tmp_path / "f.csv").columns) == ["mfcc_0"]
+    sio.save_data({"time": np.array([0.0, 0.1]), "mfcc_0": np.array([1.0, 2.0])}, tmp_path / "f.npz")
+    assert set(sio.read_data(tmp_path / "f.npz")) == {"time", "mfcc_0"}
+    sio.save_data(np.arange(4.0), tmp_path / "v.csv")
+    assert list(sio.read_data(tmp_path / "v.csv").columns) == ["value"]
+    sio.save_data(np.arange(4.0), tmp_path / "v.npz")
+    sig, _ = sio.signal_from(sio.read_data(tmp_path / "v.npz"))
+    assert np.array_equal(sig, np.arange(4.0))
+    with pytest.raises(ValueError):
+        sio.save_data({"a": np.zeros(2)}, tmp_path / "d.csv")
