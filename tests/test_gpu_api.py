@@ -1,0 +1,226 @@
+"""GPU parity of the reference-shaped Python API (sygnals_amd.core.*) -- the tests read like the
+reference's own (tests/test_dsp.py, test_filters.py, test_features_*.py) but pin numbers: against golden
+vectors produced by the reference's functions where those run, against the oracle elsewhere."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import cpu_ref as O
+from tests.gpu_util import assert_parity, peak_rel
+
+TOL = 1e-5
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gd():
+    return np.load(os.path.join(G, "ref_dsp.npz"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from sygnals_amd import ops
+    ops.require_gpu()
+
+
+@pytest.mark.parametrize("win", ["hann", "hamming", "blackman", None])
+@pytest.mark.parametrize("n", [None, 1024, 512, 1500])
+def test_compute_fft_vs_reference_golden(gd, win, n):
+    from sygnals_amd.core.dsp import compute_fft
+    f, s = compute_fft(gd["x1000"], fs=1000.0, n=n, window=win)          # n=None -> 1000 (Bluestein), 1500 too
+    assert f.dtype == np.float64 and s.dtype == np.complex128
+    assert np.array_equal(f, gd[f"fft_{win}_{n}_f"])
+    assert peak_rel(s, gd[f"fft_{win}_{n}_s"]) <= TOL
+
+
+def test_compute_ifft_vs_reference_golden(gd):
+    from sygnals_amd.core.dsp import compute_fft, compute_ifft
+    _, sp = O.compute_fft(gd["x1000"], fs=1000.0, window=None)
+    assert_parity(compute_ifft(sp), gd["ifft_none"], TOL, "ifft")
+    assert_parity(compute_ifft(sp, n=768), gd["ifft_n768"], TOL, "ifft n=768")
+    assert_parity(compute_ifft(sp, n=1200), gd["ifft_n1200"], TOL, "ifft n=1200")
+    # reference tests/test_dsp.py:69-76: ifft(fft(x)) == x (at fp32 precision here)
+    _, s2 = compute_fft(gd["x4096"], fs=48000.0, window=None)
+    assert_parity(compute_ifft(s2), gd["x4096"], TOL, "fft/ifft round trip")
+    x = compute_ifft(sp)
+    assert x.dtype == np.float64
+
+
+@pytest.mark.parametrize("n", [4096, 16384, 65536, 48000, 12345])
+def test_fft_long_and_odd_lengths(n):
+    from sygnals_amd.core.dsp import compute_fft, compute_ifft
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=n).astype(np.float32).astype(np.float64)
+    f, s = compute_fft(x, fs=48000.0, window=None)
+    ref = np.fft.fft(x)
+    assert peak_rel(s, ref) <= TOL
+    assert_parity(compute_ifft(ref), x, TOL, f"ifft n={n}")
+    # linearity / Parseval: size-independent properties
+    assert abs(np.sum(np.abs(s) ** 2) / n - np.sum(x ** 2)) <= 1e-4 * np.sum(x ** 2)
+
+
+@pytest.mark.parametrize("w", ["hann", "hamming", "blackman", "bartlett", "boxcar"])
+def test_apply_window_vs_reference_golden(gd, w):
+    from sygnals_amd.core.dsp import apply_window
+    assert_parity(apply_window(gd["x1000"], w), gd[f"win_{w}"], TOL, w)
+
+
+def test_compute_stft_like_reference_tests():
+    from sygnals_amd.core.dsp import compute_stft
+    sr = 22050
+    t = np.arange(2 * sr) / sr
+    y = np.sin(2 * np.pi * (100 + 2450 * t / 2) * t)                      # chirp, reference tests/test_dsp.py:79-91
+    X = compute_stft(y, n_fft=1024, hop_length=256)
+    assert X.shape == (513, 1 + len(y) // 256) and X.dtype == np.complex128
+    assert peak_rel(X, O.stft(y.astype(np.float32).astype(np.float64), 1024, 256)) <= TOL
+    X2 = compute_stft(y)                                                  # defaults: 2048, hop 512
+    assert X2.shape == (1025, 1 + len(y) // 512)
+    assert peak_rel(X2, O.stft(y.astype(np.float32).astype(np.float64))) <= TOL
+    X3 = compute_stft(y, n_fft=512, pad_mode="reflect")
+    assert peak_rel(X3, O.stft(y.astype(np.float32).astype(np.float64), 512, pad_mode="reflect")) <= TOL
+    with pytest.raises(ValueError, match="1D"):
+        compute_stft(np.zeros((2, 10)))
+
+
+WELCH = [("w4096", dict(nperseg=4096)), ("w256", dict(nperseg=256)), ("w1024o768", dict(nperseg=1024, noverlap=768)),
+         ("w512nfft1024", dict(nperseg=512, nfft=1024)), ("w1024spec", dict(nperseg=1024, scaling="spectrum")),
+         ("w1024nodet", dict(nperseg=1024, detrend=False)), ("w1024hamming", dict(nperseg=1024, window="hamming"))]
+
+
+@pytest.mark.parametrize("tag,kw", WELCH)
+def test_compute_psd_welch_vs_reference_golden(gd, tag, kw):
+    from sygnals_amd.core.dsp import compute_psd_welch
+    f, p = compute_psd_welch(gd["x20000"], fs=48000.0, **kw)
+    assert f.dtype == np.float64 and p.dtype == np.float64
+    assert np.allclose(f, gd[f"welch_{tag}_f"], rtol=0, atol=1e-9)
+    assert_parity(p, gd[f"welch_{tag}_p"], TOL, tag)
+
+
+def test_filters_vs_reference_golden():
+    from sygnals_amd.core import filters as F
+    g = np.load(os.path.join(G, "ref_filters.npz"))
+    x = g["conv_x"]
+    assert_parity(F.band_pass_filter(x, 300.0, 3400.0, 48000.0, order=4), g["conv_bp"], TOL, "band_pass")
+    assert_parity(F.low_pass_filter(x, 4000.0, 48000.0), g["conv_lp"], TOL, "low_pass")
+    assert_parity(F.high_pass_filter(x, 4000.0, 48000.0), g["conv_hp"], TOL, "high_pass")
+    assert_parity(F.band_stop_filter(x, 1000.0, 5000.0, 48000.0), g["conv_bs"], TOL, "band_stop")
+    y = F.apply_sos_filter(g["lp8_1k_sos"], g["lp8_1k_x"])
+    assert y.dtype == np.float64 and y.shape == g["lp8_1k_x"].shape
+    assert_parity(y, g["lp8_1k_y"], TOL, "apply_sos_filter")
+    with pytest.raises(ValueError, match="greater than padlen"):
+        F.apply_sos_filter(g["lp8_1k_sos"], np.zeros(10))
+
+
+def test_per_frame_feature_functions_vs_reference_golden():
+    from sygnals_amd.core.features import frequency_domain as fd
+    g = np.load(os.path.join(G, "ref_freq.npz"))
+    S, fr = g["spectra"], g["freqs"]
+    for i in (0, 3, 4, 5, 6, 11):
+        s = S[i]
+        c = fd.spectral_centroid(s, fr)
+        assert isinstance(c, np.float64)
+        assert abs(c - g["centroid"][i]) <= TOL * g["centroid"].max()
+        assert abs(fd.spectral_bandwidth(s, fr) - g["bandwidth"][i]) <= TOL * g["bandwidth"].max()
+        assert abs(fd.spectral_bandwidth(s, fr, p=1) - g["bandwidth_p1"][i]) <= TOL * g["bandwidth_p1"].max()
+        assert abs(fd.spectral_bandwidth(s, fr, centroid=np.float64(5000.0)) - g["bandwidth_c"][i]) <= 2 * TOL * g["bandwidth_c"].max()
+        assert abs(fd.spectral_flatness(s) - g["flatness"][i]) <= 2e-5
+        assert fd.spectral_rolloff(s, fr) == g["rolloff85"][i]
+        assert fd.spectral_rolloff(s, fr, roll_percent=0.5) == g["rolloff50"][i]
+        assert fd.dominant_frequency(s, fr) == g["dominant"][i]
+    z = S[3]                                                             # all-zero frame constants
+    assert fd.spectral_centroid(z, fr) == 0.0 and fd.spectral_bandwidth(z, fr) == 0.0
+    assert fd.spectral_flatness(z) == 0.0 and fd.spectral_rolloff(z, fr) == fr[-1] and fd.dominant_frequency(z, fr) == fr[0]
+
+
+def test_spectral_contrast_api():
+    from sygnals_amd.core.features.frequency_domain import spectral_contrast
+    y = O.synth_clips(1, 22050, 22050, seed=8)[0].astype(np.float64)
+    S = np.abs(O.stft(y, 2048, 512))
+    C = spectral_contrast(S, 22050, n_bands=6)
+    assert C.shape == (7, S.shape[1]) and C.dtype == np.float64
+    assert_parity(C, O.spectral_contrast(S.astype(np.float32).astype(np.float64), 22050), TOL, "contrast")
+    Cl = spectral_contrast(S, 22050, linear=True)
+    assert_parity(Cl, O.spectral_contrast(S.astype(np.float32).astype(np.float64), 22050, linear=True), TOL, "linear")
+    with pytest.raises(ValueError, match="Nyquist"):
+        spectral_contrast(np.ones((257, 4)), 8000)
+
+
+def test_mfcc_function_both_entry_points():
+    from sygnals_amd.core.features.cepstral import mfcc
+    y = O.synth_clips(1, 22050, 22050, seed=9)[0].astype(np.float64)
+    S = O.power_to_db(O.melspectrogram(np.abs(O.stft(y)) ** 2, 22050))
+    m = mfcc(S=S, sr=22050, n_mfcc=20)
+    assert m.shape == (20, 1 + len(y) // 512) and m.dtype == np.float64      # reference tests/test_features_cepstral.py:47-75
+    assert_parity(m, O.mfcc(S=S.astype(np.float32).astype(np.float64), n_mfcc=20), TOL, "mfcc(S)")
+    assert_parity(mfcc(S=S, n_mfcc=13), m[:13], 1e-6, "first 13 of 20")     # :94-117
+    assert_parity(mfcc(S=S, n_mfcc=13, lifter=22.0), O.mfcc(S=S.astype(np.float32).astype(np.float64), lifter=22.0), TOL, "lifter")
+    my = mfcc(y=y, sr=22050, n_mfcc=13, n_fft=1024, hop_length=512)
+    assert_parity(my, O.mfcc(y=y.astype(np.float32).astype(np.float64), sr=22050, n_fft=1024, hop_length=512), TOL, "mfcc(y)")
+
+
+def test_extract_features_like_reference_manager_tests():
+    from sygnals_amd.core.features.manager import extract_features
+    import pandas as pd
+    sr = 22050
+    y = O.synth_clips(1, sr, sr, seed=10)[0].astype(np.float64)
+    feats = ["spectral_centroid", "spectral_bandwidth", "spectral_flatness", "spectral_rolloff", "dominant_frequency",
+             "spectral_contrast", "mfcc"]
+    d = extract_features(y, sr, feats, output_format="dict_of_arrays", feature_params={"mfcc": {"n_mfcc": 20}})
+    ref = O.extract_features(y.astype(np.float32).astype(np.float64), sr, feats, feature_params={"mfcc": {"n_mfcc": 20}})
+    T = 1 + len(y) // 512
+    assert set(d) == set(ref) and all(v.shape == (T,) and v.dtype == np.float64 for v in d.values())
+    assert np.allclose(d["time"], ref["time"], rtol=0, atol=1e-12)
+    st = O.spectral_stats_frames(np.abs(O.stft(y.astype(np.float32).astype(np.float64))), O.fft_frequencies(sr, 2048))
+    for k in d:
+        if k == "time":
+            continue
+        if k in ("spectral_rolloff", "dominant_frequency"):
+            m = st["rolloff_margin" if k == "spectral_rolloff" else "dominant_margin"] > 1e-6
+            assert np.array_equal(d[k][m], ref[k][m]), k
+        elif k == "spectral_flatness":
+            assert_parity(d[k], ref[k], 2e-5, k)
+        else:
+            assert_parity(d[k], ref[k], TOL, k)
+    df = extract_features(y, sr, ["mfcc", "spectral_centroid"])
+    assert isinstance(df, pd.DataFrame) and df.index.name == "time" and isinstance(df.index, pd.TimedeltaIndex)
+    assert list(df.columns) == [f"mfcc_{i}" for i in range(13)] + ["spectral_centroid"] and len(df) == T
+    # other frame sizes take the generic kernels (reference tests use frame 1024 / hop 256)
+    d2 = extract_features(y, sr, ["mfcc", "spectral_centroid", "spectral_contrast"], frame_length=1024, hop_length=256,
+                          output_format="dict_of_arrays")
+    r2 = O.extract_features(y.astype(np.float32).astype(np.float64), sr, ["mfcc", "spectral_centroid", "spectral_contrast"],
+                            frame_length=1024, hop_length=256)
+    for k in r2:
+        assert_parity(d2[k], r2[k], TOL if k != "time" else 1e-12, f"frame 1024: {k}")
+    # short signals (reference tests/test_features_manager.py:183-220)
+    short = extract_features(y[:512], sr, ["spectral_centroid"], frame_length=1024, hop_length=256, output_format="dict_of_arrays")
+    assert short["spectral_centroid"].shape == (3,)
+    one = extract_features(y[:100], sr, ["mfcc"], output_format="dict_of_arrays")
+    assert one["mfcc_0"].shape == (1,)
+
+
+def test_cli_features_extract_c1(tmp_path):
+    """Config C1: 10 s mono 16 kHz PCM16 WAV through `features extract -f mfcc` (n_mels 128, 13 MFCC)."""
+    from click.testing import CliRunner
+    from scipy.io import wavfile
+    from sygnals_amd.cli.main import cli
+    y = O.synth_clips(1, 160000, 16000, seed=12)[0]
+    pcm = np.round(y * 32767).astype(np.int16)
+    wavfile.write(str(tmp_path / "c1.wav"), 16000, pcm)
+    r = CliRunner().invoke(cli, ["features", "extract", str(tmp_path / "c1.wav"), "-o", str(tmp_path / "o.npz"), "-f", "mfcc"])
+    assert r.exit_code == 0, r.output
+    z = np.load(tmp_path / "o.npz")
+    assert set(z.files) == {"time", *[f"mfcc_{i}" for i in range(13)]} and z["mfcc_0"].shape == (313,)
+    ref = O.extract_features(pcm.astype(np.float64) / 32768.0, 16000, ["mfcc"])
+    got = np.stack([z[f"mfcc_{i}"] for i in range(13)]); exp = np.stack([ref[f"mfcc_{i}"] for i in range(13)])
+    assert_parity(got, exp, TOL, "C1 CLI mfcc")
+    r = CliRunner().invoke(cli, ["features", "extract", str(tmp_path / "c1.wav"), "-o", str(tmp_path / "o.csv"), "-f", "mfcc",
+                                 "-f", "spectral_centroid"])
+    assert r.exit_code == 0, r.output
+    import pandas as pd
+    assert "time" not in pd.read_csv(tmp_path / "o.csv").columns          # reference drops the index (data_handler.py:248)
+    r = CliRunner().invoke(cli, ["features", "extract", str(tmp_path / "c1.wav"), "-o", str(tmp_path / "x.npz"), "-f", "bogus"])
+    assert r.exit_code == 2 and "Unknown feature" in r.output
