@@ -4,7 +4,7 @@ import numpy as np
 
 def peak_rel(a, b):
     """max|a-b| / max|b|  (the parity metric of SURVEY section 8d)."""
-    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    a = np.asarray(a); b = np.asarray(b)
     den = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
 
