@@ -53,7 +53,11 @@ def cpu_baseline(target_seconds=12.0):
     per core, BLAS threads pinned to 1); sized from a single-core probe to about `target_seconds`.
     """
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 64)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))          # a 1-GPU box's CPU share is 16 cores
     probe = _cpu_worker((1, 8))
     per_clip = probe / 8
     n_per = max(8, int(target_seconds / per_clip))

@@ -33,6 +33,8 @@ constexpr int P_STRIDE = 1026;  // == 2 (mod 32): conflict-free MFMA B-operand r
 constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
 constexpr int SCRATCH_FLOATS = WAVES * MC * 2;
 constexpr int SLAB_FLOATS = WAVES * 256;
+constexpr int TW2_FLOATS = 128;        // W_64^(b'*c') table, [4][16] complex
+constexpr int TW1_FLOATS = 15 * 64 * 2;  // W_1024^(lane*c) table, [15][64] complex
 
 struct MelPlan {
   int n_tiles;
@@ -64,19 +66,12 @@ __device__ __forceinline__ void unit_groups(int u, int& c, int& cp, int& cm, int
 }
 
 struct LaneConst {
-  float2 tw1[15];   // W_1024^(lane*c), c = 1..15
-  float2 tw2[15];   // W_64^(b'*c'),   c' = 1..15
   float2 twp[2][4]; // W_2048^k for the 4 mirror pairs of each unit
   int kk[2][4];     // output bin k of each pair (its mirror is 1024 - k)
   int g0[2], g1[2]; // LDS complex index of primary / mirror group of each unit
 };
 
 __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const float2* __restrict__ twid) {
-#pragma unroll
-  for (int c = 1; c < 16; ++c) lc.tw1[c - 1] = twid[2 * lane * c];
-  const int bp = lane & 3;
-#pragma unroll
-  for (int c = 1; c < 16; ++c) lc.tw2[c - 1] = twid[32 * bp * c];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int u = lane + 64 * j, c, cp, cm, cmp;
@@ -99,11 +94,12 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
 // pair (j, d): X[kk[j][d]] -> xs[j][d], X[1024 - kk[j][d]] -> xm[j][d]; lane 63 also
 // returns X[512] in x512.
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
+                                             const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
                                              int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512) {
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
   dft16(v);
 #pragma unroll
-  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], lc.tw1[c - 1]);
+  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], tw1l[(c - 1) * 64 + lane]);   // W_1024^(lane*c), LDS table
 #pragma unroll
   for (int c = 0; c < 16; ++c) sc[swz1(c, lane)] = v[c];
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
@@ -111,8 +107,16 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
 #pragma unroll
   for (int a = 0; a < 16; ++a) v[a] = sc[swz1(cl, 4 * a + bp)];
   dft16(v);
+  {
+    // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
+    const float4* t4 = reinterpret_cast<const float4*>(tw2l + bp * 16);
 #pragma unroll
-  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], lc.tw2[c - 1]);
+    for (int m = 0; m < 8; ++m) {
+      const float4 tt = t4[m];
+      if (m > 0) v[2 * m] = cmul(v[2 * m], make_float2(tt.x, tt.y));
+      v[2 * m + 1] = cmul(v[2 * m + 1], make_float2(tt.z, tt.w));
+    }
+  }
   {
     const int base = cl * 64 + bp;
     const int x = (cl & 7) ^ ((cl >> 3) << 3);
@@ -156,30 +160,26 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   x512 = make_float2(x512.x, -x512.y);
 }
 
+// Raw (unwindowed) samples of one frame: element n = 64a + lane of the packed complex frame covers
+// samples s0 + 2n, s0 + 2n + 1; samples outside [0, L) are the zero padding of center=True.
 template <bool VEC2>
-__device__ __forceinline__ void load_frame(float2 (&v)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
-                                           const float2* __restrict__ win2, int lane) {
-  // element n = 64a + lane of the packed complex frame covers samples s0 + 2n, s0 + 2n + 1
-  const bool interior = (s0 >= 0) && (s0 + NFFT <= L);
+__device__ __forceinline__ void load_frame_raw(float2 (&r)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
+                                               int lane, bool valid) {
+  const bool interior = valid && (s0 >= 0) && (s0 + NFFT <= L);
   if (interior) {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
       const int n = 64 * a + lane;
-      float2 x;
-      if (VEC2) x = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
-      else x = make_float2(yb[s0 + 2 * n], yb[s0 + 2 * n + 1]);
-      float2 w = win2[n];
-      v[a] = make_float2(x.x * w.x, x.y * w.y);
+      if (VEC2) r[a] = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
+      else r[a] = make_float2(yb[s0 + 2 * n], yb[s0 + 2 * n + 1]);
     }
   } else {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-      const int n = 64 * a + lane;
-      const int64_t s = s0 + 2 * n;
-      float x0 = (s >= 0 && s < L) ? yb[s] : 0.f;
-      float x1 = (s + 1 >= 0 && s + 1 < L) ? yb[s + 1] : 0.f;
-      float2 w = win2[n];
-      v[a] = make_float2(x0 * w.x, x1 * w.y);
+      const int64_t s = s0 + 2 * (64 * a + lane);
+      const float x0 = (valid && s >= 0 && s < L) ? yb[s] : 0.f;
+      const float x1 = (valid && s + 1 >= 0 && s + 1 < L) ? yb[s + 1] : 0.f;
+      r[a] = make_float2(x0, x1);
     }
   }
 }
@@ -331,28 +331,40 @@ __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, i
 }
 
 // ----------------------------------------------------------------------------------
-template <bool VEC2, bool COMPLEX_OUT>
+// MODE 0: mel only   MODE 1: mel + per-frame statistics / contrast   MODE 2: complex STFT output
+template <bool VEC2, int MODE>
 __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int tiles_per_clip,
-    const float2* __restrict__ win2, const float2* __restrict__ twid, const float* __restrict__ wpacked,
-    MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz, float roll_percent, float bw_p,
-    float* __restrict__ stats_out, ContrastPlan cplan, float* __restrict__ contrast_out,
-    float2* __restrict__ cout) {
+    int64_t total_tiles, int tiles_per_wg, const float2* __restrict__ win2, const float2* __restrict__ twid,
+    const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
+    float roll_percent, float bw_p, float* __restrict__ stats_out, ContrastPlan cplan,
+    float* __restrict__ contrast_out, float2* __restrict__ cout) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* scratch = reinterpret_cast<float2*>(lds);                 // [WAVES][1024] complex
   float* Pbuf = lds + SCRATCH_FLOATS;                               // [16][P_STRIDE] (+16)
   float* slab = Pbuf + P_FLOATS;                                    // [WAVES][16][16]
-  int* cpl = reinterpret_cast<int*>(slab + SLAB_FLOATS);            // contrast plan [3][SYG_MAX_BANDS]
+  float2* tw2l = reinterpret_cast<float2*>(slab + SLAB_FLOATS);     // [4][16] complex
+  float2* tw1l = tw2l + TW2_FLOATS / 2;                             // [15][64] complex
+  int* cpl = reinterpret_cast<int*>(slab + SLAB_FLOATS + TW2_FLOATS + TW1_FLOATS);  // contrast plan
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t b = blockIdx.x / tiles_per_clip;
-  const int64_t t0 = (int64_t)(blockIdx.x % tiles_per_clip) * TILE_T;
-  const float* yb = y + b * ldy;
+  constexpr int FPW = TILE_T / WAVES;                               // frames per wave per tile (2)
+  constexpr bool COMPLEX_OUT = (MODE == 2);
+
+  // persistent workgroup: a contiguous chunk of tiles (consecutive tiles of a clip share 3/4 of
+  // their samples, so the re-reads of the frame overlap stay in this CU's L1 / this XCD's L2)
+  const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+  const int64_t tile_end = (tile_begin + tiles_per_wg < total_tiles) ? tile_begin + tiles_per_wg : total_tiles;
+  if (tile_begin >= tile_end) return;
 
   LaneConst lc;
   init_lane_const(lc, lane, twid);
   float2* sc = scratch + w * MC;
+  if (tid < 64) tw2l[tid] = twid[32 * (tid >> 4) * (tid & 15)];
+  for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
+  __syncthreads();
 
+  int ns = 0, woff = 0, k0 = 0;
   if (!COMPLEX_OUT) {
     // zero the row pads / slack once (read by the MFMA B operand against zero weights)
     if (tid < TILE_T) Pbuf[tid * P_STRIDE + NBIN] = 0.f;
@@ -360,98 +372,151 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
 #pragma unroll
     for (int r = 0; r < SYG_MAX_BANDS; ++r)
       if (tid == r) { cpl[r] = cplan.lo[r]; cpl[SYG_MAX_BANDS + r] = cplan.hi[r]; cpl[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
-  }
-
-#pragma unroll 1
-  for (int j = 0; j < TILE_T / WAVES; ++j) {
-    const int fs = w * (TILE_T / WAVES) + j;
-    const int64_t t = t0 + fs;
-    float* prow = Pbuf + fs * P_STRIDE;
-    if (t < T) {
-      float2 v[16];
-      load_frame<VEC2>(v, yb, L, t * (int64_t)hop - pad, win2, lane);
-      float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048(v, lc, sc, lane, xs, xm, x512);
-      if (COMPLEX_OUT) {
-        float2* o = cout + (b * T + t) * NBIN;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            o[lc.kk[u][d]] = xs[u][d];
-            o[MC - lc.kk[u][d]] = xm[u][d];
-          }
-        if (lane == 63) o[512] = x512;
-      } else {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            prow[lc.kk[u][d]] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
-            prow[MC - lc.kk[u][d]] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
-          }
-        if (lane == 63) prow[512] = fmaf(x512.x, x512.x, x512.y * x512.y);
-      }
-    } else if (!COMPLEX_OUT) {
-      for (int k = lane; k < NBIN; k += 64) prow[k] = 0.f;
-    }
-  }
-  if (COMPLEX_OUT) return;
-  __syncthreads();
-
-  // ---- phase 2: block-sparse mel projection on the matrix cores
-  {
-    const int f = lane & 15, g = lane >> 4;
-    int ns = 0, woff = 0, k0 = 0;
 #pragma unroll
     for (int ww = 0; ww < WAVES; ++ww)
       if (w == ww) { ns = plan.nsteps[ww]; woff = plan.woff[ww]; k0 = plan.k0[ww]; }
-    const float* wp = wpacked + (int64_t)woff * 64 + lane;
-    const float* pr = Pbuf + f * P_STRIDE + k0 + g;
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int i = 0; i < ns; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pr[4 * i], acc, 0, 0, 0);
-    float* sl = slab + w * 256;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sl[(4 * g + r) * 16 + f] = acc[r];
-  }
-  __syncthreads();
-  for (int i = tid; i < plan.n_tiles * 256; i += NTHREADS) {
-    const int tile = i >> 8, m = (i >> 4) & 15, tt = i & 15;
-    float s = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < WAVES; ++ww)
-      if (plan.tile[ww] == tile) s += slab[ww * 256 + m * 16 + tt];
-    const int mel = tile * 16 + m;
-    if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = s;
   }
 
-  // ---- phase 2b: per-frame statistics / contrast means from the same LDS rows
-  if (stats_out != nullptr || contrast_out != nullptr) {
+  auto tile_coords = [&](int64_t tile, int64_t& b, int64_t& t0) {
+    b = tile / tiles_per_clip;
+    t0 = (tile - b * tiles_per_clip) * TILE_T;
+  };
+
+  // software pipeline, one frame deep: while frame q of this wave's sequence (frames 2w, 2w+1 of
+  // tile 0, then of tile 1, ...) is transformed, the raw samples of frame q+1 are in flight
+  float2 raw[16];
+  {
+    int64_t b, t0;
+    tile_coords(tile_begin, b, t0);
+    const int64_t t = t0 + w * FPW;
+    load_frame_raw<VEC2>(raw, y + b * ldy, L, t * (int64_t)hop - pad, lane, t < T);
+  }
+
 #pragma unroll 1
-    for (int j = 0; j < TILE_T / WAVES; ++j) {
-      const int fs = w * (TILE_T / WAVES) + j;
+  for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
+    int64_t b, t0;
+    tile_coords(tile, b, t0);
+#pragma unroll 1
+    for (int j = 0; j < FPW; ++j) {
+      const int fs = w * FPW + j;
       const int64_t t = t0 + fs;
-      if (t >= T) continue;
-      const float* prow = Pbuf + fs * P_STRIDE;
-      if (stats_out != nullptr)
-        row_stats(prow, lane, binhz, roll_percent, bw_p, stats_out + (b * SYG_NSTAT) * T + t, T);
-      if (contrast_out != nullptr) {
-        for (int r = 0; r < cplan.n_rows; ++r) {
-          float pk, vl;
-          row_contrast(prow, lane, cpl[r], cpl[SYG_MAX_BANDS + r], cpl[2 * SYG_MAX_BANDS + r], pk, vl);
-          if (lane == 0) {
-            contrast_out[((b * 2 + 0) * cplan.n_rows + r) * T + t] = pk;
-            contrast_out[((b * 2 + 1) * cplan.n_rows + r) * T + t] = vl;
+      float* prow = Pbuf + fs * P_STRIDE;
+      float2 v[16];
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const float2 wv = win2[64 * a + lane];
+        v[a] = make_float2(raw[a].x * wv.x, raw[a].y * wv.y);
+      }
+      {  // issue the loads of the next frame in this wave's sequence
+        int64_t nb = b, nt = t + 1;
+        bool more = true;
+        if (j == FPW - 1) {
+          more = tile + 1 < tile_end;
+          if (more) {
+            int64_t nt0;
+            tile_coords(tile + 1, nb, nt0);
+            nt = nt0 + w * FPW;
+          }
+        }
+        load_frame_raw<VEC2>(raw, y + nb * ldy, L, nt * (int64_t)hop - pad, lane, more && nt < T);
+      }
+      if (t < T) {
+        float2 xs[2][4], xm[2][4], x512;
+        wave_rfft2048(v, lc, sc, tw1l, tw2l, lane, xs, xm, x512);
+        if (COMPLEX_OUT) {
+          float2* o = cout + (b * T + t) * NBIN;
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              o[lc.kk[u][d]] = xs[u][d];
+              o[MC - lc.kk[u][d]] = xm[u][d];
+            }
+          if (lane == 63) o[512] = x512;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              prow[lc.kk[u][d]] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
+              prow[MC - lc.kk[u][d]] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
+            }
+          if (lane == 63) prow[512] = fmaf(x512.x, x512.x, x512.y * x512.y);
+        }
+      } else if (!COMPLEX_OUT) {
+        for (int k = lane; k < NBIN; k += 64) prow[k] = 0.f;
+      }
+    }
+    if (COMPLEX_OUT) continue;
+    __syncthreads();
+
+    // ---- phase 2: block-sparse mel projection on the matrix cores
+    {
+      const int f = lane & 15, g = lane >> 4;
+      const float* wp = wpacked + (int64_t)woff * 64 + lane;
+      const float* pr = Pbuf + f * P_STRIDE + k0 + g;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int i = 0; i < ns; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pr[4 * i], acc, 0, 0, 0);
+      float* sl = slab + w * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sl[(4 * g + r) * 16 + f] = acc[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < plan.n_tiles * 256; i += NTHREADS) {
+      const int mt = i >> 8, m = (i >> 4) & 15, tt = i & 15;
+      float sum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WAVES; ++ww)
+        if (plan.tile[ww] == mt) sum += slab[ww * 256 + m * 16 + tt];
+      const int mel = mt * 16 + m;
+      if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+    }
+
+    // ---- phase 2b: per-frame statistics / contrast means from the same LDS rows
+    if (MODE == 1 && (stats_out != nullptr || contrast_out != nullptr)) {
+#pragma unroll 1
+      for (int j = 0; j < FPW; ++j) {
+        const int fs = w * FPW + j;
+        const int64_t t = t0 + fs;
+        if (t >= T) continue;
+        const float* prow = Pbuf + fs * P_STRIDE;
+        if (stats_out != nullptr)
+          row_stats(prow, lane, binhz, roll_percent, bw_p, stats_out + (b * SYG_NSTAT) * T + t, T);
+        if (contrast_out != nullptr) {
+          for (int r = 0; r < cplan.n_rows; ++r) {
+            float pk, vl;
+            row_contrast(prow, lane, cpl[r], cpl[SYG_MAX_BANDS + r], cpl[2 * SYG_MAX_BANDS + r], pk, vl);
+            if (lane == 0) {
+              contrast_out[((b * 2 + 0) * cplan.n_rows + r) * T + t] = pk;
+              contrast_out[((b * 2 + 1) * cplan.n_rows + r) * T + t] = vl;
+            }
           }
         }
       }
+      __syncthreads();   // the rows are overwritten by the next tile's FFT phase
     }
   }
 }
 
-constexpr size_t LDS_BYTES_MEL = (size_t)(SCRATCH_FLOATS + P_FLOATS + SLAB_FLOATS + 3 * SYG_MAX_BANDS) * sizeof(float);
-constexpr size_t LDS_BYTES_C2C = (size_t)SCRATCH_FLOATS * sizeof(float);
+constexpr size_t LDS_BYTES_MEL = (size_t)(SCRATCH_FLOATS + P_FLOATS + SLAB_FLOATS + TW2_FLOATS + TW1_FLOATS + 3 * SYG_MAX_BANDS) * sizeof(float);
+constexpr size_t LDS_BYTES_C2C = LDS_BYTES_MEL;   // same carve-up (the mel rows are simply unused)
+
+// One workgroup per CU (the LDS footprint admits one); each takes a contiguous chunk of tiles.
+void persistent_grid(int64_t total_tiles, int& wgs, int& per) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  int64_t p = (total_tiles + n_cu - 1) / n_cu;
+  if (p < 1) p = 1;
+  per = (int)p;
+  wgs = (int)((total_tiles + p - 1) / p);
+}
 
 int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                  const float* window, const float* twiddle) {
@@ -516,18 +581,24 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
   const int pad = center ? NFFT / 2 : 0;
   const int tiles = (int)((T + TILE_T - 1) / TILE_T);
   const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
-  dim3 grid((unsigned)(B * tiles)), block(NTHREADS);
+  const int64_t total_tiles = B * tiles;
+  int wgs = 0, per = 0;
+  persistent_grid(total_tiles, wgs, per);
+  dim3 grid((unsigned)wgs), block(NTHREADS);
   hipStream_t st = (hipStream_t)stream;
   const float binhz = sr / (float)NFFT;
-  auto kern = vec2 ? stft2048_kernel<true, false> : stft2048_kernel<false, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[vec2]) {
+  const bool extra = (stats_out != nullptr) || (contrast_out != nullptr);
+  auto kern = extra ? (vec2 ? stft2048_kernel<true, 1> : stft2048_kernel<false, 1>)
+                    : (vec2 ? stft2048_kernel<true, 0> : stft2048_kernel<false, 0>);
+  static bool attr_set[4] = {false, false, false, false};
+  const int ai = (extra ? 2 : 0) + (vec2 ? 1 : 0);
+  if (!attr_set[ai]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LDS_BYTES_MEL);
     if (e != hipSuccess) { set_error("stft2048_mel: cannot reserve %zu B LDS: %s", LDS_BYTES_MEL, hipGetErrorString(e)); return SYG_E_LAUNCH; }
-    attr_set[vec2] = true;
+    attr_set[ai] = true;
   }
-  hipLaunchKernelGGL(kern, grid, block, LDS_BYTES_MEL, st, y, L, ldy, hop, pad, T, tiles,
+  hipLaunchKernelGGL(kern, grid, block, LDS_BYTES_MEL, st, y, L, ldy, hop, pad, T, tiles, total_tiles, per,
                      (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels, mel_out, binhz,
                      roll_percent, bw_p, stats_out, cp, contrast_out, (float2*)nullptr);
   SYG_CHECK_LAUNCH("stft2048_mel");
@@ -543,10 +614,13 @@ extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_
   const int pad = center ? NFFT / 2 : 0;
   const int tiles = (int)((T + TILE_T - 1) / TILE_T);
   const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
-  dim3 grid((unsigned)(B * tiles)), block(NTHREADS);
+  const int64_t total_tiles = B * tiles;
+  int wgs = 0, per = 0;
+  persistent_grid(total_tiles, wgs, per);
+  dim3 grid((unsigned)wgs), block(NTHREADS);
   MelPlan plan = {};
   ContrastPlan cp = {};
-  auto kern = vec2 ? stft2048_kernel<true, true> : stft2048_kernel<false, true>;
+  auto kern = vec2 ? stft2048_kernel<true, 2> : stft2048_kernel<false, 2>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[vec2]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -555,7 +629,7 @@ extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_
     attr_set[vec2] = true;
   }
   hipLaunchKernelGGL(kern, grid, block, LDS_BYTES_C2C, (hipStream_t)stream, y, L, ldy, hop, pad, T, tiles,
-                     (const float2*)window, (const float2*)twiddle, (const float*)nullptr, plan, 0,
+                     total_tiles, per, (const float2*)window, (const float2*)twiddle, (const float*)nullptr, plan, 0,
                      (float*)nullptr, 0.f, 0.f, 0.f, (float*)nullptr, cp, (float*)nullptr, (float2*)out);
   SYG_CHECK_LAUNCH("stft2048_c2c");
   return SYG_OK;
