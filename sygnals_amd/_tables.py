@@ -92,7 +92,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
     for t in range(nt):
         cols = np.flatnonzero(np.any(basis[16 * t:16 * t + 16] != 0, axis=0))
         if cols.size:
-            lo[t], hi[t] = cols[0], cols[-1] + 1
+            lo[t], hi[t] = (cols[0] // 4) * 4, cols[-1] + 1      # k0 must be a multiple of 4 (row skew)
     steps = (hi - lo + 3) // 4
     nw = np.ones(nt, int)
     for _ in range(waves - nt):

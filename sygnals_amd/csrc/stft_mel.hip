@@ -29,11 +29,14 @@ constexpr int NBIN = 1025;
 constexpr int TILE_T = 16;      // frames per workgroup
 constexpr int WAVES = 8;
 constexpr int NTHREADS = WAVES * 64;
-constexpr int P_STRIDE = 1026;  // == 2 (mod 32): conflict-free MFMA B-operand reads
+constexpr int P_STRIDE = 1090;  // == 2 (mod 32): conflict-free MFMA B-operand reads; rows are skewed, see ppos()
 constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
-constexpr int SCRATCH_FLOATS = WAVES * MC * 2;
+constexpr int XPL = 260;         // exchange-2 plane stride (complex): 256 + 4 skew
+constexpr int SC_COMPLEX = 4 * XPL;  // per-wave exchange scratch (1040 complex, 8320 B)
+constexpr int SCRATCH_FLOATS = WAVES * SC_COMPLEX * 2;
 constexpr int SLAB_FLOATS = WAVES * 256;
-constexpr int TW2_FLOATS = 128;        // W_64^(b'*c') table, [4][16] complex
+constexpr int TW2_STRIDE = 18;         // complex entries per lane class (16 + 2 pad: distinct banks)
+constexpr int TW2_FLOATS = 4 * TW2_STRIDE * 2;  // W_64^(b'*c') table
 constexpr int TW1_FLOATS = 15 * 64 * 2;  // W_1024^(lane*c) table, [15][64] complex
 
 struct MelPlan {
@@ -55,7 +58,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // LDS complex-index swizzles (validated by tools/wave_fft_model.py)
 __device__ __forceinline__ int swz1(int c, int b) { return c * 64 + (b ^ (4 * (c & 7))); }
-__device__ __forceinline__ int swz2g(int c, int cp) { return c * 64 + 4 * (cp ^ (c & 7) ^ ((c >> 3) << 3)); }
+// exchange 2 is planar: element b' of group (c, c') lives at b'*XPL + 16*c' + (c ^ c')  -- conflict free for
+// the ds_write_b64 of pass 2 and for the four ds_read_b64 per group of pass 3
+__device__ __forceinline__ int swz2g(int c, int cp) { return cp * 16 + (c ^ cp); }
+// position of bin k inside an LDS power row: one pad word every 16 bins turns the stride-16 bin pattern
+// of the pass-3 output into a conflict-free store while 4-aligned bin quads stay contiguous for the MFMA
+__device__ __forceinline__ int ppos(int k) { return k + (k >> 4); }
 
 // unit u (0..127) -> primary group (c, c') and mirror group (cm, cm')
 __device__ __forceinline__ void unit_groups(int u, int& c, int& cp, int& cm, int& cmp) {
@@ -68,6 +76,8 @@ __device__ __forceinline__ void unit_groups(int u, int& c, int& cp, int& cm, int
 struct LaneConst {
   float2 twp[2][4]; // W_2048^k for the 4 mirror pairs of each unit
   int kk[2][4];     // output bin k of each pair (its mirror is 1024 - k)
+  int pk[2][4];     // ppos(k): position of bin k in an LDS power row
+  int pm[2][4];     // ppos(1024 - k)
   int g0[2], g1[2]; // LDS complex index of primary / mirror group of each unit
 };
 
@@ -84,6 +94,8 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
       int k = kb + 256 * d;
       if (u == 127) k = (d == 0) ? 0 : (d == 1) ? 256 : (d == 2) ? 128 : 384;
       lc.kk[j][d] = k;
+      lc.pk[j][d] = ppos(k);
+      lc.pm[j][d] = ppos(MC - k);
       lc.twp[j][d] = twid[k];
     }
   }
@@ -109,7 +121,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   dft16(v);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
-    const float4* t4 = reinterpret_cast<const float4*>(tw2l + bp * 16);
+    const float4* t4 = reinterpret_cast<const float4*>(tw2l + bp * TW2_STRIDE);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const float4 tt = t4[m];
@@ -118,22 +130,18 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
     }
   }
   {
-    const int base = cl * 64 + bp;
-    const int x = (cl & 7) ^ ((cl >> 3) << 3);
+    const int base = bp * XPL;
 #pragma unroll
-    for (int cp = 0; cp < 16; ++cp) sc[base + 4 * (cp ^ x)] = v[cp];
+    for (int cp = 0; cp < 16; ++cp) sc[base + cp * 16 + (cl ^ cp)] = v[cp];
   }
   // ---- pass 3: radix-4 over b' for two mirror-paired units, then the real split
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const float4* p0 = reinterpret_cast<const float4*>(sc + lc.g0[j]);
-    const float4* p1 = reinterpret_cast<const float4*>(sc + lc.g1[j]);
-    float4 q0 = p0[0], q1 = p0[1], r0 = p1[0], r1 = p1[1];
+    const float2* p0 = sc + lc.g0[j];
+    const float2* p1 = sc + lc.g1[j];
     float2 G[4], H[4];
-    bfly4(make_float2(q0.x, q0.y), make_float2(q0.z, q0.w), make_float2(q1.x, q1.y), make_float2(q1.z, q1.w),
-          G[0], G[1], G[2], G[3]);
-    bfly4(make_float2(r0.x, r0.y), make_float2(r0.z, r0.w), make_float2(r1.x, r1.y), make_float2(r1.z, r1.w),
-          H[0], H[1], H[2], H[3]);
+    bfly4(p0[0], p0[XPL], p0[2 * XPL], p0[3 * XPL], G[0], G[1], G[2], G[3]);
+    bfly4(p1[0], p1[XPL], p1[2 * XPL], p1[3 * XPL], H[0], H[1], H[2], H[3]);
     float2 zk[4] = {G[0], G[1], G[2], G[3]};
     float2 zm[4] = {H[3], H[2], H[1], H[0]};
     if (j == 1) {
@@ -208,7 +216,7 @@ __device__ void row_stats(const float* __restrict__ prow, int lane, float binhz,
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int k = b0 + i;
-    const float p = (k < NBIN) ? prow[k] : 0.f;
+    const float p = (k < NBIN) ? prow[ppos(k)] : 0.f;
     pl[i] = p;
     const float m = sqrtf(p);
     if (k < NBIN) {
@@ -300,7 +308,7 @@ __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, i
       const uint32_t want = largest ? (prefix | (1u << bit)) : prefix;
       int cnt = 0;
       for (int i = lane; i < n; i += 64) {
-        const uint32_t u = __float_as_uint(prow[lo + i]);
+        const uint32_t u = __float_as_uint(prow[ppos(lo + i)]);
         cnt += ((u & mask) == want) ? 1 : 0;
       }
 #pragma unroll
@@ -317,7 +325,7 @@ __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, i
   float slo = 0.f, shi = 0.f;
   int clo = 0, chi = 0;
   for (int i = lane; i < n; i += 64) {
-    const float p = prow[lo + i];
+    const float p = prow[ppos(lo + i)];
     const uint32_t u = __float_as_uint(p);
     const float m = sqrtf(p);
     if (u < tlo) { slo += m; ++clo; }
@@ -359,15 +367,15 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
 
   LaneConst lc;
   init_lane_const(lc, lane, twid);
-  float2* sc = scratch + w * MC;
-  if (tid < 64) tw2l[tid] = twid[32 * (tid >> 4) * (tid & 15)];
+  float2* sc = scratch + w * SC_COMPLEX;
+  if (tid < 64) tw2l[(tid >> 4) * TW2_STRIDE + (tid & 15)] = twid[32 * (tid >> 4) * (tid & 15)];
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
   __syncthreads();
 
   int ns = 0, woff = 0, k0 = 0;
   if (!COMPLEX_OUT) {
     // zero the row pads / slack once (read by the MFMA B operand against zero weights)
-    if (tid < TILE_T) Pbuf[tid * P_STRIDE + NBIN] = 0.f;
+    if (tid < TILE_T) Pbuf[tid * P_STRIDE + P_STRIDE - 1] = 0.f;   // ppos(1025): read against zero weights
     if (tid < 16) Pbuf[TILE_T * P_STRIDE + tid] = 0.f;
 #pragma unroll
     for (int r = 0; r < SYG_MAX_BANDS; ++r)
@@ -438,13 +446,13 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
           for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-              prow[lc.kk[u][d]] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
-              prow[MC - lc.kk[u][d]] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
+              prow[lc.pk[u][d]] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
+              prow[lc.pm[u][d]] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
             }
-          if (lane == 63) prow[512] = fmaf(x512.x, x512.x, x512.y * x512.y);
+          if (lane == 63) prow[ppos(512)] = fmaf(x512.x, x512.x, x512.y * x512.y);
         }
       } else if (!COMPLEX_OUT) {
-        for (int k = lane; k < NBIN; k += 64) prow[k] = 0.f;
+        for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
       }
     }
     if (COMPLEX_OUT) continue;
@@ -454,10 +462,11 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
     {
       const int f = lane & 15, g = lane >> 4;
       const float* wp = wpacked + (int64_t)woff * 64 + lane;
-      const float* pr = Pbuf + f * P_STRIDE + k0 + g;
+      const float* pr = Pbuf + f * P_STRIDE + g;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-      for (int i = 0; i < ns; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pr[4 * i], acc, 0, 0, 0);
+      for (int i = 0; i < ns; ++i)   // k0 is a multiple of 4: the quad k0+4i .. +3 is contiguous in the skewed row
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pr[ppos(k0 + 4 * i)], acc, 0, 0, 0);
       float* sl = slab + w * 256;
 #pragma unroll
       for (int r = 0; r < 4; ++r) sl[(4 * g + r) * 16 + f] = acc[r];
@@ -557,7 +566,7 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
     plan.woff[w] = plan_host[1 + 3 * WAVES + w];
     SYG_REQUIRE(plan.tile[w] >= -1 && plan.tile[w] < plan.n_tiles, "stft2048_mel: bad tile in plan");
     SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 3 &&
-                    plan.woff[w] >= 0,
+                    plan.woff[w] >= 0 && plan.k0[w] % 4 == 0,
                 "stft2048_mel: plan segment %d out of range (k0=%d nsteps=%d)", w, plan.k0[w], plan.nsteps[w]);
   }
   ContrastPlan cp;
