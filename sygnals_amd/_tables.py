@@ -116,7 +116,8 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
                 blocks.append(blk.astype(np.float32))
                 off += s1 - s0
             w += 1
-    wpacked = np.concatenate(blocks, axis=0) if blocks else np.zeros((1, 64), np.float32)
+    blocks.append(np.zeros((48, 64), np.float32))          # tail padding: the kernel prefetches whole groups of steps
+    wpacked = np.concatenate(blocks, axis=0)
     plan = np.concatenate([[nt], tile, k0, ns, woff]).astype(np.int32)
     return np.ascontiguousarray(wpacked), plan
 

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
   int ns = 0, woff = 0, k0 = 0;
   if (!COMPLEX_OUT) {
     // zero the row pads / slack once (read by the MFMA B operand against zero weights)
-    if (tid < TILE_T) Pbuf[tid * P_STRIDE + P_STRIDE - 1] = 0.f;   // ppos(1025): read against zero weights
-    if (tid < 16) Pbuf[TILE_T * P_STRIDE + tid] = 0.f;
+    // pad words of the skewed rows, the row tails and the slack are read against zero weights: they must
+    // hold finite values, so the whole buffer (and the slab behind it) is cleared once
+    for (int i = tid; i < P_FLOATS + SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
 #pragma unroll
     for (int r = 0; r < SYG_MAX_BANDS; ++r)
       if (tid == r) { cpl[r] = cplan.lo[r]; cpl[SYG_MAX_BANDS + r] = cplan.hi[r]; cpl[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
@@ -415,7 +416,9 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
         const float2 wv = win2[64 * a + lane];
         v[a] = make_float2(raw[a].x * wv.x, raw[a].y * wv.y);
       }
-      {  // issue the loads of the next frame in this wave's sequence
+      // issue the loads of the next frame of this tile (the first frame of the NEXT tile is requested
+      // after the mel phase, when the A-operand registers are free again)
+      if (j < FPW - 1 || COMPLEX_OUT) {
         int64_t nb = b, nt = t + 1;
         bool more = true;
         if (j == FPW - 1) {
@@ -456,20 +459,52 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
       }
     }
     if (COMPLEX_OUT) continue;
-    __syncthreads();
 
-    // ---- phase 2: block-sparse mel projection on the matrix cores
+    // ---- phase 2: block-sparse mel projection on the matrix cores.  The wave's A operands (its
+    // slice of the packed filterbank, L2 resident) are requested BEFORE the barrier so that their
+    // round trip overlaps the wait for the slowest FFT wave; they sit in the registers the FFT freed.
+    constexpr int AREG = 40, AGRP = 8;   // wpacked carries >= AREG zero steps of tail padding
+    float areg[AREG];
+    {
+      const float* wp = wpacked + (int64_t)woff * 64 + lane;
+#pragma unroll
+      for (int i0 = 0; i0 < AREG; i0 += AGRP) {
+        if (i0 < ns) {                  // wave-uniform: whole groups of 8 unconditional loads
+#pragma unroll
+          for (int i = i0; i < i0 + AGRP; ++i) areg[i] = wp[i * 64];
+        }
+      }
+    }
+    __syncthreads();
     {
       const int f = lane & 15, g = lane >> 4;
-      const float* wp = wpacked + (int64_t)woff * 64 + lane;
       const float* pr = Pbuf + f * P_STRIDE + g;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
+      // k0 is a multiple of 4: the bin quad k0+4i .. +3 is contiguous in the skewed row.  Steps past
+      // the segment multiply by a zero A operand (their B reads stay inside the zero-initialised buffer).
+#pragma unroll
+      for (int i0 = 0; i0 < AREG; i0 += AGRP) {
+        if (i0 < ns) {
+#pragma unroll
+          for (int i = i0; i < i0 + AGRP; ++i)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32((i < ns) ? areg[i] : 0.f, pr[ppos(k0 + 4 * i)], acc, 0, 0, 0);
+        }
+      }
+      if (ns > AREG) {       // long segments (many mel bands per tile): stream the rest
+        const float* wp = wpacked + (int64_t)woff * 64 + lane;
 #pragma unroll 4
-      for (int i = 0; i < ns; ++i)   // k0 is a multiple of 4: the quad k0+4i .. +3 is contiguous in the skewed row
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pr[ppos(k0 + 4 * i)], acc, 0, 0, 0);
+        for (int i = AREG; i < ns; ++i)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pr[ppos(k0 + 4 * i)], acc, 0, 0, 0);
+      }
       float* sl = slab + w * 256;
 #pragma unroll
       for (int r = 0; r < 4; ++r) sl[(4 * g + r) * 16 + f] = acc[r];
+    }
+    if (tile + 1 < tile_end) {   // first frame of the next tile: in flight across the slab barrier and the reduce
+      int64_t nb, nt0;
+      tile_coords(tile + 1, nb, nt0);
+      const int64_t nt = nt0 + w * FPW;
+      load_frame_raw<VEC2>(raw, y + nb * ldy, L, nt * (int64_t)hop - pad, lane, nt < T);
     }
     __syncthreads();
     for (int i = tid; i < plan.n_tiles * 256; i += NTHREADS) {

@@ -20,3 +20,18 @@ for name, fn in (("mfcc", lambda: ops.mfcc_batch(y, 48000, n_mels=40)),
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print(f"{name}: {ms*1e3:.1f} us/step  {B*48000/ms/1e3:.0f} Msamples/s  roofline {B*196888/ms/1e-3/8e12*100:.2f}%")
+
+# --- experiment: FFT phase only (mel plan with zero steps) ---
+cfg = ops.mel_config(48000, 2048, 40)
+saved = cfg.plan.copy()
+cfg.plan[17:25] = 0
+def fftonly():
+    ops.stft2048_mel(y, 48000, n_mels=40)
+for _ in range(3): fftonly()
+torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): fftonly()
+e1.record(); torch.cuda.synchronize()
+print(f"fft-only (no MFMA steps): {e0.elapsed_time(e1)/20*1e3:.1f} us/step")
+cfg.plan[:] = saved
