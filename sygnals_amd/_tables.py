@@ -92,7 +92,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
     for t in range(nt):
         cols = np.flatnonzero(np.any(basis[16 * t:16 * t + 16] != 0, axis=0))
         if cols.size:
-            lo[t], hi[t] = (cols[0] // 4) * 4, cols[-1] + 1      # k0 must be a multiple of 4 (row skew)
+            lo[t], hi[t] = (cols[0] // 16) * 16, cols[-1] + 1    # segment starts are multiples of 16 bins (row skew)
     steps = (hi - lo + 3) // 4
     nw = np.ones(nt, int)
     for _ in range(waves - nt):
@@ -105,6 +105,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
     lane = np.arange(64)
     for t in range(nt):
         per = -(-steps[t] // nw[t]) if steps[t] else 0
+        per = -(-per // 4) * 4                              # whole groups of 4 steps = 16 bins
         for j in range(nw[t]):
             s0 = min(j * per, steps[t]); s1 = min((j + 1) * per, steps[t])
             tile[w] = t; k0[w] = lo[t] + 4 * s0; ns[w] = s1 - s0; woff[w] = off

@@ -463,38 +463,30 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
     // ---- phase 2: block-sparse mel projection on the matrix cores.  The wave's A operands (its
     // slice of the packed filterbank, L2 resident) are requested BEFORE the barrier so that their
     // round trip overlaps the wait for the slowest FFT wave; they sit in the registers the FFT freed.
-    constexpr int AREG = 40, AGRP = 8;   // wpacked carries >= AREG zero steps of tail padding
+    constexpr int AREG = 40;             // wpacked carries >= AREG zero steps of tail padding
     float areg[AREG];
     {
       const float* wp = wpacked + (int64_t)woff * 64 + lane;
 #pragma unroll
-      for (int i0 = 0; i0 < AREG; i0 += AGRP) {
-        if (i0 < ns) {                  // wave-uniform: whole groups of 8 unconditional loads
-#pragma unroll
-          for (int i = i0; i < i0 + AGRP; ++i) areg[i] = wp[i * 64];
-        }
-      }
+      for (int i = 0; i < AREG; ++i) areg[i] = wp[i * 64];          // unconditional: no control flow
     }
     __syncthreads();
     {
       const int f = lane & 15, g = lane >> 4;
       const float* pr = Pbuf + f * P_STRIDE + g;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
-      // k0 is a multiple of 4: the bin quad k0+4i .. +3 is contiguous in the skewed row.  Steps past
-      // the segment multiply by a zero A operand (their B reads stay inside the zero-initialised buffer).
+      // k0 is a multiple of 16, so ppos(k0 + 4i) = ppos(k0) + 4i + (i >> 2): one base register and
+      // compile-time offsets.  Steps past the segment multiply by a zero A operand (their B reads stay
+      // inside the zero-initialised buffer).
+      const float* pq = pr + ppos(k0);
 #pragma unroll
-      for (int i0 = 0; i0 < AREG; i0 += AGRP) {
-        if (i0 < ns) {
-#pragma unroll
-          for (int i = i0; i < i0 + AGRP; ++i)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32((i < ns) ? areg[i] : 0.f, pr[ppos(k0 + 4 * i)], acc, 0, 0, 0);
-        }
-      }
+      for (int i = 0; i < AREG; ++i)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((i < ns) ? areg[i] : 0.f, pq[4 * i + (i >> 2)], acc, 0, 0, 0);
       if (ns > AREG) {       // long segments (many mel bands per tile): stream the rest
         const float* wp = wpacked + (int64_t)woff * 64 + lane;
 #pragma unroll 4
         for (int i = AREG; i < ns; ++i)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pr[ppos(k0 + 4 * i)], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pq[4 * i + (i >> 2)], acc, 0, 0, 0);
       }
       float* sl = slab + w * 256;
 #pragma unroll
@@ -601,7 +593,7 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
     plan.woff[w] = plan_host[1 + 3 * WAVES + w];
     SYG_REQUIRE(plan.tile[w] >= -1 && plan.tile[w] < plan.n_tiles, "stft2048_mel: bad tile in plan");
     SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 3 &&
-                    plan.woff[w] >= 0 && plan.k0[w] % 4 == 0,
+                    plan.woff[w] >= 0 && plan.k0[w] % 16 == 0,
                 "stft2048_mel: plan segment %d out of range (k0=%d nsteps=%d)", w, plan.k0[w], plan.nsteps[w]);
   }
   ContrastPlan cp;
