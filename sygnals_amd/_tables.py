@@ -81,7 +81,8 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
     Rows are grouped in tiles of 16; for each tile only its non-zero column range is kept.
     The tiles' 4-bin k-steps are split over `waves` contiguous segments (one per wave,
     balanced greedily).  Returns (wpacked float32 [steps, 64], plan int32 [1 + 4*waves])
-    where lane l of step s holds A[m = l & 15][k = l >> 4] = basis[16*tile + m][k0 + 4*i + k].
+    where A[m = l & 15][k = l >> 4] of step i = basis[16*tile + m][k0 + 4*i + k]; rows of `wpacked` are
+    stored four steps at a time as [group][lane][4] so that a lane fetches four steps with one 16-byte load.
     """
     basis = np.asarray(basis, dtype=np.float32)
     M, F = basis.shape
@@ -108,16 +109,18 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
         per = -(-per // 4) * 4                              # whole groups of 4 steps = 16 bins
         for j in range(nw[t]):
             s0 = min(j * per, steps[t]); s1 = min((j + 1) * per, steps[t])
-            tile[w] = t; k0[w] = lo[t] + 4 * s0; ns[w] = s1 - s0; woff[w] = off
+            n4 = -(-(s1 - s0) // 4) * 4                     # padded with zero-weight steps to a multiple of 4
+            tile[w] = t; k0[w] = lo[t] + 4 * s0; ns[w] = n4; woff[w] = off
             if s1 > s0:
                 rows = 16 * t + (lane & 15)[None, :]
-                cols = (lo[t] + 4 * np.arange(s0, s1))[:, None] + (lane >> 4)[None, :]
-                ok = (rows < M) & (cols < F)
-                blk = np.where(ok, basis[np.minimum(rows, M - 1), np.minimum(cols, F - 1)], 0.0)
-                blocks.append(blk.astype(np.float32))
-                off += s1 - s0
+                cols = (lo[t] + 4 * np.arange(s0, s0 + n4))[:, None] + (lane >> 4)[None, :]
+                ok = (rows < M) & (cols < F) & (np.arange(s0, s0 + n4) < s1)[:, None]
+                blk = np.where(ok, basis[np.minimum(rows, M - 1), np.minimum(cols, F - 1)], 0.0).astype(np.float32)
+                # device layout: [group of 4 steps][lane][step in group] -> one float4 per lane per group
+                blocks.append(blk.reshape(n4 // 4, 4, 64).transpose(0, 2, 1).reshape(n4, 64))
+                off += n4
             w += 1
-    blocks.append(np.zeros((48, 64), np.float32))          # tail padding: the kernel prefetches whole groups of steps
+    blocks.append(np.zeros((16, 64), np.float32))
     wpacked = np.concatenate(blocks, axis=0)
     plan = np.concatenate([[nt], tile, k0, ns, woff]).astype(np.int32)
     return np.ascontiguousarray(wpacked), plan

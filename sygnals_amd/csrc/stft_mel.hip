@@ -387,8 +387,9 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
   }
 
   auto tile_coords = [&](int64_t tile, int64_t& b, int64_t& t0) {
-    b = tile / tiles_per_clip;
-    t0 = (tile - b * tiles_per_clip) * TILE_T;
+    const uint32_t q = (uint32_t)tile / (uint32_t)tiles_per_clip;   // total_tiles < 2^31 (checked on the host)
+    b = q;
+    t0 = (int64_t)((uint32_t)tile - q * (uint32_t)tiles_per_clip) * TILE_T;
   };
 
   // software pipeline, one frame deep: while frame q of this wave's sequence (frames 2w, 2w+1 of
@@ -463,30 +464,24 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
     // ---- phase 2: block-sparse mel projection on the matrix cores.  The wave's A operands (its
     // slice of the packed filterbank, L2 resident) are requested BEFORE the barrier so that their
     // round trip overlaps the wait for the slowest FFT wave; they sit in the registers the FFT freed.
-    constexpr int AREG = 40;             // wpacked carries >= AREG zero steps of tail padding
-    float areg[AREG];
-    {
-      const float* wp = wpacked + (int64_t)woff * 64 + lane;
-#pragma unroll
-      for (int i = 0; i < AREG; ++i) areg[i] = wp[i * 64];          // unconditional: no control flow
-    }
     __syncthreads();
     {
       const int f = lane & 15, g = lane >> 4;
-      const float* pr = Pbuf + f * P_STRIDE + g;
-      v4f acc = {0.f, 0.f, 0.f, 0.f};
       // k0 is a multiple of 16, so ppos(k0 + 4i) = ppos(k0) + 4i + (i >> 2): one base register and
-      // compile-time offsets.  Steps past the segment multiply by a zero A operand (their B reads stay
-      // inside the zero-initialised buffer).
-      const float* pq = pr + ppos(k0);
-#pragma unroll
-      for (int i = 0; i < AREG; ++i)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((i < ns) ? areg[i] : 0.f, pq[4 * i + (i >> 2)], acc, 0, 0, 0);
-      if (ns > AREG) {       // long segments (many mel bands per tile): stream the rest
-        const float* wp = wpacked + (int64_t)woff * 64 + lane;
+      // compile-time offsets.  The A operands are packed four steps per lane (one 16-byte load feeds
+      // four MFMAs); the step count of a segment is a multiple of 4 (zero-weight padding).
+      const float* pq = Pbuf + f * P_STRIDE + g + ppos(k0);
+      const float4* wp4 = reinterpret_cast<const float4*>(wpacked) + (int64_t)(woff >> 2) * 64 + lane;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      const int ng = ns >> 2;
 #pragma unroll 4
-        for (int i = AREG; i < ns; ++i)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i * 64], pq[4 * i + (i >> 2)], acc, 0, 0, 0);
+      for (int q = 0; q < ng; ++q) {
+        const float4 a4 = wp4[q * 64];
+        const float* pb = pq + 17 * q;          // 16 bins + 1 pad word per group of four steps
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, pb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, pb[4], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, pb[8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, pb[12], acc, 0, 0, 0);
       }
       float* sl = slab + w * 256;
 #pragma unroll
@@ -592,8 +587,8 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
     plan.nsteps[w] = plan_host[1 + 2 * WAVES + w];
     plan.woff[w] = plan_host[1 + 3 * WAVES + w];
     SYG_REQUIRE(plan.tile[w] >= -1 && plan.tile[w] < plan.n_tiles, "stft2048_mel: bad tile in plan");
-    SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 3 &&
-                    plan.woff[w] >= 0 && plan.k0[w] % 16 == 0,
+    SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 15 &&
+                    plan.woff[w] >= 0 && plan.k0[w] % 16 == 0 && plan.nsteps[w] % 4 == 0 && plan.woff[w] % 4 == 0,
                 "stft2048_mel: plan segment %d out of range (k0=%d nsteps=%d)", w, plan.k0[w], plan.nsteps[w]);
   }
   ContrastPlan cp;

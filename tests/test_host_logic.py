@@ -32,9 +32,13 @@ def test_mel_plan_reconstructs_dense_basis(n_mels):
     R = np.zeros((16 * nt, 1032), np.float64)
     lane = np.arange(64)
     for w in range(8):
-        assert k0[w] + 4 * ns[w] <= 1025 + 3
+        assert k0[w] + 4 * ns[w] <= 1025 + 15
+        assert ns[w] % 4 == 0 and wo[w] % 4 == 0 and k0[w] % 16 == 0
+        seg = wp[wo[w]:wo[w] + ns[w]].reshape(-1, 64, 4).transpose(0, 2, 1).reshape(-1, 64)   # undo [group][lane][4]
         for i in range(ns[w]):
-            R[tile[w] * 16 + (lane & 15), k0[w] + 4 * i + (lane >> 4)] += wp[wo[w] + i]
+            cols = k0[w] + 4 * i + (lane >> 4)
+            ok = cols < 1032
+            R[tile[w] * 16 + (lane & 15)[ok], cols[ok]] += seg[i][ok]
     assert_array_equal(R[:n_mels, :1025], W.astype(np.float64))
     assert not R[n_mels:].any() and not R[:, 1025:].any()
     # every tile is covered by consecutive, non-overlapping wave segments
