@@ -45,8 +45,8 @@ const char* syg_last_error(void);
  *   y          [B, L] float32, row stride ldy            (clips)
  *   window     [2048] float32  periodic analysis window (already centre-padded)
  *   twiddle    [2048] complex  W_2048^k = exp(-2*pi*i*k/2048)
- *   wpacked    packed block-sparse mel weights (see syg_mel_plan_* below / _tables.py)
- *   plan_host  HOST int32[1 + 4*8]: {n_tiles, tile[8], k0[8], nsteps[8], woff[8]}
+ *   wpacked    packed block-sparse mel weights, [group of 4 k-steps][lane][4] (see sygnals_amd/_tables.py)
+ *   plan_host  HOST int32[2 + 4*16]: {n_tiles, n_waves (8 or 16), tile[16], k0[16], nsteps[16], woff[16]}
  *   mel_out    [B, n_mels, T] float32 mel POWER spectrogram
  *   stats_out  optional [B, SYG_NSTAT, T] float32 per-frame spectral statistics
  *              (NULL to skip), rows in SYG_STAT_* order; replaces the per-frame loop

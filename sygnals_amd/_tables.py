@@ -13,7 +13,8 @@ import functools
 import numpy as np
 import scipy.signal
 
-WAVES = 8           # waves per workgroup of the fused kernel (stft_mel.hip)
+WAVES = 8           # default waves per workgroup of the fused kernel (stft_mel.hip): 8 or 16
+MAXW = 16
 MAX_BANDS = 16      # SYG_MAX_BANDS
 
 
@@ -80,13 +81,16 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
 
     Rows are grouped in tiles of 16; for each tile only its non-zero column range is kept.
     The tiles' 4-bin k-steps are split over `waves` contiguous segments (one per wave,
-    balanced greedily).  Returns (wpacked float32 [steps, 64], plan int32 [1 + 4*waves])
+    balanced greedily).  Returns (wpacked float32 [steps, 64], plan int32 [2 + 4*16] =
+    {n_tiles, n_waves, tile[16], k0[16], nsteps[16], woff[16]})
     where A[m = l & 15][k = l >> 4] of step i = basis[16*tile + m][k0 + 4*i + k]; rows of `wpacked` are
     stored four steps at a time as [group][lane][4] so that a lane fetches four steps with one 16-byte load.
     """
     basis = np.asarray(basis, dtype=np.float32)
     M, F = basis.shape
     nt = (M + 15) // 16
+    if waves not in (8, 16):
+        raise ValueError("waves must be 8 or 16")
     if nt > waves:
         raise ValueError(f"n_mels={M} needs {nt} tiles > {waves} waves (max n_mels {16 * waves})")
     lo = np.zeros(nt, int); hi = np.zeros(nt, int)
@@ -98,8 +102,8 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
     nw = np.ones(nt, int)
     for _ in range(waves - nt):
         nw[int(np.argmax(steps / nw))] += 1
-    tile = -np.ones(waves, np.int32); k0 = np.zeros(waves, np.int32)
-    ns = np.zeros(waves, np.int32); woff = np.zeros(waves, np.int32)
+    tile = -np.ones(MAXW, np.int32); k0 = np.zeros(MAXW, np.int32)
+    ns = np.zeros(MAXW, np.int32); woff = np.zeros(MAXW, np.int32)
     blocks = []
     w = 0
     off = 0
@@ -122,7 +126,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
             w += 1
     blocks.append(np.zeros((16, 64), np.float32))
     wpacked = np.concatenate(blocks, axis=0)
-    plan = np.concatenate([[nt], tile, k0, ns, woff]).astype(np.int32)
+    plan = np.concatenate([[nt, waves], tile, k0, ns, woff]).astype(np.int32)
     return np.ascontiguousarray(wpacked), plan
 
 

@@ -1,50 +1,47 @@
 // Fused STFT(2048) -> power -> mel kernel for gfx950 (MI355X).
 //
-// One workgroup (8 waves) owns a tile of 16 consecutive frames of one clip.
-//   phase 1  each wave computes two frames: coalesced float2 loads of the (overlapped)
-//            frame straight from HBM/L2, Hann (any) window, a 1024-point complex FFT
-//            held 16 points per lane (radix 16 x 16 x 4, two LDS exchanges, XOR-swizzled
-//            so both exchanges are bank-conflict free on write and on exchange-1 read),
-//            real-FFT split on mirror pairs, |X|^2 written as one 1025-float row in LDS;
-//   phase 2  the 16 power rows are the B operand of v_mfma_f32_16x16x4_f32: the mel
-//            filterbank is stored block-sparse (per 16-mel tile only its non-zero bin
-//            range) and split over the 8 waves; partial 16x16 tiles are combined in a
-//            fixed order (deterministic) and stored as mel[b, m, t];
-//   phase 2b (optional) per-frame spectral statistics and contrast peak/valley means
-//            are reduced from the same LDS rows with wave-level scans.
+// One persistent workgroup of W waves (W = 8: two workgroups per CU; W = 16: one) walks a contiguous
+// chunk of tiles; a tile is W consecutive frames of one clip, one frame per wave.
+//   phase 1  each wave: coalesced float2 loads of its (overlapped) frame straight from HBM/L2, analysis
+//            window, a 1024-point complex FFT held 16 points per lane (radix 16 x 16 x 4).  The two
+//            exchanges go through a 4.1 KiB per-wave LDS scratch in two half-rounds each (XOR / planar
+//            swizzles: every ds_write_b64 / ds_read_b64 is bank-conflict free), which is what lets 16
+//            waves (4 per SIMD) stay resident on a CU.  Real-FFT split on mirror pairs, |X|^2 stored as
+//            one skewed 1025-bin row in LDS.
+//   phase 2  the W power rows are the B operand of v_mfma_f32_16x16x4_f32: the mel filterbank is stored
+//            block-sparse (per 16-mel tile only its non-zero bin range), split over the waves and streamed
+//            four k-steps per 16-byte load; partial 16 x W tiles are combined in a fixed order
+//            (deterministic) and stored as mel[b, m, t].
+//   phase 2b (MODE 1) per-frame spectral statistics and contrast tail means from the same LDS rows.
 // Nothing but the input samples and the mel / stats outputs touches HBM.
 //
-// Reference behaviour reproduced: librosa.stft (center zero padding, periodic window,
-// rfft) -> np.abs -> **2 -> melspectrogram, as called from
-// sygnals/core/features/manager.py:184-187, 198, 219-222; per-frame statistics follow
-// sygnals/core/features/frequency_domain.py:24-386.
+// Reference behaviour reproduced: librosa.stft (center zero padding, periodic window, rfft) -> np.abs ->
+// **2 -> melspectrogram, as called from sygnals/core/features/manager.py:184-187, 198, 219-222; per-frame
+// statistics follow sygnals/core/features/frequency_domain.py:24-386.
+// Index maps are validated by tools/wave_fft_model_v3.py.
 #include "common.h"
+#include <string.h>
 
 namespace syg {
 namespace {
 
 constexpr int NFFT = 2048;
-constexpr int MC = 1024;        // complex points per frame
+constexpr int MC = 1024;         // complex points per frame
 constexpr int NBIN = 1025;
-constexpr int TILE_T = 16;      // frames per workgroup
-constexpr int WAVES = 8;
-constexpr int NTHREADS = WAVES * 64;
-constexpr int P_STRIDE = 1090;  // == 2 (mod 32): conflict-free MFMA B-operand reads; rows are skewed, see ppos()
-constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
-constexpr int XPL = 260;         // exchange-2 plane stride (complex): 256 + 4 skew
-constexpr int SC_COMPLEX = 4 * XPL;  // per-wave exchange scratch (1040 complex, 8320 B)
-constexpr int SCRATCH_FLOATS = WAVES * SC_COMPLEX * 2;
-constexpr int SLAB_FLOATS = WAVES * 256;
-constexpr int TW2_STRIDE = 18;         // complex entries per lane class (16 + 2 pad: distinct banks)
-constexpr int TW2_FLOATS = 4 * TW2_STRIDE * 2;  // W_64^(b'*c') table
-constexpr int TW1_FLOATS = 15 * 64 * 2;  // W_1024^(lane*c) table, [15][64] complex
+constexpr int MAXW = 16;         // waves per workgroup (8 or 16)
+constexpr int P_STRIDE = 1090;   // == 2 (mod 32): conflict-free MFMA B-operand reads; rows are skewed, see ppos()
+constexpr int PL2 = 132;         // exchange-2 plane stride (complex): 128 group slots + 4 skew
+constexpr int SC_COMPLEX = 4 * PL2;   // per-wave exchange scratch: 528 complex = 4224 B
+constexpr int TW2_STRIDE = 18;   // complex entries per lane class (16 + 2 pad: distinct banks)
+constexpr int TW2_FLOATS = 4 * TW2_STRIDE * 2;
+constexpr int TW1_FLOATS = 15 * 64 * 2;
 
 struct MelPlan {
   int n_tiles;
-  int tile[WAVES];
-  int k0[WAVES];
-  int nsteps[WAVES];
-  int woff[WAVES];
+  int tile[MAXW];
+  int k0[MAXW];
+  int nsteps[MAXW];
+  int woff[MAXW];
 };
 
 struct ContrastPlan {
@@ -56,138 +53,167 @@ struct ContrastPlan {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// LDS complex-index swizzles (validated by tools/wave_fft_model.py)
-__device__ __forceinline__ int swz1(int c, int b) { return c * 64 + (b ^ (4 * (c & 7))); }
-// exchange 2 is planar: element b' of group (c, c') lives at b'*XPL + 16*c' + (c ^ c')  -- conflict free for
-// the ds_write_b64 of pass 2 and for the four ds_read_b64 per group of pass 3
-__device__ __forceinline__ int swz2g(int c, int cp) { return cp * 16 + (c ^ cp); }
+// exchange 2 (half buffer by c' & 7, planar in b'): slot of group (c, c') inside a plane
+__device__ __forceinline__ int x2g(int c, int cp) { return (cp & 7) * 16 + ((c + 4 * ((cp & 7) >> 1)) & 15); }
 // position of bin k inside an LDS power row: one pad word every 16 bins turns the stride-16 bin pattern
-// of the pass-3 output into a conflict-free store while 4-aligned bin quads stay contiguous for the MFMA
+// of the pass-3 output into a conflict-free store while 16-aligned runs of bins stay contiguous for the MFMA
 __device__ __forceinline__ int ppos(int k) { return k + (k >> 4); }
 
-// unit u (0..127) -> primary group (c, c') and mirror group (cm, cm')
-__device__ __forceinline__ void unit_groups(int u, int& c, int& cp, int& cm, int& cmp) {
-  if (u < 112) { c = 1 + (u >> 4); cp = u & 15; cm = 16 - c; cmp = 15 - cp; }
-  else if (u < 120) { c = 8; cp = u - 112; cm = 8; cmp = 15 - cp; }
-  else if (u < 127) { c = 0; cp = u - 119; cm = 0; cmp = 16 - cp; }
-  else { c = 0; cp = 0; cm = 0; cmp = 8; }
-}
-
 struct LaneConst {
-  float2 twp[2][4]; // W_2048^k for the 4 mirror pairs of each unit
-  int kk[2][4];     // output bin k of each pair (its mirror is 1024 - k)
-  int pk[2][4];     // ppos(k): position of bin k in an LDS power row
-  int pm[2][4];     // ppos(1024 - k)
-  int g0[2], g1[2]; // LDS complex index of primary / mirror group of each unit
+  float2 twb[2];     // W_2048^kb of each unit (kb = c + 16 c'); pair d uses twb * W_8^d
+  float2 cA2, cA3;   // unit-0 multipliers for d = 2, 3: W_8^2, W_8^3 -- except lane 0 (see below)
+  int pkb[2];        // ppos(kb): pair d of a regular unit sits at pkb + 272 d (its mirror at pmb - 272 d)
+  int pmb[2];        // ppos(1024 - kb)
+  int dA2, dA3;      // unit-0 position offsets for d = 2, 3 (544, 816 -- except lane 0)
+  int kb[2];         // kb (complex-output mode)
+  int g0[2], g1[2];  // exchange-2 slot of the primary (c' < 8) / mirror (c' >= 8) group
 };
 
+// unit u = lane + 64 j: primary group (c = u >> 3, c' = u & 7), bins k = kb + 256 d; mirror group
+// (16 - c, 15 - c') holds bins 1024 - k, with the c = 0 exceptions (0, 16 - c') and, for u = 0 (lane 0), the
+// self-mirrored pair of groups (0,0) / (0,8) whose four pairs are the bins {0, 256, 128, 384} (+ bin 512).
 __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const float2* __restrict__ twid) {
+  constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    int u = lane + 64 * j, c, cp, cm, cmp;
-    unit_groups(u, c, cp, cm, cmp);
-    lc.g0[j] = swz2g(c, cp);
-    lc.g1[j] = swz2g(cm, cmp);
+    const int u = lane + 64 * j, c = u >> 3, cp = u & 7;
+    int cm = 16 - c, cmp = 15 - cp;
+    if (c == 0) { cm = 0; cmp = (cp == 0) ? 8 : 16 - cp; }
+    lc.g0[j] = x2g(c, cp);
+    lc.g1[j] = x2g(cm, cmp);
     const int kb = c + 16 * cp;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      int k = kb + 256 * d;
-      if (u == 127) k = (d == 0) ? 0 : (d == 1) ? 256 : (d == 2) ? 128 : 384;
-      lc.kk[j][d] = k;
-      lc.pk[j][d] = ppos(k);
-      lc.pm[j][d] = ppos(MC - k);
-      lc.twp[j][d] = twid[k];
-    }
+    lc.kb[j] = kb;
+    lc.pkb[j] = ppos(kb);
+    lc.pmb[j] = ppos(MC - kb);
+    lc.twb[j] = twid[kb];
   }
+  const bool sp = (lane == 0);
+  lc.cA2 = sp ? make_float2(C1, -S1) : make_float2(0.f, -1.f);   // W_2048^128 = W_16^1   |  W_8^2
+  lc.cA3 = sp ? make_float2(S1, -C1) : make_float2(-R, -R);      // W_2048^384 = W_16^3   |  W_8^3
+  lc.dA2 = sp ? ppos(128) : 544;
+  lc.dA3 = sp ? ppos(384) : 816;
 }
 
-// 1024-point complex forward FFT of the windowed frame + real split.
-// v[a] holds z[64a + lane] on entry.  On exit Xa/Xb hold the 16 (+1) spectrum values:
-// pair (j, d): X[kk[j][d]] -> xs[j][d], X[1024 - kk[j][d]] -> xm[j][d]; lane 63 also
-// returns X[512] in x512.
+// 1024-point complex forward FFT of the windowed frame + real split.  v[a] holds z[64a + lane] on entry.
+// On exit pair (j, d) holds X[k] in xs[j][d] and X[1024 - k] in xm[j][d] (k = kb_j + 256 d; lane 0 / unit 0:
+// k = 0, 256, 128, 384); lane 0 also returns X[512].
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
                                              const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
                                              int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512) {
+  const int cl = lane >> 2, bp = lane & 3;
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
   dft16(v);
 #pragma unroll
-  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], tw1l[(c - 1) * 64 + lane]);   // W_1024^(lane*c), LDS table
+  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], tw1l[(c - 1) * 64 + lane]);
+  // ---- exchange 1 in two half-rounds through a 512-complex buffer: round h moves the 32 COLUMNS
+  // b = 32h..32h+31 (those 32 lanes store their 16 values, y[c][b] at c*32 + ((b & 31) ^ 4(c & 7))); every
+  // lane then reads the 8 operands y[lane>>2][4a + b'], a = 8h..8h+7, that live in this half -- the reads
+  // are not divergent and land in fixed registers
+  float2 t[16];
+  {
+    const int wcol = lane & 31;
+    const int rx = 4 * (cl & 7);
+    const int rbase = cl * 32 + bp;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) sc[swz1(c, lane)] = v[c];
+    for (int h = 0; h < 2; ++h) {
+      if ((lane >> 5) == h) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sc[c * 32 + (wcol ^ (4 * (c & 7)))] = v[c];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[8 * h + i] = sc[rbase + ((4 * i) ^ rx)];
+    }
+  }
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
-  const int cl = lane >> 2, bp = lane & 3;
-#pragma unroll
-  for (int a = 0; a < 16; ++a) v[a] = sc[swz1(cl, 4 * a + bp)];
-  dft16(v);
+  dft16(t);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
     const float4* t4 = reinterpret_cast<const float4*>(tw2l + bp * TW2_STRIDE);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const float4 tt = t4[m];
-      if (m > 0) v[2 * m] = cmul(v[2 * m], make_float2(tt.x, tt.y));
-      v[2 * m + 1] = cmul(v[2 * m + 1], make_float2(tt.z, tt.w));
+      if (m > 0) t[2 * m] = cmul(t[2 * m], make_float2(tt.x, tt.y));
+      t[2 * m + 1] = cmul(t[2 * m + 1], make_float2(tt.z, tt.w));
     }
   }
+  // ---- exchange 2 in two half-rounds (c' < 8, then c' >= 8); every unit's primary group has c' < 8 and its
+  // mirror c' >= 8, so round 0 delivers all primaries and round 1 all mirrors.  Pass 3 = radix-4 over b'.
+  float2 G[2][4], H[2][4];
   {
-    const int base = bp * XPL;
+    const int wbase = bp * PL2;
 #pragma unroll
-    for (int cp = 0; cp < 16; ++cp) sc[base + cp * 16 + (cl ^ cp)] = v[cp];
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sc[wbase + r * 16 + ((cl + 4 * (r >> 1)) & 15)] = t[8 * h + r];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float2* p = sc + (h == 0 ? lc.g0[j] : lc.g1[j]);
+        if (h == 0) bfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], G[j][0], G[j][1], G[j][2], G[j][3]);
+        else bfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], H[j][0], H[j][1], H[j][2], H[j][3]);
+      }
+    }
   }
-  // ---- pass 3: radix-4 over b' for two mirror-paired units, then the real split
+  // ---- real split on mirror pairs
+  x512 = make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const float2* p0 = sc + lc.g0[j];
-    const float2* p1 = sc + lc.g1[j];
-    float2 G[4], H[4];
-    bfly4(p0[0], p0[XPL], p0[2 * XPL], p0[3 * XPL], G[0], G[1], G[2], G[3]);
-    bfly4(p1[0], p1[XPL], p1[2 * XPL], p1[3 * XPL], H[0], H[1], H[2], H[3]);
-    float2 zk[4] = {G[0], G[1], G[2], G[3]};
-    float2 zm[4] = {H[3], H[2], H[1], H[0]};
-    if (j == 1) {
-      // unit 127 (lane 63) pairs the self-mirrored groups (0,0) and (0,8) differently
-      const bool sp = (lane == 63);
-      x512 = G[2];
-      zk[2] = sp ? H[0] : zk[2];
-      zk[3] = sp ? H[1] : zk[3];
-      zm[0] = sp ? G[0] : zm[0];
-      zm[1] = sp ? G[3] : zm[1];
-      zm[2] = sp ? H[3] : zm[2];
-      zm[3] = sp ? H[2] : zm[3];
+    float2 zk[4] = {G[j][0], G[j][1], G[j][2], G[j][3]};
+    float2 zm[4] = {H[j][3], H[j][2], H[j][1], H[j][0]};
+    if (j == 0) {
+      // unit 0 (lane 0) pairs the self-mirrored groups (0,0) and (0,8) differently
+      const bool sp = (lane == 0);
+      zk[2] = sp ? H[0][0] : zk[2];
+      zk[3] = sp ? H[0][1] : zk[3];
+      zm[0] = sp ? G[0][0] : zm[0];
+      zm[1] = sp ? G[0][3] : zm[1];
+      zm[2] = sp ? H[0][3] : zm[2];
+      zm[3] = sp ? H[0][2] : zm[3];
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       // E2 = zk + conj(zm), O2 = -i (zk - conj(zm));  X[k] = (E2 + w O2)/2, X[1024-k] = conj(E2 - w O2)/2
-      float2 E = make_float2(zk[d].x + zm[d].x, zk[d].y - zm[d].y);
-      float2 O = make_float2(zk[d].y + zm[d].y, zm[d].x - zk[d].x);
-      float2 wO = cmul(lc.twp[j][d], O);
+      const float2 E = make_float2(zk[d].x + zm[d].x, zk[d].y - zm[d].y);
+      const float2 O = make_float2(zk[d].y + zm[d].y, zm[d].x - zk[d].x);
+      // w = twb * W_8^d (unit 0, d >= 2: twb * cA_d, which differs in lane 0 only)
+      constexpr float R = 0.70710678118654752440f;
+      float2 rO;
+      if (d == 0) rO = O;
+      else if (d == 1) rO = make_float2(R * (O.x + O.y), R * (O.y - O.x));
+      else if (j == 0) rO = cmul(O, d == 2 ? lc.cA2 : lc.cA3);
+      else if (d == 2) rO = make_float2(O.y, -O.x);
+      else rO = make_float2(R * (O.y - O.x), -R * (O.x + O.y));
+      const float2 wO = cmul(lc.twb[j], rO);
       xs[j][d] = make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
       xm[j][d] = make_float2(0.5f * (E.x - wO.x), -0.5f * (E.y - wO.y));
     }
   }
-  x512 = make_float2(x512.x, -x512.y);
 }
 
-// Raw (unwindowed) samples of one frame: element n = 64a + lane of the packed complex frame covers
-// samples s0 + 2n, s0 + 2n + 1; samples outside [0, L) are the zero padding of center=True.
+// Windowed samples of one frame: element n = 64a + lane of the packed complex frame covers samples
+// s0 + 2n, s0 + 2n + 1; samples outside [0, L) are the zero padding of center=True.
 template <bool VEC2>
-__device__ __forceinline__ void load_frame_raw(float2 (&r)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
-                                               int lane, bool valid) {
-  const bool interior = valid && (s0 >= 0) && (s0 + NFFT <= L);
+__device__ __forceinline__ void load_frame(float2 (&v)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
+                                           const float2* __restrict__ win2, int lane) {
+  const bool interior = (s0 >= 0) && (s0 + NFFT <= L);
   if (interior) {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
       const int n = 64 * a + lane;
-      if (VEC2) r[a] = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
-      else r[a] = make_float2(yb[s0 + 2 * n], yb[s0 + 2 * n + 1]);
+      float2 x;
+      if (VEC2) x = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
+      else x = make_float2(yb[s0 + 2 * n], yb[s0 + 2 * n + 1]);
+      const float2 wv = win2[n];
+      v[a] = make_float2(x.x * wv.x, x.y * wv.y);
     }
   } else {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-      const int64_t s = s0 + 2 * (64 * a + lane);
-      const float x0 = (valid && s >= 0 && s < L) ? yb[s] : 0.f;
-      const float x1 = (valid && s + 1 >= 0 && s + 1 < L) ? yb[s + 1] : 0.f;
-      r[a] = make_float2(x0, x1);
+      const int n = 64 * a + lane;
+      const int64_t s = s0 + 2 * n;
+      const float x0 = (s >= 0 && s < L) ? yb[s] : 0.f;
+      const float x1v = (s + 1 >= 0 && s + 1 < L) ? yb[s + 1] : 0.f;
+      const float2 wv = win2[n];
+      v[a] = make_float2(x0 * wv.x, x1v * wv.y);
     }
   }
 }
@@ -340,27 +366,31 @@ __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, i
 
 // ----------------------------------------------------------------------------------
 // MODE 0: mel only   MODE 1: mel + per-frame statistics / contrast   MODE 2: complex STFT output
-template <bool VEC2, int MODE>
-__global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
+template <int WAVES, bool VEC2, int MODE>
+__global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int tiles_per_clip,
     int64_t total_tiles, int tiles_per_wg, const float2* __restrict__ win2, const float2* __restrict__ twid,
     const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
     float roll_percent, float bw_p, float* __restrict__ stats_out, ContrastPlan cplan,
     float* __restrict__ contrast_out, float2* __restrict__ cout) {
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
+  constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
+  constexpr int SLAB_FLOATS = WAVES * 16 * TILE_T;
+  constexpr bool COMPLEX_OUT = (MODE == 2);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float2* scratch = reinterpret_cast<float2*>(lds);                 // [WAVES][1024] complex
-  float* Pbuf = lds + SCRATCH_FLOATS;                               // [16][P_STRIDE] (+16)
-  float* slab = Pbuf + P_FLOATS;                                    // [WAVES][16][16]
-  float2* tw2l = reinterpret_cast<float2*>(slab + SLAB_FLOATS);     // [4][16] complex
+  float2* scratch = reinterpret_cast<float2*>(lds);                 // [WAVES][528] complex
+  float* Pbuf = lds + WAVES * SC_COMPLEX * 2;                       // [TILE_T][P_STRIDE] (+16)
+  float* slab = Pbuf + P_FLOATS;                                    // [WAVES][16][TILE_T]
+  float2* tw2l = reinterpret_cast<float2*>(slab + SLAB_FLOATS);     // [4][18] complex
   float2* tw1l = tw2l + TW2_FLOATS / 2;                             // [15][64] complex
   int* cpl = reinterpret_cast<int*>(slab + SLAB_FLOATS + TW2_FLOATS + TW1_FLOATS);  // contrast plan
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  constexpr int FPW = TILE_T / WAVES;                               // frames per wave per tile (2)
-  constexpr bool COMPLEX_OUT = (MODE == 2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps frame addressing on the scalar unit
 
-  // persistent workgroup: a contiguous chunk of tiles (consecutive tiles of a clip share 3/4 of
-  // their samples, so the re-reads of the frame overlap stay in this CU's L1 / this XCD's L2)
+  // persistent workgroup: a contiguous chunk of tiles (consecutive tiles of a clip share part of their
+  // samples, so the re-reads of the frame overlap stay in this CU's L1 / this XCD's L2)
   const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
   const int64_t tile_end = (tile_begin + tiles_per_wg < total_tiles) ? tile_begin + tiles_per_wg : total_tiles;
   if (tile_begin >= tile_end) return;
@@ -370,11 +400,9 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
   float2* sc = scratch + w * SC_COMPLEX;
   if (tid < 64) tw2l[(tid >> 4) * TW2_STRIDE + (tid & 15)] = twid[32 * (tid >> 4) * (tid & 15)];
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
-  __syncthreads();
 
   int ns = 0, woff = 0, k0 = 0;
   if (!COMPLEX_OUT) {
-    // zero the row pads / slack once (read by the MFMA B operand against zero weights)
     // pad words of the skewed rows, the row tails and the slack are read against zero weights: they must
     // hold finite values, so the whole buffer (and the slab behind it) is cleared once
     for (int i = tid; i < P_FLOATS + SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
@@ -385,92 +413,56 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
     for (int ww = 0; ww < WAVES; ++ww)
       if (w == ww) { ns = plan.nsteps[ww]; woff = plan.woff[ww]; k0 = plan.k0[ww]; }
   }
-
-  auto tile_coords = [&](int64_t tile, int64_t& b, int64_t& t0) {
-    const uint32_t q = (uint32_t)tile / (uint32_t)tiles_per_clip;   // total_tiles < 2^31 (checked on the host)
-    b = q;
-    t0 = (int64_t)((uint32_t)tile - q * (uint32_t)tiles_per_clip) * TILE_T;
-  };
-
-  // software pipeline, one frame deep: while frame q of this wave's sequence (frames 2w, 2w+1 of
-  // tile 0, then of tile 1, ...) is transformed, the raw samples of frame q+1 are in flight
-  float2 raw[16];
-  {
-    int64_t b, t0;
-    tile_coords(tile_begin, b, t0);
-    const int64_t t = t0 + w * FPW;
-    load_frame_raw<VEC2>(raw, y + b * ldy, L, t * (int64_t)hop - pad, lane, t < T);
-  }
+  __syncthreads();
 
 #pragma unroll 1
   for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
-    int64_t b, t0;
-    tile_coords(tile, b, t0);
-#pragma unroll 1
-    for (int j = 0; j < FPW; ++j) {
-      const int fs = w * FPW + j;
-      const int64_t t = t0 + fs;
-      float* prow = Pbuf + fs * P_STRIDE;
+    const uint32_t cq = (uint32_t)tile / (uint32_t)tiles_per_clip;      // total_tiles < 2^31 (checked on the host)
+    const int64_t b = cq;
+    const int64_t t0 = (int64_t)((uint32_t)tile - cq * (uint32_t)tiles_per_clip) * TILE_T;
+    const int64_t t = t0 + w;
+    float* prow = Pbuf + w * P_STRIDE;
+    if (t < T) {
       float2 v[16];
+      load_frame<VEC2>(v, y + b * ldy, L, t * (int64_t)hop - pad, win2, lane);
+      float2 xs[2][4], xm[2][4], x512;
+      wave_rfft2048(v, lc, sc, tw1l, tw2l, lane, xs, xm, x512);
+      if (COMPLEX_OUT) {
+        float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll
-      for (int a = 0; a < 16; ++a) {
-        const float2 wv = win2[64 * a + lane];
-        v[a] = make_float2(raw[a].x * wv.x, raw[a].y * wv.y);
-      }
-      // issue the loads of the next frame of this tile (the first frame of the NEXT tile is requested
-      // after the mel phase, when the A-operand registers are free again)
-      if (j < FPW - 1 || COMPLEX_OUT) {
-        int64_t nb = b, nt = t + 1;
-        bool more = true;
-        if (j == FPW - 1) {
-          more = tile + 1 < tile_end;
-          if (more) {
-            int64_t nt0;
-            tile_coords(tile + 1, nb, nt0);
-            nt = nt0 + w * FPW;
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            int k = lc.kb[u] + 256 * d;
+            if (u == 0 && d >= 2 && lane == 0) k = (d == 2) ? 128 : 384;
+            o[k] = xs[u][d];
+            o[MC - k] = xm[u][d];
           }
-        }
-        load_frame_raw<VEC2>(raw, y + nb * ldy, L, nt * (int64_t)hop - pad, lane, more && nt < T);
+        if (lane == 0) o[512] = x512;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int off = (u == 0 && d == 2) ? lc.dA2 : (u == 0 && d == 3) ? lc.dA3 : 272 * d;
+            prow[lc.pkb[u] + off] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
+            prow[lc.pmb[u] - off] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
+          }
+        if (lane == 0) prow[ppos(512)] = fmaf(x512.x, x512.x, x512.y * x512.y);
       }
-      if (t < T) {
-        float2 xs[2][4], xm[2][4], x512;
-        wave_rfft2048(v, lc, sc, tw1l, tw2l, lane, xs, xm, x512);
-        if (COMPLEX_OUT) {
-          float2* o = cout + (b * T + t) * NBIN;
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              o[lc.kk[u][d]] = xs[u][d];
-              o[MC - lc.kk[u][d]] = xm[u][d];
-            }
-          if (lane == 63) o[512] = x512;
-        } else {
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              prow[lc.pk[u][d]] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
-              prow[lc.pm[u][d]] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
-            }
-          if (lane == 63) prow[ppos(512)] = fmaf(x512.x, x512.x, x512.y * x512.y);
-        }
-      } else if (!COMPLEX_OUT) {
-        for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
-      }
+    } else if (!COMPLEX_OUT) {
+      for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
     }
     if (COMPLEX_OUT) continue;
-
-    // ---- phase 2: block-sparse mel projection on the matrix cores.  The wave's A operands (its
-    // slice of the packed filterbank, L2 resident) are requested BEFORE the barrier so that their
-    // round trip overlaps the wait for the slowest FFT wave; they sit in the registers the FFT freed.
     __syncthreads();
+
+    // ---- phase 2: block-sparse mel projection on the matrix cores
     {
       const int f = lane & 15, g = lane >> 4;
       // k0 is a multiple of 16, so ppos(k0 + 4i) = ppos(k0) + 4i + (i >> 2): one base register and
       // compile-time offsets.  The A operands are packed four steps per lane (one 16-byte load feeds
       // four MFMAs); the step count of a segment is a multiple of 4 (zero-weight padding).
-      const float* pq = Pbuf + f * P_STRIDE + g + ppos(k0);
+      const float* pq = Pbuf + (f & (TILE_T - 1)) * P_STRIDE + g + ppos(k0);
       const float4* wp4 = reinterpret_cast<const float4*>(wpacked) + (int64_t)(woff >> 2) * 64 + lane;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
       const int ng = ns >> 2;
@@ -483,35 +475,26 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, pb[8], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, pb[12], acc, 0, 0, 0);
       }
-      float* sl = slab + w * 256;
+      if (f < TILE_T) {
+        float* sl = slab + w * (16 * TILE_T);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sl[(4 * g + r) * 16 + f] = acc[r];
-    }
-    if (tile + 1 < tile_end) {   // first frame of the next tile: in flight across the slab barrier and the reduce
-      int64_t nb, nt0;
-      tile_coords(tile + 1, nb, nt0);
-      const int64_t nt = nt0 + w * FPW;
-      load_frame_raw<VEC2>(raw, y + nb * ldy, L, nt * (int64_t)hop - pad, lane, nt < T);
+        for (int r = 0; r < 4; ++r) sl[(4 * g + r) * TILE_T + f] = acc[r];
+      }
     }
     __syncthreads();
-    for (int i = tid; i < plan.n_tiles * 256; i += NTHREADS) {
-      const int mt = i >> 8, m = (i >> 4) & 15, tt = i & 15;
+    for (int i = tid; i < plan.n_tiles * 16 * TILE_T; i += NTHREADS) {
+      const int mt = i / (16 * TILE_T), m = (i / TILE_T) & 15, tt = i & (TILE_T - 1);
       float sum = 0.f;
 #pragma unroll
       for (int ww = 0; ww < WAVES; ++ww)
-        if (plan.tile[ww] == mt) sum += slab[ww * 256 + m * 16 + tt];
+        if (plan.tile[ww] == mt) sum += slab[ww * (16 * TILE_T) + m * TILE_T + tt];
       const int mel = mt * 16 + m;
       if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
     }
 
     // ---- phase 2b: per-frame statistics / contrast means from the same LDS rows
     if (MODE == 1 && (stats_out != nullptr || contrast_out != nullptr)) {
-#pragma unroll 1
-      for (int j = 0; j < FPW; ++j) {
-        const int fs = w * FPW + j;
-        const int64_t t = t0 + fs;
-        if (t >= T) continue;
-        const float* prow = Pbuf + fs * P_STRIDE;
+      if (t < T) {
         if (stats_out != nullptr)
           row_stats(prow, lane, binhz, roll_percent, bw_p, stats_out + (b * SYG_NSTAT) * T + t, T);
         if (contrast_out != nullptr) {
@@ -530,11 +513,14 @@ __global__ __launch_bounds__(NTHREADS) void stft2048_kernel(
   }
 }
 
-constexpr size_t LDS_BYTES_MEL = (size_t)(SCRATCH_FLOATS + P_FLOATS + SLAB_FLOATS + TW2_FLOATS + TW1_FLOATS + 3 * SYG_MAX_BANDS) * sizeof(float);
-constexpr size_t LDS_BYTES_C2C = LDS_BYTES_MEL;   // same carve-up (the mel rows are simply unused)
+template <int WAVES>
+constexpr size_t lds_bytes() {
+  return (size_t)(WAVES * SC_COMPLEX * 2 + WAVES * P_STRIDE + 16 + WAVES * 16 * WAVES + TW2_FLOATS + TW1_FLOATS +
+                  3 * SYG_MAX_BANDS) * sizeof(float);
+}
 
-// One workgroup per CU (the LDS footprint admits one); each takes a contiguous chunk of tiles.
-void persistent_grid(int64_t total_tiles, int& wgs, int& per) {
+// Workgroups per CU: two of 8 waves or one of 16; each takes a contiguous chunk of tiles.
+void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -543,14 +529,15 @@ void persistent_grid(int64_t total_tiles, int& wgs, int& per) {
       n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  int64_t p = (total_tiles + n_cu - 1) / n_cu;
+  const int64_t slots = (int64_t)n_cu * (waves == 8 ? 2 : 1);
+  int64_t p = (total_tiles + slots - 1) / slots;
   if (p < 1) p = 1;
   per = (int)p;
   wgs = (int)((total_tiles + p - 1) / p);
 }
 
 int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
-                 const float* window, const float* twiddle) {
+                 const float* window, const float* twiddle, int waves) {
   SYG_REQUIRE(y && window && twiddle, "stft2048: null pointer argument");
   SYG_REQUIRE(B >= 1 && L >= 1 && ldy >= L, "stft2048: need B >= 1, L >= 1, ldy >= L (B=%lld L=%lld ldy=%lld)",
               (long long)B, (long long)L, (long long)ldy);
@@ -558,7 +545,35 @@ int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int
   const int64_t Texp = center ? 1 + L / hop : (L >= NFFT ? 1 + (L - NFFT) / hop : 0);
   SYG_REQUIRE(T >= 1 && T == Texp, "stft2048: T=%lld does not match the framing rule (%lld)", (long long)T,
               (long long)Texp);
-  SYG_REQUIRE(B * ((T + TILE_T - 1) / TILE_T) < (int64_t)0x7fffffff, "stft2048: grid too large");
+  SYG_REQUIRE(B * ((T + waves - 1) / waves) < (int64_t)0x7fffffff, "stft2048: grid too large");
+  return SYG_OK;
+}
+
+template <int WAVES, int MODE>
+int launch(bool vec2, const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+           const float* window, const float* twiddle, const float* wpacked, const MelPlan& plan, int n_mels,
+           float* mel_out, float binhz, float roll_percent, float bw_p, float* stats_out, const ContrastPlan& cp,
+           float* contrast_out, float* cout, hipStream_t st) {
+  const int pad = center ? NFFT / 2 : 0;
+  const int tiles = (int)((T + WAVES - 1) / WAVES);
+  const int64_t total_tiles = B * tiles;
+  int wgs = 0, per = 0;
+  persistent_grid(total_tiles, WAVES, wgs, per);
+  auto kern = vec2 ? stft2048_kernel<WAVES, true, MODE> : stft2048_kernel<WAVES, false, MODE>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[vec2]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes<WAVES>());
+    if (e != hipSuccess) {
+      set_error("stft2048: cannot reserve %zu B LDS: %s", lds_bytes<WAVES>(), hipGetErrorString(e));
+      return SYG_E_LAUNCH;
+    }
+    attr_set[vec2] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes<WAVES>(), st, y, L, ldy, hop, pad, T,
+                     tiles, total_tiles, per, (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels,
+                     mel_out, binhz, roll_percent, bw_p, stats_out, cp, contrast_out, (float2*)cout);
+  SYG_CHECK_LAUNCH("stft2048");
   return SYG_OK;
 }
 
@@ -572,27 +587,31 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
                                     const int32_t* plan_host, int n_mels, float* mel_out, float sr,
                                     float roll_percent, float bw_p, float* stats_out, const int32_t* cplan_host,
                                     float* contrast_out, void* stream) {
-  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle);
-  if (rc) return rc;
   SYG_REQUIRE(wpacked && plan_host && mel_out, "stft2048_mel: null pointer argument");
-  SYG_REQUIRE(n_mels >= 1 && n_mels <= 16 * WAVES, "stft2048_mel: n_mels must be in [1, %d] (got %d)", 16 * WAVES,
+  const int waves = plan_host[1];
+  SYG_REQUIRE(waves == 8 || waves == 16, "stft2048_mel: plan must be built for 8 or 16 waves (got %d)", waves);
+  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, waves);
+  if (rc) return rc;
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= 16 * waves, "stft2048_mel: n_mels must be in [1, %d] (got %d)", 16 * waves,
               n_mels);
   MelPlan plan;
+  memset(&plan, 0, sizeof(plan));
   plan.n_tiles = plan_host[0];
   SYG_REQUIRE(plan.n_tiles == (n_mels + 15) / 16, "stft2048_mel: plan has %d tiles, n_mels=%d needs %d",
               plan.n_tiles, n_mels, (n_mels + 15) / 16);
-  for (int w = 0; w < WAVES; ++w) {
-    plan.tile[w] = plan_host[1 + w];
-    plan.k0[w] = plan_host[1 + WAVES + w];
-    plan.nsteps[w] = plan_host[1 + 2 * WAVES + w];
-    plan.woff[w] = plan_host[1 + 3 * WAVES + w];
+  for (int w = 0; w < MAXW; ++w) {
+    plan.tile[w] = plan_host[2 + w];
+    plan.k0[w] = plan_host[2 + MAXW + w];
+    plan.nsteps[w] = plan_host[2 + 2 * MAXW + w];
+    plan.woff[w] = plan_host[2 + 3 * MAXW + w];
+    if (w >= waves) { plan.tile[w] = -1; plan.nsteps[w] = 0; plan.k0[w] = 0; plan.woff[w] = 0; }
     SYG_REQUIRE(plan.tile[w] >= -1 && plan.tile[w] < plan.n_tiles, "stft2048_mel: bad tile in plan");
     SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 15 &&
                     plan.woff[w] >= 0 && plan.k0[w] % 16 == 0 && plan.nsteps[w] % 4 == 0 && plan.woff[w] % 4 == 0,
                 "stft2048_mel: plan segment %d out of range (k0=%d nsteps=%d)", w, plan.k0[w], plan.nsteps[w]);
   }
   ContrastPlan cp;
-  cp.n_rows = 0;
+  memset(&cp, 0, sizeof(cp));
   if (contrast_out) {
     SYG_REQUIRE(cplan_host, "stft2048_mel: contrast_out given without cplan_host");
     cp.n_rows = cplan_host[0];
@@ -609,59 +628,29 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
   }
   if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f,
                              "stft2048_mel: invalid statistics parameters");
-  const int pad = center ? NFFT / 2 : 0;
-  const int tiles = (int)((T + TILE_T - 1) / TILE_T);
   const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
-  const int64_t total_tiles = B * tiles;
-  int wgs = 0, per = 0;
-  persistent_grid(total_tiles, wgs, per);
-  dim3 grid((unsigned)wgs), block(NTHREADS);
-  hipStream_t st = (hipStream_t)stream;
-  const float binhz = sr / (float)NFFT;
   const bool extra = (stats_out != nullptr) || (contrast_out != nullptr);
-  auto kern = extra ? (vec2 ? stft2048_kernel<true, 1> : stft2048_kernel<false, 1>)
-                    : (vec2 ? stft2048_kernel<true, 0> : stft2048_kernel<false, 0>);
-  static bool attr_set[4] = {false, false, false, false};
-  const int ai = (extra ? 2 : 0) + (vec2 ? 1 : 0);
-  if (!attr_set[ai]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_BYTES_MEL);
-    if (e != hipSuccess) { set_error("stft2048_mel: cannot reserve %zu B LDS: %s", LDS_BYTES_MEL, hipGetErrorString(e)); return SYG_E_LAUNCH; }
-    attr_set[ai] = true;
-  }
-  hipLaunchKernelGGL(kern, grid, block, LDS_BYTES_MEL, st, y, L, ldy, hop, pad, T, tiles, total_tiles, per,
-                     (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels, mel_out, binhz,
-                     roll_percent, bw_p, stats_out, cp, contrast_out, (float2*)nullptr);
-  SYG_CHECK_LAUNCH("stft2048_mel");
-  return SYG_OK;
+  const float binhz = sr / (float)NFFT;
+  hipStream_t st = (hipStream_t)stream;
+#define SYG_LAUNCH(W, M)                                                                                        \
+  launch<W, M>(vec2, y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out, binhz,      \
+               roll_percent, bw_p, stats_out, cp, contrast_out, nullptr, st)
+  if (waves == 8) return extra ? SYG_LAUNCH(8, 1) : SYG_LAUNCH(8, 0);
+  return extra ? SYG_LAUNCH(16, 1) : SYG_LAUNCH(16, 0);
+#undef SYG_LAUNCH
 }
 
 extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
                                     int64_t T, const float* window, const float* twiddle, float* out,
                                     void* stream) {
-  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle);
+  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 8);
   if (rc) return rc;
   SYG_REQUIRE(out, "stft2048_c2c: null output");
-  const int pad = center ? NFFT / 2 : 0;
-  const int tiles = (int)((T + TILE_T - 1) / TILE_T);
   const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
-  const int64_t total_tiles = B * tiles;
-  int wgs = 0, per = 0;
-  persistent_grid(total_tiles, wgs, per);
-  dim3 grid((unsigned)wgs), block(NTHREADS);
-  MelPlan plan = {};
-  ContrastPlan cp = {};
-  auto kern = vec2 ? stft2048_kernel<true, 2> : stft2048_kernel<false, 2>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[vec2]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_BYTES_C2C);
-    if (e != hipSuccess) { set_error("stft2048_c2c: cannot reserve LDS: %s", hipGetErrorString(e)); return SYG_E_LAUNCH; }
-    attr_set[vec2] = true;
-  }
-  hipLaunchKernelGGL(kern, grid, block, LDS_BYTES_C2C, (hipStream_t)stream, y, L, ldy, hop, pad, T, tiles,
-                     total_tiles, per, (const float2*)window, (const float2*)twiddle, (const float*)nullptr, plan, 0,
-                     (float*)nullptr, 0.f, 0.f, 0.f, (float*)nullptr, cp, (float*)nullptr, (float2*)out);
-  SYG_CHECK_LAUNCH("stft2048_c2c");
-  return SYG_OK;
+  MelPlan plan;
+  ContrastPlan cp;
+  memset(&plan, 0, sizeof(plan));
+  memset(&cp, 0, sizeof(cp));
+  return launch<8, 2>(vec2, y, B, L, ldy, hop, center, T, window, twiddle, nullptr, plan, 0, nullptr, 0.f, 0.f, 0.f,
+                      nullptr, cp, nullptr, out, (hipStream_t)stream);
 }

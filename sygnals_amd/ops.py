@@ -84,6 +84,12 @@ def num_frames(L: int, n_fft: int, hop: int, center: bool) -> int:
 
 
 # ------------------------------------------------------------------ fused 2048 path
+def fused_waves() -> int:
+    """Waves per workgroup of the fused kernel: 8 (two workgroups per CU) or 16 (one)."""
+    import os
+    return int(os.environ.get("SYGNALS_AMD_WAVES", T.WAVES))
+
+
 class MelConfig:
     """Device tables for one (sr, n_fft, n_mels, fmin, fmax) mel front end."""
 
@@ -91,8 +97,9 @@ class MelConfig:
         basis = T.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
         self.basis_host = basis
         self.n_mels = n_mels
-        if n_fft == 2048 and n_mels <= 16 * T.WAVES:
-            wp, plan = T.pack_mel_plan(basis)
+        waves = fused_waves()
+        if n_fft == 2048 and n_mels <= 16 * waves:
+            wp, plan = T.pack_mel_plan(basis, waves)
             self.wpacked = _dev(wp)
             self.plan = np.ascontiguousarray(plan, dtype=np.int32)
         else:
@@ -103,7 +110,7 @@ class MelConfig:
 
 def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> MelConfig:
     fmax = sr / 2.0 if fmax is None else fmax
-    return _cached(("mel", float(sr), n_fft, n_mels, float(fmin), float(fmax)),
+    return _cached(("mel", float(sr), n_fft, n_mels, float(fmin), float(fmax), fused_waves()),
                    lambda: MelConfig(sr, n_fft, n_mels, fmin, fmax))
 
 
@@ -124,7 +131,7 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
         raise ValueError("signal too short for one frame")
     cfg = mel_config(sr, 2048, n_mels, fmin, fmax)
     if cfg.wpacked is None:
-        raise SygnalsHipError(f"fused path supports n_mels <= {16 * T.WAVES}")
+        raise SygnalsHipError(f"fused path supports n_mels <= {16 * fused_waves()}")
     win = window_dev(window, win_length, 2048)
     tw = twiddle_dev(2048)
     mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)

@@ -23,15 +23,18 @@ def test_mel_filterbank_bit_identical_to_oracle(sr, n_fft, n_mels):
     assert_array_equal(T.mel_filterbank(sr, n_fft, n_mels, 100.0, sr / 4), O.mel_filterbank(sr, n_fft, n_mels, 100.0, sr / 4))
 
 
+@pytest.mark.parametrize("waves", [8, 16])
 @pytest.mark.parametrize("n_mels", [1, 13, 16, 40, 64, 100, 128])
-def test_mel_plan_reconstructs_dense_basis(n_mels):
+def test_mel_plan_reconstructs_dense_basis(n_mels, waves):
     W = T.mel_filterbank(48000, 2048, n_mels)
-    wp, plan = T.pack_mel_plan(W)
-    nt = plan[0]; tile = plan[1:9]; k0 = plan[9:17]; ns = plan[17:25]; wo = plan[25:33]
+    wp, plan = T.pack_mel_plan(W, waves)
+    assert plan[1] == waves and plan.shape == (66,)
+    nt = plan[0]; tile = plan[2:18]; k0 = plan[18:34]; ns = plan[34:50]; wo = plan[50:66]
+    assert (tile[waves:] == -1).all() and (ns[waves:] == 0).all()
     assert nt == (n_mels + 15) // 16 and wp.dtype == np.float32 and wp.shape[1] == 64
     R = np.zeros((16 * nt, 1032), np.float64)
     lane = np.arange(64)
-    for w in range(8):
+    for w in range(waves):
         assert k0[w] + 4 * ns[w] <= 1025 + 15
         assert ns[w] % 4 == 0 and wo[w] % 4 == 0 and k0[w] % 16 == 0
         seg = wp[wo[w]:wo[w] + ns[w]].reshape(-1, 64, 4).transpose(0, 2, 1).reshape(-1, 64)   # undo [group][lane][4]

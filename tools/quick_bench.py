@@ -24,7 +24,7 @@ for name, fn in (("mfcc", lambda: ops.mfcc_batch(y, 48000, n_mels=40)),
 # --- experiment: FFT phase only (mel plan with zero steps) ---
 cfg = ops.mel_config(48000, 2048, 40)
 saved = cfg.plan.copy()
-cfg.plan[17:25] = 0
+cfg.plan[34:50] = 0
 def fftonly():
     ops.stft2048_mel(y, 48000, n_mels=40)
 for _ in range(3): fftonly()

@@ -1,0 +1,127 @@
+"""NumPy lane/register model of the v3 wave FFT (half-size exchange scratch, two rounds per
+exchange, primary groups = c' < 8).  Validates index maps + LDS bank behaviour.  Dev aid only."""
+import numpy as np
+
+M = 1024
+PL2 = 132  # exchange-2 plane stride (complex) for a half: 128 groups-slots + 4 skew
+
+
+def W(N, e):
+    return np.exp(-2j * np.pi * e / N)
+
+
+def x1(c, b):            # exchange 1, half buffer (c & 7 selects the row)
+    return (c & 7) * 64 + (b ^ (4 * (c & 7)))
+
+
+def x2(c, cp, bp):       # exchange 2, half buffer (c' & 7), planar in b'
+    return bp * PL2 + (cp & 7) * 16 + ((c + 4 * ((cp & 7) >> 1)) & 15)
+
+
+def unit(u):
+    """unit u (0..127) -> primary (c, c' < 8) and mirror (cm, cm' >= 8)."""
+    c, cp = u >> 3, u & 7
+    if c != 0:
+        return c, cp, 16 - c, 15 - cp
+    if cp != 0:
+        return 0, cp, 0, 16 - cp
+    return 0, 0, 0, 8
+
+
+def model(x, win):
+    xw = x * win
+    z = xw[0::2] + 1j * xw[1::2]
+    lane = np.arange(64)
+    v = np.stack([z[64 * a + lane] for a in range(16)], 0)
+    y = np.stack([sum(v[a] * W(16, a * c) for a in range(16)) for c in range(16)], 0)
+    y = y * np.stack([W(1024, lane * c) for c in range(16)], 0)
+    cl, bp = lane >> 2, lane & 3
+    u_ = np.zeros((16, 64), complex)
+    for h in (0, 1):
+        buf = np.full(512, np.nan, complex)
+        for c in range(8 * h, 8 * h + 8):
+            buf[x1(c, lane)] = y[c]
+        act = (lane >> 5) == h
+        for a in range(16):
+            u_[a, act] = buf[x1(cl[act], 4 * a + bp[act])]
+    t = np.stack([sum(u_[a] * W(16, a * cp) for a in range(16)) for cp in range(16)], 0)
+    t = t * np.stack([W(64, bp * cp) for cp in range(16)], 0)
+    G = np.zeros((2, 4, 64), complex); H = np.zeros((2, 4, 64), complex)
+    for h in (0, 1):
+        buf = np.full(4 * PL2, np.nan, complex)
+        for cp in range(8 * h, 8 * h + 8):
+            buf[x2(cl, cp, bp)] = t[cp]
+        for j in (0, 1):
+            for l in range(64):
+                c, cp, cm, cmp_ = unit(l + 64 * j)
+                for b in range(4):
+                    if h == 0:
+                        G[j, b, l] = buf[x2(c, cp, b)]
+                    else:
+                        H[j, b, l] = buf[x2(cm, cmp_, b)]
+    X = np.full(1025, np.nan + 0j)
+    for j in (0, 1):
+        for l in range(64):
+            u = l + 64 * j
+            c, cp, cm, cmp_ = unit(u)
+            g = np.array([sum(G[j, b, l] * W(4, b * d) for b in range(4)) for d in range(4)])
+            hh = np.array([sum(H[j, b, l] * W(4, b * d) for b in range(4)) for d in range(4)])
+            k = c + 16 * cp + 256 * np.arange(4)
+            if u == 0:
+                pairs = [(g[0], g[0], 0), (g[1], g[3], 256), (hh[0], hh[3], 128), (hh[1], hh[2], 384), (g[2], g[2], 512)]
+            else:
+                km = cm + 16 * cmp_ + 256 * np.arange(4)
+                assert all((k[d] + km[3 - d]) % 1024 == 0 for d in range(4))
+                pairs = [(g[d], hh[3 - d], k[d]) for d in range(4)]
+            for zk, zm, kk in pairs:
+                E = 0.5 * (zk + np.conj(zm)); O = -0.5j * (zk - np.conj(zm))
+                w = np.exp(-1j * np.pi * kk / M)
+                X[kk] = E + w * O
+                X[M - kk] = np.conj(E - w * O)
+    return X
+
+
+def conf(addr_bytes, width, groups, modbytes, active=None):
+    worst = 0
+    for g in groups:
+        g = [l for l in g if active is None or active[l]]
+        if not g:
+            continue
+        a = np.unique(addr_bytes[g])
+        slots = (a // width) % (modbytes // width)
+        worst = max(worst, np.bincount(slots).max())
+    return worst
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=2048)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(2048) / 2048)
+    X = model(x, win)
+    print("max err", np.abs(X - np.fft.rfft(x * win)).max(), "nan:", np.isnan(X).any())
+    lane = np.arange(64)
+    G16 = [list(range(i, i + 16)) for i in range(0, 64, 16)]
+    G32 = [list(range(32)), list(range(32, 64))]
+    cl, bp = lane >> 2, lane & 3
+    print("x1 write:", [conf(8 * x1(c, lane), 8, G16, 128) for c in range(16)])
+    for h in (0, 1):
+        act = (lane >> 5) == h
+        print("x1 read h", h, [conf(8 * x1(cl, 4 * a + bp), 8, G32, 256, act) for a in range(16)])
+    print("x2 write:", [conf(8 * x2(cl, cp, bp), 8, G16, 128) for cp in range(16)])
+    for j in (0, 1):
+        pc = np.array([unit(l + 64 * j)[0] for l in lane]); pcp = np.array([unit(l + 64 * j)[1] for l in lane])
+        mc = np.array([unit(l + 64 * j)[2] for l in lane]); mcp = np.array([unit(l + 64 * j)[3] for l in lane])
+        print("x2 read unit", j, "primary", [conf(8 * x2(pc, pcp, b), 8, G32, 256) for b in range(4)],
+              "mirror", [conf(8 * x2(mc, mcp, b), 8, G32, 256) for b in range(4)])
+    def pos(k): return k + (k >> 4)
+    for j in (0, 1):
+        res = []
+        for d in range(4):
+            kk = []
+            for l in lane:
+                c, cp, cm, cmp_ = unit(l + 64 * j); k = c + 16 * cp + 256 * d
+                if l + 64 * j == 0: k = [0, 256, 128, 384][d]
+                kk.append(k)
+            kk = np.array(kk)
+            res.append((conf(4 * pos(kk), 4, G32, 128), conf(4 * pos(1024 - kk), 4, G32, 128)))
+        print("P write unit", j, res)
