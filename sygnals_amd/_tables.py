@@ -114,7 +114,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
         for j in range(nw[t]):
             s0 = min(j * per, steps[t]); s1 = min((j + 1) * per, steps[t])
             n4 = -(-(s1 - s0) // 4) * 4                     # padded with zero-weight steps to a multiple of 4
-            tile[w] = t; k0[w] = lo[t] + 4 * s0; ns[w] = n4; woff[w] = off
+            tile[w] = t; k0[w] = (lo[t] + 4 * s0) if s1 > s0 else 0; ns[w] = n4; woff[w] = off
             if s1 > s0:
                 rows = 16 * t + (lane & 15)[None, :]
                 cols = (lo[t] + 4 * np.arange(s0, s0 + n4))[:, None] + (lane >> 4)[None, :]

@@ -72,6 +72,16 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     bfly4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3], v[q], v[q + 4], v[q + 8], v[q + 12]);
 }
 
+// Lanes of one wave exchange data through LDS without a workgroup barrier (the LDS executes a wave's
+// DS instructions in order).  To the COMPILER that is a data race: it may assume a lane that did not store
+// re-reads unchanged memory.  This wavefront-scope release/acquire pair emits no instruction but makes every
+// later LDS read observe the stores of the other lanes.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

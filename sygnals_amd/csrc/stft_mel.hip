@@ -120,8 +120,10 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
 #pragma unroll
         for (int c = 0; c < 16; ++c) sc[c * 32 + (wcol ^ (4 * (c & 7)))] = v[c];
       }
+      wave_lds_sync();
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[8 * h + i] = sc[rbase + ((4 * i) ^ rx)];
+      wave_lds_sync();
     }
   }
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
@@ -145,12 +147,14 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) sc[wbase + r * 16 + ((cl + 4 * (r >> 1)) & 15)] = t[8 * h + r];
+      wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float2* p = sc + (h == 0 ? lc.g0[j] : lc.g1[j]);
         if (h == 0) bfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], G[j][0], G[j][1], G[j][2], G[j][3]);
         else bfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], H[j][0], H[j][1], H[j][2], H[j][3]);
       }
+      wave_lds_sync();
     }
   }
   // ---- real split on mirror pairs
@@ -423,10 +427,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const int64_t t = t0 + w;
     float* prow = Pbuf + w * P_STRIDE;
     if (t < T) {
+      // the lane id is laundered through an empty asm each iteration: the LDS / global addresses derived
+      // from it are then recomputed per frame (a few integer ops) instead of being hoisted out of the tile
+      // loop as ~100 loop-invariant registers that would spill
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
       float2 v[16];
-      load_frame<VEC2>(v, y + b * ldy, L, t * (int64_t)hop - pad, win2, lane);
+      load_frame<VEC2>(v, y + b * ldy, L, t * (int64_t)hop - pad, win2, lv);
       float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048(v, lc, sc, tw1l, tw2l, lane, xs, xm, x512);
+      wave_rfft2048(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512);
       if (COMPLEX_OUT) {
         float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll

@@ -29,6 +29,11 @@ def _stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _ld(t: torch.Tensor) -> int:
+    """Row stride in elements (a size-1 leading axis may carry an arbitrary stride)."""
+    return int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -143,7 +148,7 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
         cpv = torch.empty((B, 2, int(cplan[0]), Tn), dtype=torch.float32, device=y.device)
         cplan_p = cplan.ctypes.data_as(C.c_void_p)
     rc = lib().syg_stft2048_mel_f32(
-        _ptr(y), B, L, y.stride(0), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(cfg.wpacked),
+        _ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(cfg.wpacked),
         cfg.plan.ctypes.data_as(C.c_void_p), n_mels, _ptr(mel), float(sr), float(roll_percent), float(bw_p),
         _ptr(stats), cplan_p, _ptr(cpv), C.c_void_p(_stream_ptr()))
     check(rc, "syg_stft2048_mel_f32")
@@ -162,7 +167,7 @@ def stft2048_c2c(y: torch.Tensor, hop: int = 512, center: bool = True, window="h
     win = window_dev(window, win_length, 2048)
     tw = twiddle_dev(2048)
     out = torch.empty((B, Tn, 1025, 2), dtype=torch.float32, device=y.device)
-    rc = lib().syg_stft2048_c2c_f32(_ptr(y), B, L, y.stride(0), hop, int(center), Tn, _ptr(win), _ptr(tw),
+    rc = lib().syg_stft2048_c2c_f32(_ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw),
                                     _ptr(out), C.c_void_p(_stream_ptr()))
     check(rc, "syg_stft2048_c2c_f32")
     return out
@@ -248,7 +253,7 @@ def stft_pow2(y: torch.Tensor, n_fft: int, hop: int, center: bool = True, window
         raise ValueError("signal too short for one frame")
     win = window_dev(window, win_length, n_fft)
     out = torch.empty((B, Tn, n_fft // 2 + 1, 2), dtype=torch.float32, device=y.device)
-    rc = lib().syg_stft_pow2_c2c_f32(_ptr(y), B, L, y.stride(0), n_fft, hop, int(center), Tn, _ptr(win),
+    rc = lib().syg_stft_pow2_c2c_f32(_ptr(y), B, L, _ld(y), n_fft, hop, int(center), Tn, _ptr(win),
                                      _ptr(twiddle_rfft_dev(n_fft)), _ptr(out), C.c_void_p(_stream_ptr()))
     check(rc, "syg_stft_pow2_c2c_f32")
     return out
@@ -330,8 +335,8 @@ def sosfiltfilt(x: torch.Tensor, sos: np.ndarray, zi: np.ndarray, padlen: int) -
         raise SygnalsHipError(f"sosfiltfilt: unsupported configuration (sections={S}, max 8)")
     work = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
     y = torch.empty((B, L), dtype=torch.float32, device=x.device)
-    rc = lib().syg_sosfiltfilt_f32(_ptr(x), B, L, x.stride(0), sos.ctypes.data_as(C.c_void_p),
-                                   zi.ctypes.data_as(C.c_void_p), S, int(padlen), _ptr(y), y.stride(0), _ptr(work),
+    rc = lib().syg_sosfiltfilt_f32(_ptr(x), B, L, _ld(x), sos.ctypes.data_as(C.c_void_p),
+                                   zi.ctypes.data_as(C.c_void_p), S, int(padlen), _ptr(y), _ld(y), _ptr(work),
                                    C.c_void_p(_stream_ptr()))
     check(rc, "syg_sosfiltfilt_f32")
     return y
@@ -348,7 +353,7 @@ def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: 
     nbytes = lib().syg_welch_work_bytes(B, nfft)
     work = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     out = torch.empty((B, nfft // 2 + 1), dtype=torch.float32, device=x.device)
-    rc = lib().syg_welch_f32(_ptr(x), B, L, x.stride(0), nperseg, nperseg - noverlap, nfft, _ptr(win),
+    rc = lib().syg_welch_f32(_ptr(x), B, L, _ld(x), nperseg, nperseg - noverlap, nfft, _ptr(win),
                              _ptr(twiddle_rfft_dev(nfft)), int(bool(detrend)), float(scale), _ptr(out), _ptr(work),
                              C.c_void_p(_stream_ptr()))
     check(rc, "syg_welch_f32")
@@ -417,7 +422,7 @@ def pack_real(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None) ->
         x = x.contiguous()
     rows, ln = x.shape
     out = torch.empty((rows, n, 2), dtype=torch.float32, device=x.device)
-    rc = lib().syg_pack_real_c64(_ptr(x), rows, ln, x.stride(0), _ptr(window), _ptr(out), n,
+    rc = lib().syg_pack_real_c64(_ptr(x), rows, ln, _ld(x), _ptr(window), _ptr(out), n,
                                  C.c_void_p(_stream_ptr()))
     check(rc, "syg_pack_real_c64")
     return out
