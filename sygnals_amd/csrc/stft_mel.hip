@@ -22,6 +22,10 @@
 #include "common.h"
 #include <string.h>
 
+#ifndef SYG_ABL
+#define SYG_ABL 0   // development ablations (tools/ablate.sh); 0 = product build
+#endif
+
 namespace syg {
 namespace {
 
@@ -103,8 +107,13 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   const int cl = lane >> 2, bp = lane & 3;
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
   dft16(v);
+#if SYG_ABL == 3 || SYG_ABL == 4
+#pragma unroll
+  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], make_float2(0.6f, 0.8f));
+#else
 #pragma unroll
   for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], tw1l[(c - 1) * 64 + lane]);
+#endif
   // ---- exchange 1 in two half-rounds through a 512-complex buffer: round h moves the 32 COLUMNS
   // b = 32h..32h+31 (those 32 lanes store their 16 values, y[c][b] at c*32 + ((b & 31) ^ 4(c & 7))); every
   // lane then reads the 8 operands y[lane>>2][4a + b'], a = 8h..8h+7, that live in this half -- the reads
@@ -114,6 +123,10 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
     const int wcol = lane & 31;
     const int rx = 4 * (cl & 7);
     const int rbase = cl * 32 + bp;
+#if SYG_ABL == 2 || SYG_ABL == 4
+#pragma unroll
+    for (int a = 0; a < 16; ++a) t[a] = v[a];
+#else
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if ((lane >> 5) == h) {
@@ -125,6 +138,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
       for (int i = 0; i < 8; ++i) t[8 * h + i] = sc[rbase + ((4 * i) ^ rx)];
       wave_lds_sync();
     }
+#endif
   }
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
   dft16(t);
@@ -143,6 +157,13 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   float2 G[2][4], H[2][4];
   {
     const int wbase = bp * PL2;
+#if SYG_ABL == 2 || SYG_ABL == 4
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bfly4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3], G[j][0], G[j][1], G[j][2], G[j][3]);
+      bfly4(t[8 + 4 * j], t[9 + 4 * j], t[10 + 4 * j], t[11 + 4 * j], H[j][0], H[j][1], H[j][2], H[j][3]);
+    }
+#else
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -156,6 +177,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
       }
       wave_lds_sync();
     }
+#endif
   }
   // ---- real split on mirror pairs
   x512 = make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
@@ -433,7 +455,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       int lv = lane;
       asm volatile("" : "+v"(lv));
       float2 v[16];
+#if SYG_ABL == 1
+#pragma unroll
+      for (int a = 0; a < 16; ++a) v[a] = make_float2((float)(lv + a) * 1e-3f, (float)(lv - a) * 1e-3f);
+#else
       load_frame<VEC2>(v, y + b * ldy, L, t * (int64_t)hop - pad, win2, lv);
+#endif
       float2 xs[2][4], xm[2][4], x512;
       wave_rfft2048(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512);
       if (COMPLEX_OUT) {
