@@ -72,85 +72,6 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     bfly4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3], v[q], v[q + 4], v[q + 8], v[q + 12]);
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// Packed complex arithmetic.  gfx950 reaches its fp32 vector peak only through the packed VOP3P forms
-// (v_pk_add/mul/fma_f32: two fp32 lanes per register pair per issue; a plain v_add_f32 occupies the same
-// issue slot for half the work -- measured: ~4 cycles per wave64 VALU instruction either way).  A complex
-// number is a natural pair, so the FFT butterflies are written on clang's native 2-vectors: a + b is ONE
-// v_pk_add_f32, a twiddle multiply is v_pk_mul + v_pk_fma with op_sel / neg modifiers for the swizzles.
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2f pcmul(v2f a, v2f w) {
-  const v2f wr = {-w.y, w.x};
-  return a.xx * w + a.yy * wr;           // (ax wx - ay wy, ax wy + ay wx)
-}
-__device__ __forceinline__ v2f p_mi(v2f a) { return v2f{a.y, -a.x}; }   // a * (-i)
-
-// Single-instruction forms of the swizzled adds (VOP3P op_sel / neg modifiers; the compiler materialises
-// the swizzle with v_xor + v_mov when its result has two users):
-//   pk_add_mi(a, b)   = a + (-i) b = (a.x + b.y, a.y - b.x)      pk_sub_mi(a, b)   = a - (-i) b
-//   pk_add_conj(a, b) = a + conj(b) = (a.x + b.x, a.y - b.y)      pk_sub_conj(a, b) = a - conj(b)
-__device__ __forceinline__ v2f pk_add_mi(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ v2f pk_sub_mi(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// ((-i) d) * w  without forming (-i) d:  d.yy * w - d.xx * (-w.y, w.x)
-__device__ __forceinline__ v2f pcmul_mi(v2f d, v2f w) {
-  const v2f wr = {-w.y, w.x};
-  return d.yy * w - d.xx * wr;
-}
-
-// Forward radix-4 butterfly: o[q] = sum_p a[p] * (-i)^(p*q).  A2MI: input a2 still needs its (-i) factor
-// (the W16^4 twiddle of the 16-point transform), applied inside the first adds.
-template <bool A2MI = false>
-__device__ __forceinline__ void pbfly4(v2f a0, v2f a1, v2f a2, v2f a3, v2f& o0, v2f& o1, v2f& o2, v2f& o3) {
-  const v2f t0 = A2MI ? pk_add_mi(a0, a2) : a0 + a2;
-  const v2f t1 = A2MI ? pk_sub_mi(a0, a2) : a0 - a2;
-  const v2f t2 = a1 + a3, t3 = a1 - a3;
-  o0 = t0 + t2;
-  o2 = t0 - t2;
-  o1 = pk_add_mi(t1, t3);
-  o3 = pk_sub_mi(t1, t3);
-}
-
-// In-register forward 16-point DFT, natural order in and out (radix-4 x radix-4), packed math.
-__device__ __forceinline__ void pdft16(v2f (&v)[16]) {
-  constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
-  v2f s[16];  // s[i + 4q]
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pbfly4(v[i], v[i + 4], v[i + 8], v[i + 12], s[i], s[i + 4], s[i + 8], s[i + 12]);
-  // twiddle s[i + 4q] *= W16^(i*q); W16^4 = -i of s[2 + 8] is folded into its butterfly (A2MI)
-  s[1 + 4] = pcmul(s[1 + 4], v2f{C1, -S1});    // e=1
-  s[2 + 4] = pcmul(s[2 + 4], v2f{R, -R});      // e=2
-  s[3 + 4] = pcmul(s[3 + 4], v2f{S1, -C1});    // e=3
-  s[1 + 8] = pcmul(s[1 + 8], v2f{R, -R});      // e=2
-  s[3 + 8] = pcmul(s[3 + 8], v2f{-R, -R});     // e=6
-  s[1 + 12] = pcmul(s[1 + 12], v2f{S1, -C1});  // e=3
-  s[2 + 12] = pcmul(s[2 + 12], v2f{-R, -R});   // e=6
-  s[3 + 12] = pcmul(s[3 + 12], v2f{-C1, S1});  // e=9
-  pbfly4(s[0], s[1], s[2], s[3], v[0], v[4], v[8], v[12]);
-  pbfly4(s[4], s[5], s[6], s[7], v[1], v[5], v[9], v[13]);
-  pbfly4<true>(s[8], s[9], s[10], s[11], v[2], v[6], v[10], v[14]);
-  pbfly4(s[12], s[13], s[14], s[15], v[3], v[7], v[11], v[15]);
-}
-
 // Lanes of one wave exchange data through LDS without a workgroup barrier (the LDS executes a wave's
 // DS instructions in order).  To the COMPILER that is a data race: it may assume a lane that did not store
 // re-reads unchanged memory.  This wavefront-scope release/acquire pair emits no instruction but makes every

@@ -64,8 +64,8 @@ __device__ __forceinline__ int x2g(int c, int cp) { return (cp & 7) * 16 + ((c +
 __device__ __forceinline__ int ppos(int k) { return k + (k >> 4); }
 
 struct LaneConst {
-  v2f twb[2];        // W_2048^kb of each unit (kb = c + 16 c'); pair d uses twb * W_8^d
-  v2f cA2, cA3;      // unit-0 multipliers for d = 2, 3: W_8^2, W_8^3 -- except lane 0 (see below)
+  float2 twb[2];     // W_2048^kb of each unit (kb = c + 16 c'); pair d uses twb * W_8^d
+  float2 cA2, cA3;   // unit-0 multipliers for d = 2, 3: W_8^2, W_8^3 -- except lane 0 (see below)
   int pkb[2];        // ppos(kb): pair d of a regular unit sits at pkb + 272 d (its mirror at pmb - 272 d)
   int pmb[2];        // ppos(1024 - kb)
   int dA2, dA3;      // unit-0 position offsets for d = 2, 3 (544, 816 -- except lane 0)
@@ -76,7 +76,7 @@ struct LaneConst {
 // unit u = lane + 64 j: primary group (c = u >> 3, c' = u & 7), bins k = kb + 256 d; mirror group
 // (16 - c, 15 - c') holds bins 1024 - k, with the c = 0 exceptions (0, 16 - c') and, for u = 0 (lane 0), the
 // self-mirrored pair of groups (0,0) / (0,8) whose four pairs are the bins {0, 256, 128, 384} (+ bin 512).
-__device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const v2f* __restrict__ twid) {
+__device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const float2* __restrict__ twid) {
   constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -92,33 +92,33 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const v
     lc.twb[j] = twid[kb];
   }
   const bool sp = (lane == 0);
-  lc.cA2 = sp ? v2f{C1, -S1} : v2f{0.f, -1.f};   // W_2048^128 = W_16^1   |  W_8^2
-  lc.cA3 = sp ? v2f{S1, -C1} : v2f{-R, -R};      // W_2048^384 = W_16^3   |  W_8^3
+  lc.cA2 = sp ? make_float2(C1, -S1) : make_float2(0.f, -1.f);   // W_2048^128 = W_16^1   |  W_8^2
+  lc.cA3 = sp ? make_float2(S1, -C1) : make_float2(-R, -R);      // W_2048^384 = W_16^3   |  W_8^3
   lc.dA2 = sp ? ppos(128) : 544;
   lc.dA3 = sp ? ppos(384) : 816;
 }
 
 // 1024-point complex forward FFT of the windowed frame + real split.  v[a] holds z[64a + lane] on entry.
-// On exit pair (j, d) holds 2 X[k] in xs[j][d] and 2 conj(X[1024 - k]) in xm[j][d] (k = kb_j + 256 d; lane 0 /
-// unit 0: k = 0, 256, 128, 384); lane 0 also returns X[512] (true scale).
-__device__ __forceinline__ void wave_rfft2048(v2f (&v)[16], const LaneConst& lc, v2f* __restrict__ sc,
-                                             const v2f* __restrict__ tw1l, const v2f* __restrict__ tw2l,
-                                             int lane, v2f (&xs)[2][4], v2f (&xm)[2][4], v2f& x512) {
+// On exit pair (j, d) holds X[k] in xs[j][d] and X[1024 - k] in xm[j][d] (k = kb_j + 256 d; lane 0 / unit 0:
+// k = 0, 256, 128, 384); lane 0 also returns X[512].
+__device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
+                                             const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
+                                             int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512) {
   const int cl = lane >> 2, bp = lane & 3;
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
-  pdft16(v);
+  dft16(v);
 #if SYG_ABL == 3 || SYG_ABL == 4
 #pragma unroll
-  for (int c = 1; c < 16; ++c) v[c] = pcmul(v[c], v2f{0.6f, 0.8f});
+  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], make_float2(0.6f, 0.8f));
 #else
 #pragma unroll
-  for (int c = 1; c < 16; ++c) v[c] = pcmul(v[c], tw1l[(c - 1) * 64 + lane]);
+  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], tw1l[(c - 1) * 64 + lane]);
 #endif
   // ---- exchange 1 in two half-rounds through a 512-complex buffer: round h moves the 32 COLUMNS
   // b = 32h..32h+31 (those 32 lanes store their 16 values, y[c][b] at c*32 + ((b & 31) ^ 4(c & 7))); every
   // lane then reads the 8 operands y[lane>>2][4a + b'], a = 8h..8h+7, that live in this half -- the reads
   // are not divergent and land in fixed registers
-  v2f t[16];
+  float2 t[16];
   {
     const int wcol = lane & 31;
     const int rx = 4 * (cl & 7);
@@ -141,27 +141,27 @@ __device__ __forceinline__ void wave_rfft2048(v2f (&v)[16], const LaneConst& lc,
 #endif
   }
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
-  pdft16(t);
+  dft16(t);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
     const float4* t4 = reinterpret_cast<const float4*>(tw2l + bp * TW2_STRIDE);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const float4 tt = t4[m];
-      if (m > 0) t[2 * m] = pcmul(t[2 * m], v2f{tt.x, tt.y});
-      t[2 * m + 1] = pcmul(t[2 * m + 1], v2f{tt.z, tt.w});
+      if (m > 0) t[2 * m] = cmul(t[2 * m], make_float2(tt.x, tt.y));
+      t[2 * m + 1] = cmul(t[2 * m + 1], make_float2(tt.z, tt.w));
     }
   }
   // ---- exchange 2 in two half-rounds (c' < 8, then c' >= 8); every unit's primary group has c' < 8 and its
   // mirror c' >= 8, so round 0 delivers all primaries and round 1 all mirrors.  Pass 3 = radix-4 over b'.
-  v2f G[2][4], H[2][4];
+  float2 G[2][4], H[2][4];
   {
     const int wbase = bp * PL2;
 #if SYG_ABL == 2 || SYG_ABL == 4
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      pbfly4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3], G[j][0], G[j][1], G[j][2], G[j][3]);
-      pbfly4(t[8 + 4 * j], t[9 + 4 * j], t[10 + 4 * j], t[11 + 4 * j], H[j][0], H[j][1], H[j][2], H[j][3]);
+      bfly4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3], G[j][0], G[j][1], G[j][2], G[j][3]);
+      bfly4(t[8 + 4 * j], t[9 + 4 * j], t[10 + 4 * j], t[11 + 4 * j], H[j][0], H[j][1], H[j][2], H[j][3]);
     }
 #else
 #pragma unroll
@@ -171,20 +171,20 @@ __device__ __forceinline__ void wave_rfft2048(v2f (&v)[16], const LaneConst& lc,
       wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const v2f* p = sc + (h == 0 ? lc.g0[j] : lc.g1[j]);
-        if (h == 0) pbfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], G[j][0], G[j][1], G[j][2], G[j][3]);
-        else pbfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], H[j][0], H[j][1], H[j][2], H[j][3]);
+        const float2* p = sc + (h == 0 ? lc.g0[j] : lc.g1[j]);
+        if (h == 0) bfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], G[j][0], G[j][1], G[j][2], G[j][3]);
+        else bfly4(p[0], p[PL2], p[2 * PL2], p[3 * PL2], H[j][0], H[j][1], H[j][2], H[j][3]);
       }
       wave_lds_sync();
     }
 #endif
   }
   // ---- real split on mirror pairs
-  x512 = v2f{G[0][2].x, -G[0][2].y};      // X[512] = conj(Z[512]) (meaningful in lane 0 only; true scale)
+  x512 = make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    v2f zk[4] = {G[j][0], G[j][1], G[j][2], G[j][3]};
-    v2f zm[4] = {H[j][3], H[j][2], H[j][1], H[j][0]};
+    float2 zk[4] = {G[j][0], G[j][1], G[j][2], G[j][3]};
+    float2 zm[4] = {H[j][3], H[j][2], H[j][1], H[j][0]};
     if (j == 0) {
       // unit 0 (lane 0) pairs the self-mirrored groups (0,0) and (0,8) differently
       const bool sp = (lane == 0);
@@ -197,21 +197,20 @@ __device__ __forceinline__ void wave_rfft2048(v2f (&v)[16], const LaneConst& lc,
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      // E = zk + conj(zm), D = zk - conj(zm), O = -i D;  2 X[k] = E + w O,  2 conj(X[1024-k]) = E - w O.
-      // Outputs are returned UNSCALED and unconjugated for the mirror: xs = 2 X[k], xm = 2 conj(X[1024-k]).
-      const v2f E = pk_add_conj(zk[d], zm[d]);
-      const v2f D = pk_sub_conj(zk[d], zm[d]);
+      // E2 = zk + conj(zm), O2 = -i (zk - conj(zm));  X[k] = (E2 + w O2)/2, X[1024-k] = conj(E2 - w O2)/2
+      const float2 E = make_float2(zk[d].x + zm[d].x, zk[d].y - zm[d].y);
+      const float2 O = make_float2(zk[d].y + zm[d].y, zm[d].x - zk[d].x);
       // w = twb * W_8^d (unit 0, d >= 2: twb * cA_d, which differs in lane 0 only)
       constexpr float R = 0.70710678118654752440f;
-      v2f rO;
-      if (d == 0) rO = p_mi(D);
-      else if (d == 1) rO = pcmul_mi(D, v2f{R, -R});
-      else if (j == 0) rO = pcmul_mi(D, d == 2 ? lc.cA2 : lc.cA3);
-      else if (d == 2) rO = -D;                       // (-i)(-i) D
-      else rO = pcmul_mi(D, v2f{-R, -R});
-      const v2f wO = pcmul(rO, lc.twb[j]);
-      xs[j][d] = E + wO;
-      xm[j][d] = E - wO;
+      float2 rO;
+      if (d == 0) rO = O;
+      else if (d == 1) rO = make_float2(R * (O.x + O.y), R * (O.y - O.x));
+      else if (j == 0) rO = cmul(O, d == 2 ? lc.cA2 : lc.cA3);
+      else if (d == 2) rO = make_float2(O.y, -O.x);
+      else rO = make_float2(R * (O.y - O.x), -R * (O.x + O.y));
+      const float2 wO = cmul(lc.twb[j], rO);
+      xs[j][d] = make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
+      xm[j][d] = make_float2(0.5f * (E.x - wO.x), -0.5f * (E.y - wO.y));
     }
   }
 }
@@ -219,17 +218,18 @@ __device__ __forceinline__ void wave_rfft2048(v2f (&v)[16], const LaneConst& lc,
 // Windowed samples of one frame: element n = 64a + lane of the packed complex frame covers samples
 // s0 + 2n, s0 + 2n + 1; samples outside [0, L) are the zero padding of center=True.
 template <bool VEC2>
-__device__ __forceinline__ void load_frame(v2f (&v)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
-                                           const v2f* __restrict__ win2, int lane) {
+__device__ __forceinline__ void load_frame(float2 (&v)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
+                                           const float2* __restrict__ win2, int lane) {
   const bool interior = (s0 >= 0) && (s0 + NFFT <= L);
   if (interior) {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
       const int n = 64 * a + lane;
-      v2f x;
-      if (VEC2) x = *reinterpret_cast<const v2f*>(yb + s0 + 2 * n);
-      else x = v2f{yb[s0 + 2 * n], yb[s0 + 2 * n + 1]};
-      v[a] = x * win2[n];
+      float2 x;
+      if (VEC2) x = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
+      else x = make_float2(yb[s0 + 2 * n], yb[s0 + 2 * n + 1]);
+      const float2 wv = win2[n];
+      v[a] = make_float2(x.x * wv.x, x.y * wv.y);
     }
   } else {
 #pragma unroll
@@ -238,7 +238,8 @@ __device__ __forceinline__ void load_frame(v2f (&v)[16], const float* __restrict
       const int64_t s = s0 + 2 * n;
       const float x0 = (s >= 0 && s < L) ? yb[s] : 0.f;
       const float x1v = (s + 1 >= 0 && s + 1 < L) ? yb[s + 1] : 0.f;
-      v[a] = v2f{x0, x1v} * win2[n];
+      const float2 wv = win2[n];
+      v[a] = make_float2(x0 * wv.x, x1v * wv.y);
     }
   }
 }
@@ -394,21 +395,21 @@ __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, i
 template <int WAVES, bool VEC2, int MODE>
 __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int tiles_per_clip,
-    int64_t total_tiles, int tiles_per_wg, const v2f* __restrict__ win2, const v2f* __restrict__ twid,
+    int64_t total_tiles, int tiles_per_wg, const float2* __restrict__ win2, const float2* __restrict__ twid,
     const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
     float roll_percent, float bw_p, float* __restrict__ stats_out, ContrastPlan cplan,
-    float* __restrict__ contrast_out, v2f* __restrict__ cout) {
+    float* __restrict__ contrast_out, float2* __restrict__ cout) {
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
   constexpr int SLAB_FLOATS = WAVES * 16 * TILE_T;
   constexpr bool COMPLEX_OUT = (MODE == 2);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  v2f* scratch = reinterpret_cast<v2f*>(lds);                       // [WAVES][528] complex
+  float2* scratch = reinterpret_cast<float2*>(lds);                 // [WAVES][528] complex
   float* Pbuf = lds + WAVES * SC_COMPLEX * 2;                       // [TILE_T][P_STRIDE] (+16)
   float* slab = Pbuf + P_FLOATS;                                    // [WAVES][16][TILE_T]
-  v2f* tw2l = reinterpret_cast<v2f*>(slab + SLAB_FLOATS);           // [4][18] complex
-  v2f* tw1l = tw2l + TW2_FLOATS / 2;                                // [15][64] complex
+  float2* tw2l = reinterpret_cast<float2*>(slab + SLAB_FLOATS);     // [4][18] complex
+  float2* tw1l = tw2l + TW2_FLOATS / 2;                             // [15][64] complex
   int* cpl = reinterpret_cast<int*>(slab + SLAB_FLOATS + TW2_FLOATS + TW1_FLOATS);  // contrast plan
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 
   LaneConst lc;
   init_lane_const(lc, lane, twid);
-  v2f* sc = scratch + w * SC_COMPLEX;
+  float2* sc = scratch + w * SC_COMPLEX;
   if (tid < 64) tw2l[(tid >> 4) * TW2_STRIDE + (tid & 15)] = twid[32 * (tid >> 4) * (tid & 15)];
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
 
@@ -453,25 +454,25 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       // loop as ~100 loop-invariant registers that would spill
       int lv = lane;
       asm volatile("" : "+v"(lv));
-      v2f v[16];
+      float2 v[16];
 #if SYG_ABL == 1
 #pragma unroll
-      for (int a = 0; a < 16; ++a) v[a] = v2f{(float)(lv + a) * 1e-3f, (float)(lv - a) * 1e-3f};
+      for (int a = 0; a < 16; ++a) v[a] = make_float2((float)(lv + a) * 1e-3f, (float)(lv - a) * 1e-3f);
 #else
       load_frame<VEC2>(v, y + b * ldy, L, t * (int64_t)hop - pad, win2, lv);
 #endif
-      v2f xs[2][4], xm[2][4], x512;
+      float2 xs[2][4], xm[2][4], x512;
       wave_rfft2048(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512);
       if (COMPLEX_OUT) {
-        v2f* o = cout + (b * T + t) * NBIN;
+        float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
             int k = lc.kb[u] + 256 * d;
             if (u == 0 && d >= 2 && lane == 0) k = (d == 2) ? 128 : 384;
-            o[k] = xs[u][d] * v2f{0.5f, 0.5f};
-            o[MC - k] = xm[u][d] * v2f{0.5f, -0.5f};
+            o[k] = xs[u][d];
+            o[MC - k] = xm[u][d];
           }
         if (lane == 0) o[512] = x512;
       } else {
@@ -480,9 +481,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
             const int off = (u == 0 && d == 2) ? lc.dA2 : (u == 0 && d == 3) ? lc.dA3 : 272 * d;
-            const v2f qs = xs[u][d] * xs[u][d], qm = xm[u][d] * xm[u][d];
-            prow[lc.pkb[u] + off] = 0.25f * (qs.x + qs.y);
-            prow[lc.pmb[u] - off] = 0.25f * (qm.x + qm.y);
+            prow[lc.pkb[u] + off] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
+            prow[lc.pmb[u] - off] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
           }
         if (lane == 0) prow[ppos(512)] = fmaf(x512.x, x512.x, x512.y * x512.y);
       }
@@ -607,8 +607,8 @@ int launch(bool vec2, const float* y, int64_t B, int64_t L, int64_t ldy, int hop
     attr_set[vec2] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes<WAVES>(), st, y, L, ldy, hop, pad, T,
-                     tiles, total_tiles, per, (const v2f*)window, (const v2f*)twiddle, wpacked, plan, n_mels,
-                     mel_out, binhz, roll_percent, bw_p, stats_out, cp, contrast_out, (v2f*)cout);
+                     tiles, total_tiles, per, (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels,
+                     mel_out, binhz, roll_percent, bw_p, stats_out, cp, contrast_out, (float2*)cout);
   SYG_CHECK_LAUNCH("stft2048");
   return SYG_OK;
 }
