@@ -13,7 +13,7 @@ import functools
 import numpy as np
 import scipy.signal
 
-WAVES = 8           # default waves per workgroup of the fused kernel (stft_mel.hip): 8 or 16
+WAVES = 16          # default waves per workgroup of the fused kernel (stft_mel.hip): 8 or 16
 MAXW = 16
 MAX_BANDS = 16      # SYG_MAX_BANDS
 

@@ -50,7 +50,11 @@ def test_mel_plan_reconstructs_dense_basis(n_mels, waves):
 
 def test_mel_plan_rejects_too_many_mels():
     with pytest.raises(ValueError, match="max n_mels 128"):
-        T.pack_mel_plan(np.ones((129, 1025), np.float32))
+        T.pack_mel_plan(np.ones((129, 1025), np.float32), 8)
+    with pytest.raises(ValueError, match="max n_mels 256"):
+        T.pack_mel_plan(np.ones((257, 1025), np.float32), 16)
+    with pytest.raises(ValueError, match="waves must be 8 or 16"):
+        T.pack_mel_plan(np.ones((16, 1025), np.float32), 4)
 
 
 def test_dct_matrix_and_lifter():
