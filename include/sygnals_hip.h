@@ -179,6 +179,22 @@ int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg
                   const float* window, const float* twiddle, int detrend, double scale, float* psd_out,
                   void* work, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Constant-Q transform building blocks: librosa.cqt as called by compute_cqt,
+ * sygnals/core/dsp.py:276-284 (recursive per-octave algorithm; the host composes the octaves).
+ *   syg_decimate2_f32   y[b, n] = scale * sum_j taps[j] * x[b, 2n + (ntaps-1)/2 - j], n < ceil(L/2)
+ *                       (zero outside the signal) -- the decimation between octaves
+ *   syg_cqt_octave_f32  rectangular-window centred STFT frame (n_fft = 2^k <= 4096, hop) of y [B, L],
+ *                       times the frequency-domain basis [n_filt, n_fft/2+1] complex64 ->
+ *                       out[b * out_bstride + (row0 + f) * T + t] complex64; twiddle as for
+ *                       syg_stft_pow2_c2c_f32 ([n_fft + n_fft/2] complex)
+ * ------------------------------------------------------------------------------- */
+int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const float* taps, int ntaps, float scale,
+                      float* y, int64_t ldy, void* stream);
+int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
+                       const float* twiddle, const float* basis, int n_filt, float* out, int64_t out_bstride,
+                       int row0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -668,3 +668,143 @@ def mfcc_batch(Y, sr, n_fft=2048, hop_length=512, n_mels=40, n_mfcc=13, center=T
     """[B, n_mfcc, T] float64 -- config C2 for a batch of clips, one clip at a time."""
     return np.stack([mfcc_manager(np.asarray(y, dtype=np.float64), sr, n_fft, hop_length, center, window,
                                   n_mels, n_mfcc, fmin, fmax, 2.0, lifter) for y in Y])
+
+
+# --------------------------------------------------------------------------
+# a15 constant-Q transform (dsp.py:231-289 -> librosa.cqt)       PARITY UNPINNED
+# --------------------------------------------------------------------------
+# Restatement of librosa.cqt / librosa.vqt (gamma = 0) as published for librosa 0.10: early downsampling,
+# per-octave STFT (rectangular window) times a sparsified frequency-domain constant-Q basis, recursive
+# decimation by two, octave stacking and length scaling.  ONE DOCUMENTED DEVIATION: librosa resamples with
+# libsoxr ('soxr_hq', a C library that is not available here); `cqt_resample2` below uses
+# scipy.signal.resample_poly(y, 1, 2) (Kaiser-windowed FIR, 41 taps) with librosa's length / sqrt(2) scaling
+# rules.  Parity target for the device CQT is THIS restatement (SURVEY section 8c).
+HANN_BANDWIDTH = 1.50018310546875          # librosa.filters.WINDOW_BANDWIDTHS['hann']
+
+
+def note_c1_hz():
+    """librosa.note_to_hz('C1') = 440 * 2**((24 - 69) / 12)."""
+    return 440.0 * 2.0 ** ((24 - 69) / 12.0)
+
+
+def cqt_frequencies(n_bins, fmin, bins_per_octave=12, tuning=0.0):
+    corr = 2.0 ** (float(tuning) / bins_per_octave)
+    return corr * fmin * 2.0 ** (np.arange(n_bins, dtype=np.float64) / bins_per_octave)
+
+
+def cqt_resample2(y):
+    """Decimate by two: stand-in for librosa.resample(y, orig_sr=2, target_sr=1, res_type='soxr_hq', scale=True)."""
+    n = int(np.ceil(y.shape[-1] * 0.5))
+    z = scipy.signal.resample_poly(np.asarray(y, dtype=np.float64), 1, 2)
+    if z.shape[-1] < n:
+        z = np.pad(z, (0, n - z.shape[-1]))
+    return z[:n] * np.sqrt(2.0)            # scale=True: y_hat /= sqrt(ratio), ratio = 1/2
+
+
+def cqt_decimation_taps():
+    """FIR used by scipy.signal.resample_poly(x, 1, 2): firwin(41, 0.5, window=('kaiser', 5.0))."""
+    return scipy.signal.firwin(41, 0.5, window=("kaiser", 5.0))
+
+
+def _wavelet_lengths(freqs, sr, filter_scale, alpha):
+    Q = float(filter_scale) / alpha
+    cutoff = np.max(freqs * (1 + 0.5 * HANN_BANDWIDTH / Q))
+    return Q * sr / freqs, cutoff
+
+
+def cqt_filter_fft(sr, freqs, filter_scale, alpha, sparsity=0.01):
+    """Frequency-domain basis of one octave: (fft_basis complex128 [n_filters, n_fft//2+1], n_fft)."""
+    lengths, _ = _wavelet_lengths(freqs, sr, filter_scale, alpha)
+    max_len = int(2.0 ** np.ceil(np.log2(lengths.max())))
+    basis = np.zeros((len(freqs), max_len), dtype=np.complex128)
+    for i, (ilen, f) in enumerate(zip(lengths, freqs)):
+        t = np.arange(-ilen // 2, ilen // 2, dtype=np.float64)
+        sig = np.exp(1j * 2 * np.pi * f / sr * t)
+        sig = sig * scipy.signal.get_window("hann", len(sig), fftbins=True)
+        sig = sig / np.sum(np.abs(sig))                      # norm=1
+        lp = (max_len - len(sig)) // 2
+        basis[i, lp:lp + len(sig)] = sig                     # util.pad_center
+    n_fft = max_len
+    basis *= lengths[:, None] / float(n_fft)
+    fb = np.fft.fft(basis, n=n_fft, axis=1)[:, :n_fft // 2 + 1]
+    # util.sparsify_rows(quantile=sparsity)
+    mags = np.abs(fb)
+    norms = mags.sum(axis=1, keepdims=True)
+    srt = np.sort(mags, axis=1)
+    cum = np.cumsum(srt / norms, axis=1)
+    tidx = np.argmin(cum < sparsity, axis=1)
+    out = np.zeros_like(fb)
+    for i, j in enumerate(tidx):
+        keep = mags[i] >= srt[i, j]
+        out[i, keep] = fb[i, keep]
+    return out, n_fft
+
+
+def cqt_plan(sr, hop_length=512, fmin=None, n_bins=84, bins_per_octave=12, filter_scale=1.0, sparsity=0.01):
+    """Everything that does not depend on the signal: octave schedule, bases (scalings folded in)."""
+    if fmin is None:
+        fmin = note_c1_hz()
+    n_oct = int(np.ceil(float(n_bins) / bins_per_octave))
+    n_filters = min(bins_per_octave, n_bins)
+    freqs = cqt_frequencies(n_bins, fmin, bins_per_octave)
+    r = 2.0 ** (2.0 / bins_per_octave)
+    alpha = (r - 1) / (r + 1)
+    lengths_full, cutoff = _wavelet_lengths(freqs, sr, filter_scale, alpha)
+    nyq = sr / 2.0
+    if cutoff > nyq:
+        raise ValueError(f"Wavelet basis with max frequency={freqs.max()} would exceed the Nyquist frequency={nyq}. "
+                         "Try reducing the number of frequency bins.")
+    # early downsampling
+    c1 = max(0, int(np.ceil(np.log2(nyq / cutoff)) - 1) - 1)
+    twos = 0
+    h = hop_length
+    while h > 0 and h % 2 == 0:
+        twos += 1; h //= 2
+    c2 = max(0, twos - n_oct + 1)
+    early = min(c1, c2)
+    if twos < n_oct - 1:
+        raise ValueError(f"hop_length must be a positive integer multiple of 2^{n_oct - 1} for {n_oct}-octave CQT")
+    sr0 = sr / float(2 ** early)
+    hop0 = hop_length // (2 ** early)
+    octs = []
+    my_sr, my_hop = sr0, hop0
+    for i in range(n_oct):
+        sl = slice(-n_filters, None) if i == 0 else slice(-n_filters * (i + 1), -n_filters * i)
+        fo = freqs[sl]
+        fb, n_fft = cqt_filter_fft(my_sr, fo, filter_scale, alpha, sparsity)
+        fb = fb * np.sqrt(sr0 / my_sr)
+        octs.append({"basis": fb, "n_fft": n_fft, "hop": my_hop, "sr": my_sr, "n": len(fo)})
+        if my_hop % 2 == 0:
+            my_hop //= 2
+            my_sr /= 2.0
+    # scale=True: lengths are taken at the (early-downsampled) rate
+    lengths_s, _ = _wavelet_lengths(freqs, sr0, filter_scale, alpha)
+    return {"early": early, "octaves": octs, "n_bins": n_bins, "scale": 1.0 / np.sqrt(lengths_s), "freqs": freqs}
+
+
+def cqt(y, sr, hop_length=512, fmin=None, n_bins=84, bins_per_octave=12, filter_scale=1.0, sparsity=0.01):
+    """complex128 [n_bins, 1 + len(y)//hop_length] (librosa.cqt layout), see the deviation note above."""
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    plan = cqt_plan(sr, hop_length, fmin, n_bins, bins_per_octave, filter_scale, sparsity)
+    my_y = y
+    for _ in range(plan["early"]):
+        my_y = cqt_resample2(my_y)
+    resp = []
+    for i, o in enumerate(plan["octaves"]):
+        D = stft(my_y, n_fft=o["n_fft"], hop_length=o["hop"], window="boxcar", center=True)
+        resp.append(o["basis"] @ D)
+        if i + 1 < len(plan["octaves"]) and plan["octaves"][i + 1]["hop"] != o["hop"]:
+            my_y = cqt_resample2(my_y)
+    max_col = min(c.shape[1] for c in resp)
+    out = np.zeros((n_bins, max_col), dtype=np.complex128)
+    end = n_bins
+    for c in resp:                                           # __trim_stack: highest octave first
+        n_oct = c.shape[0]
+        if end < n_oct:
+            out[:end] = c[-end:, :max_col]
+        else:
+            out[end - n_oct:end] = c[:, :max_col]
+        end -= n_oct
+    return out * plan["scale"][:, None]

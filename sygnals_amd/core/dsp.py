@@ -99,6 +99,34 @@ def compute_stft(y, n_fft: int = 2048, hop_length: Optional[int] = None, win_len
     return np.ascontiguousarray(_c128(X)[0].T).astype(np.complex128, copy=False)   # [F, T] like librosa
 
 
+def compute_cqt(y, sr: int, hop_length: Optional[int] = 512, fmin: Optional[float] = None, n_bins: int = 84,
+                bins_per_octave: int = 12, **kwargs) -> np.ndarray:
+    """Constant-Q transform, complex128 [n_bins, 1 + len(y)//hop_length] (dsp.py:231-289).
+
+    Accepted librosa keyword arguments: tuning (default 0.0), filter_scale (1), sparsity (0.01); the fixed choices
+    norm=1, window='hann', scale=True, pad_mode='constant' may be passed but not changed.  The decimation filter
+    differs from librosa's soxr_hq resampler (see sygnals_amd/_cqt.py).
+    """
+    y = np.asarray(y)
+    if y.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    fixed = {"norm": 1, "window": "hann", "scale": True, "pad_mode": "constant"}
+    for k, v in fixed.items():
+        if k in kwargs and kwargs.pop(k) != v:
+            raise SygnalsHipError(f"compute_cqt: only {k}={v!r} runs on the device")
+    kwargs.pop("res_type", None)
+    tuning = kwargs.pop("tuning", 0.0)
+    filter_scale = kwargs.pop("filter_scale", 1.0)
+    sparsity = kwargs.pop("sparsity", 0.01)
+    if kwargs:
+        raise TypeError(f"compute_cqt: unsupported arguments {sorted(kwargs)}")
+    if tuning is None:
+        raise SygnalsHipError("compute_cqt: tuning estimation (tuning=None) is not offloaded; pass a number")
+    out = ops.cqt(ops.to_device_f32(y[None, :]), sr, int(hop_length), fmin, n_bins, bins_per_octave, tuning,
+                  filter_scale, sparsity)
+    return _c128(out)[0].astype(np.complex128, copy=False)
+
+
 def compute_psd_welch(x, fs: float = 1.0, window: str = "hann", nperseg: Optional[int] = None,
                       noverlap: Optional[int] = None, nfft: Optional[int] = None,
                       detrend: Union[str, bool] = "constant", scaling: str = "density"

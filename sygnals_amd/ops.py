@@ -468,3 +468,63 @@ def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     cmul(A, bf, out=A)
     c = fft_pow2_any(A, True)
     return cmul(c[:, :n].contiguous(), w_out)
+
+
+# ------------------------------------------------------------------ constant-Q transform
+def decimate2(x: torch.Tensor, taps: torch.Tensor, scale: float) -> torch.Tensor:
+    """FIR decimation by two of x [B, L] -> [B, ceil(L/2)] (zero padded ends)."""
+    require_gpu()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B, L = x.shape
+    y = torch.empty((B, (L + 1) // 2), dtype=torch.float32, device=x.device)
+    rc = lib().syg_decimate2_f32(_ptr(x), B, L, _ld(x), _ptr(taps), taps.numel(), float(scale), _ptr(y), _ld(y),
+                                 C.c_void_p(_stream_ptr()))
+    check(rc, "syg_decimate2_f32")
+    return y
+
+
+def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: int = 84, bins_per_octave: int = 12,
+        tuning: float = 0.0, filter_scale: float = 1.0, sparsity: float = 0.01) -> torch.Tensor:
+    """Constant-Q transform of y [B, L] -> complex [B, n_bins, T, 2] float32, T = 1 + L // hop_length."""
+    from ._cqt import CqtPlan, decimation_taps
+    require_gpu()
+    key = ("cqt", float(sr), int(hop_length), None if fmin is None else float(fmin), int(n_bins), int(bins_per_octave),
+           float(tuning), float(filter_scale), float(sparsity))
+
+    def build():
+        p = CqtPlan(sr, hop_length, fmin, n_bins, bins_per_octave, tuning, filter_scale, sparsity)
+        for o in p.octaves:
+            b = o["basis"]
+            o["basis_dev"] = _dev(np.stack([b.real, b.imag], axis=-1).astype(np.float32))
+        p.taps_dev = _dev(decimation_taps().astype(np.float32))
+        return p
+    plan = _cached(key, build)
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    B, L = y.shape
+    # output frames = the smallest centred frame count over the octaves (librosa's __trim_stack); this is
+    # 1 + L // hop_length except when the rounded-up decimated lengths add a frame to every octave
+    Lc = L
+    for _ in range(plan.early):
+        Lc = (Lc + 1) // 2
+    Tn = None
+    for o in plan.octaves:
+        To = 1 + Lc // o["hop"]
+        Tn = To if Tn is None else min(Tn, To)
+        if o["decimate_after"]:
+            Lc = (Lc + 1) // 2
+    out = torch.zeros((B, plan.n_bins, Tn, 2), dtype=torch.float32, device=y.device)
+    cur = y
+    s2 = float(np.sqrt(2.0))
+    for _ in range(plan.early):
+        cur = decimate2(cur, plan.taps_dev, s2)
+    for o in plan.octaves:
+        if o["n"] > 0:
+            rc = lib().syg_cqt_octave_f32(_ptr(cur), B, cur.shape[1], _ld(cur), o["n_fft"], o["hop"], Tn,
+                                          _ptr(twiddle_rfft_dev(o["n_fft"])), _ptr(o["basis_dev"]), o["n"], _ptr(out),
+                                          plan.n_bins * Tn, o["row0"], C.c_void_p(_stream_ptr()))
+            check(rc, "syg_cqt_octave_f32")
+        if o["decimate_after"]:
+            cur = decimate2(cur, plan.taps_dev, s2)
+    return out

@@ -78,7 +78,7 @@ class SygnalsAmdPlugin(_Base):
 
     def register_transforms(self, registry):
         from ..core import dsp as D
-        for fn in (D.compute_fft, D.compute_ifft, D.compute_stft, D.compute_psd_welch, D.apply_window):
+        for fn in (D.compute_fft, D.compute_ifft, D.compute_stft, D.compute_cqt, D.compute_psd_welch, D.apply_window):
             registry.add_transform(fn.__name__, fn)
 
     def register_feature_extractors(self, registry):

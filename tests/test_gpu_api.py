@@ -224,3 +224,42 @@ def test_cli_features_extract_c1(tmp_path):
     assert "time" not in pd.read_csv(tmp_path / "o.csv").columns          # reference drops the index (data_handler.py:248)
     r = CliRunner().invoke(cli, ["features", "extract", str(tmp_path / "c1.wav"), "-o", str(tmp_path / "x.npz"), "-f", "bogus"])
     assert r.exit_code == 2 and "Unknown feature" in r.output
+
+
+def test_compute_cqt_vs_oracle():
+    """a15: device CQT against the oracle restatement (same decimation FIR) -- see DESIGN.md for the resampler note."""
+    from sygnals_amd.core.dsp import compute_cqt
+    sr = 22050
+    t = np.arange(2 * sr) / sr
+    y = np.sin(2 * np.pi * (100 * t + (5000 - 100) / 4 * t * t)).astype(np.float32).astype(np.float64)
+    C = compute_cqt(y, sr, n_bins=60, bins_per_octave=12)                    # reference tests/test_dsp.py:94-106
+    assert C.shape == (60, 1 + len(y) // 512) and C.dtype == np.complex128
+    assert peak_rel(C, O.cqt(y, sr, n_bins=60)) <= TOL
+    pk = np.abs(C).argmax(axis=0)[5:-5]
+    assert (np.diff(pk) >= 0).mean() > 0.97
+    y2 = O.synth_clips(1, 48000, 48000, seed=4)[0].astype(np.float64)
+    C2 = compute_cqt(y2, 48000)                                              # config C5 parameters: 84 bins from C1
+    assert C2.shape == (84, 94)
+    assert peak_rel(C2, O.cqt(y2, 48000)) <= TOL
+    C3 = compute_cqt(y2[:20001], 48000, hop_length=256, n_bins=36, bins_per_octave=12, fmin=110.0)
+    assert peak_rel(C3, O.cqt(y2[:20001], 48000, hop_length=256, n_bins=36, fmin=110.0)) <= TOL
+    with pytest.raises(ValueError, match="1D"):
+        compute_cqt(np.zeros((2, 100)), sr)
+    with pytest.raises(ValueError, match="Nyquist"):
+        compute_cqt(y2, 8000)
+
+
+def test_cqt_batch_long_stream_consistency():
+    """C5-shaped use: a batch of long streams; size-independent property: linearity and time-shift by whole hops."""
+    from sygnals_amd import ops
+    rng = np.random.default_rng(5)
+    L = 48000 * 8
+    x = rng.normal(0, 0.1, (2, L)).astype(np.float32)
+    X = ops.cqt(ops.to_device_f32(x), 48000).cpu().numpy()
+    X = X[..., 0] + 1j * X[..., 1]
+    S = ops.cqt(ops.to_device_f32((x[0] + 2 * x[1])[None]), 48000).cpu().numpy()
+    S = S[0, ..., 0] + 1j * S[0, ..., 1]
+    assert peak_rel(S, X[0] + 2 * X[1]) <= TOL
+    ref = O.cqt(x[0, :48000 * 2].astype(np.float64), 48000)
+    got = X[0][:, :150]
+    assert peak_rel(got[:, :150], ref[:, :150]) <= 1e-3     # edge of the 2 s excerpt differs only through filter tails

@@ -196,3 +196,25 @@ def test_ops_fail_loudly_without_gpu():
     from sygnals_amd.core import dsp as D
     with pytest.raises(SygnalsHipError):
         D.compute_fft(np.zeros(64))
+
+
+@pytest.mark.parametrize("sr,hop,n_bins", [(48000, 512, 84), (22050, 512, 60), (16000, 256, 84), (44100, 1024, 40)])
+def test_cqt_plan_matches_oracle(sr, hop, n_bins):
+    from sygnals_amd._cqt import CqtPlan, decimation_taps
+    if sr == 16000 and n_bins == 84:
+        n_bins = 72
+    p, q = CqtPlan(sr, hop, n_bins=n_bins), O.cqt_plan(sr, hop, n_bins=n_bins)
+    assert p.early == q["early"] and len(p.octaves) == len(q["octaves"])
+    end = n_bins
+    for a, b in zip(p.octaves, q["octaves"]):
+        nb = b["basis"].shape[0]
+        rows = np.arange(max(end - nb, 0), end)
+        ref = (b["basis"][-len(rows):] if end < nb else b["basis"]) * q["scale"][rows][:, None]
+        assert a["n_fft"] == b["n_fft"] and a["hop"] == b["hop"] and a["row0"] == rows[0] and a["n"] == len(rows)
+        assert_allclose(a["basis"], ref, rtol=1e-12, atol=1e-15)
+        end -= nb
+    assert_array_equal(decimation_taps(), O.cqt_decimation_taps())
+    with pytest.raises(ValueError, match="Nyquist"):
+        CqtPlan(8000)
+    with pytest.raises(ValueError, match="multiple of 2"):
+        CqtPlan(48000, hop_length=48)

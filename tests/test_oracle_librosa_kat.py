@@ -180,3 +180,39 @@ def test_extract_features_names_and_shapes():
     with pytest.raises(ValueError, match="Unknown feature"):
         O.extract_features(y, 16000, ["nope"])
     assert O.extract_features(np.zeros(100), 16000, ["mfcc"], center=False)["time"].size == 0
+
+
+# ---- constant-Q transform (a15): restatement of librosa.cqt, parity unpinned (no soxr resampler) ----
+def test_cqt_structure_and_reference_style_checks():
+    sr = 22050
+    t = np.arange(2 * sr) / sr
+    y = np.sin(2 * np.pi * (100 * t + (5000 - 100) / (2 * 2) * t * t))       # chirp, reference tests/test_dsp.py:94-106
+    C = O.cqt(y, sr, n_bins=60, bins_per_octave=12)
+    assert C.shape == (60, 1 + len(y) // 512) and C.dtype == np.complex128
+    pk = np.abs(C).argmax(axis=0)[5:-5]
+    assert (np.diff(pk) >= 0).mean() > 0.97                                  # monotone peak bin for a rising chirp
+
+
+def test_cqt_closed_form_amplitude():
+    """A stationary sine at a bin's centre frequency: |C| = (A/2) * sqrt(filter length at the input rate)."""
+    sr = 48000
+    f = O.cqt_frequencies(84, O.note_c1_hz())
+    t = np.arange(2 * sr) / sr
+    for k in (33, 57, 80):
+        y = 0.5 * np.sin(2 * np.pi * f[k] * t)
+        C = np.abs(O.cqt(y, sr))
+        mid = C[:, 60:-60].mean(axis=1)
+        assert mid.argmax() == k
+        r = 2.0 ** (2.0 / 12); Q = (r + 1) / (r - 1)
+        assert abs(mid[k] - 0.25 * np.sqrt(Q * sr / f[k])) <= 0.02 * mid[k]
+
+
+def test_cqt_plan_schedule():
+    p = O.cqt_plan(48000)
+    assert p["early"] == 1 and [o["hop"] for o in p["octaves"]] == [256, 128, 64, 32, 16, 8, 4]
+    assert all(o["n_fft"] == 256 for o in p["octaves"])
+    with pytest.raises(ValueError, match="Nyquist"):
+        O.cqt_plan(8000)
+    with pytest.raises(ValueError, match="multiple of 2"):
+        O.cqt_plan(48000, hop_length=48)
+    assert abs(O.note_c1_hz() - 32.70319566257483) < 1e-12
