@@ -101,10 +101,17 @@ def main():
     from sygnals_amd import ops
     from sygnals_amd.distributed import gather_to_root
 
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a 1-GPU box: SYG_BENCH_SAME_GPU=1 puts every rank on cuda:0 and exchanges through gloo
+    # (RCCL refuses two ranks on one device); the real multi-GPU run uses one GPU per rank over RCCL
+    same_gpu = os.environ.get("SYG_BENCH_SAME_GPU") == "1"
+    dev_index = 0 if same_gpu else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     B = a.clips
     base = O.synth_clips(64, L, SR, seed=20250523 + rank)          # 64 distinct clips, tiled to the batch
@@ -114,7 +121,7 @@ def main():
     def step():
         out = ops.mfcc_batch(y, SR, N_FFT, HOP, N_MELS, N_MFCC)
         if world > 1:
-            out = gather_to_root(out, n_total, 0)
+            out = gather_to_root(out.cpu() if same_gpu else out, n_total, 0)
         return out
 
     def sync():
@@ -132,7 +139,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
