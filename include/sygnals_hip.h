@@ -49,7 +49,8 @@ const char* syg_last_error(void);
  *   plan_host  HOST int32[2 + 4*16]: {n_tiles, n_waves (8 or 16), tile[16], k0[16], nsteps[16], woff[16]}
  *   mel_out    [B, n_mels, T] float32 mel POWER spectrogram
  *   stats_out  optional [B, SYG_NSTAT, T] float32 per-frame spectral statistics
- *              (NULL to skip), rows in SYG_STAT_* order; replaces the per-frame loop
+ *              (NULL to skip), rows in SYG_STAT_* order; only the rows selected by stats_mask
+ *              (SYG_SM_* bits) are computed and written; replaces the per-frame loop
  *              manager.py:304-316 over frequency_domain.py:24-386
  *   contrast   optional: cplan_host HOST int32[1 + 3*SYG_MAX_BANDS] {n_rows, lo[], hi[], k[]}
  *              and contrast_out [B, 2, n_rows, T] (peak, valley means; NULL to skip);
@@ -67,11 +68,16 @@ const char* syg_last_error(void);
 #define SYG_STAT_POWER_SUM 6
 #define SYG_STAT_ROLLOFF_MARGIN 7
 #define SYG_MAX_BANDS 16
+#define SYG_SM_CENTROID 1   /* also MAG_SUM */
+#define SYG_SM_BANDWIDTH 2
+#define SYG_SM_FLATNESS 4
+#define SYG_SM_ROLLOFF 8    /* also POWER_SUM, ROLLOFF_MARGIN */
+#define SYG_SM_DOMINANT 16
 
 int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                          const float* window, const float* twiddle, const float* wpacked,
                          const int32_t* plan_host, int n_mels, float* mel_out,
-                         float sr, float roll_percent, float bw_p, float* stats_out,
+                         float sr, float roll_percent, float bw_p, int stats_mask, float* stats_out,
                          const int32_t* cplan_host, float* contrast_out, void* stream);
 
 /* Same front end, complex STFT output (librosa.stft as called by compute_stft,

@@ -77,7 +77,11 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     off = frame_length // 2 if center else 0
     res: Dict[str, Any] = {"time": ((np.arange(Tn) * hop_length + off) / float(sr)).astype(np.float64)}
 
-    want_stats = any(f in _SPECTRUM_BASED for f in features)
+    _bits = {"spectral_centroid": 1, "spectral_bandwidth": 2 | 1, "spectral_flatness": 4, "spectral_rolloff": 8,
+             "dominant_frequency": 16}
+    want_stats = 0
+    for f in features:
+        want_stats |= _bits.get(f, 0)
     want_contrast = "spectral_contrast" in features
     want_mfcc = "mfcc" in features
     mp = feature_params.get("mfcc", {})

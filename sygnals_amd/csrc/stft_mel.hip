@@ -257,55 +257,81 @@ __device__ __forceinline__ float wave_excl_scan(float v, int lane) {
   return s - v;
 }
 
+// smask bits: 1 centroid, 2 bandwidth, 4 flatness, 8 rolloff, 16 dominant (only the requested rows are
+// computed and written; MAG_SUM / POWER_SUM / margin ride along with centroid / rolloff)
 __device__ void row_stats(const float* __restrict__ prow, int lane, float binhz, float roll_percent, float bw_p,
-                          float* __restrict__ out, int64_t ostride) {
+                          int smask, float* __restrict__ out, int64_t ostride) {
   // lane owns the contiguous bins [17*lane, 17*lane+17) (64*17 = 1088 >= 1025)
   constexpr int CH = 17;
   const int b0 = lane * CH;
+  const float EPS = 2.220446049250313e-16f;
+  const bool want_mag = (smask & (1 | 2 | 4 | 16)) != 0;
+  float pl[CH];
   float msum = 0.f, fsum = 0.f, psum = 0.f, lsum = 0.f, mmax = -1.f;
   int amax = 0;
-  float pl[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int k = b0 + i;
     const float p = (k < NBIN) ? prow[ppos(k)] : 0.f;
     pl[i] = p;
-    const float m = sqrtf(p);
-    if (k < NBIN) {
+    psum += p;
+    if (want_mag && k < NBIN) {
+      const float m = sqrtf(p);
       msum += m;
       fsum = fmaf(m, (float)k, fsum);
-      psum += p;
-      lsum += logf(m + 2.220446049250313e-16f);
+      if (smask & 4) lsum += logf(m + EPS);
       if (m > mmax) { mmax = m; amax = k; }
     }
   }
-  const float tot_m = wave_sum(msum), tot_f = wave_sum(fsum), tot_p = wave_sum(psum), tot_l = wave_sum(lsum);
-  // argmax (first occurrence)
-  float gm = wave_max(mmax);
-  int cand = (mmax == gm) ? amax : 0x7fffffff;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-  const float EPS = 2.220446049250313e-16f;
-  const bool live = tot_m >= EPS;
-  const float cen_bin = live ? tot_f / tot_m : 0.f;
-  // bandwidth: (sum m |f - c|^p / sum m)^(1/p), in bins then scaled
-  float dsum = 0.f;
-#pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int k = b0 + i;
-    if (k < NBIN) {
-      const float d = fabsf((float)k - cen_bin) * binhz;
-      const float m = sqrtf(pl[i]);
-      dsum = fmaf(m, (bw_p == 2.f) ? d * d : powf(d, bw_p), dsum);
+  const float tot_p = wave_sum(psum);
+  float tot_m = 0.f, cen_bin = 0.f;
+  bool live = false;
+  if (want_mag) {
+    tot_m = wave_sum(msum);
+    live = tot_m >= EPS;
+    const float tot_f = wave_sum(fsum);
+    cen_bin = live ? tot_f / tot_m : 0.f;
+    if (lane == 0 && (smask & 1)) {
+      out[SYG_STAT_CENTROID * ostride] = cen_bin * binhz;
+      out[SYG_STAT_MAG_SUM * ostride] = tot_m;
     }
   }
-  const float tot_d = wave_sum(dsum);
-  // rolloff: first bin with cumsum(power) >= roll * total
-  const float excl = wave_excl_scan(psum, lane);
-  const float thr = roll_percent * tot_p;
-  int rb = 0x7fffffff;
-  float margin = 3.4e38f;
-  {
+  if (smask & 16) {   // argmax (first occurrence)
+    const float gm = wave_max(mmax);
+    int cand = (mmax == gm) ? amax : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if (lane == 0) out[SYG_STAT_DOMINANT_BIN * ostride] = (float)cand;
+  }
+  if (smask & 4) {
+    const float tot_l = wave_sum(lsum);
+    if (lane == 0) {
+      const float am = tot_m / (float)NBIN;
+      out[SYG_STAT_FLATNESS * ostride] = (am >= EPS) ? fminf(fmaxf(expf(tot_l / (float)NBIN) / am, 0.f), 1.f) : 0.f;
+    }
+  }
+  if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p)
+    float dsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int k = b0 + i;
+      if (k < NBIN) {
+        const float d = fabsf((float)k - cen_bin) * binhz;
+        dsum = fmaf(sqrtf(pl[i]), (bw_p == 2.f) ? d * d : powf(d, bw_p), dsum);
+      }
+    }
+    const float tot_d = wave_sum(dsum);
+    if (lane == 0) {
+      float bw = 0.f;
+      if (live) bw = (bw_p == 2.f) ? sqrtf(fmaxf(tot_d / tot_m, 0.f)) : powf(fmaxf(tot_d / tot_m, 0.f), 1.f / bw_p);
+      out[SYG_STAT_BANDWIDTH * ostride] = bw;
+    }
+  }
+  if (smask & 8) {    // rolloff: first bin with cumsum(power) >= roll * total
+    const float excl = wave_excl_scan(psum, lane);
+    const float thr = roll_percent * tot_p;
+    int rb = 0x7fffffff;
+    float margin = 3.4e38f;
     float c = excl;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -319,61 +345,91 @@ __device__ void row_stats(const float* __restrict__ prow, int lane, float binhz,
         }
       }
     }
-  }
-  int rbmin = rb;
+    int rbmin = rb;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) rbmin = min(rbmin, __shfl_xor(rbmin, o, 64));
-  float mg = (rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f;
+    for (int o = 32; o > 0; o >>= 1) rbmin = min(rbmin, __shfl_xor(rbmin, o, 64));
+    float mg = (rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mg = fminf(mg, __shfl_xor(mg, o, 64));
-  if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
-  if (lane == 0) {
-    const float am = tot_m / (float)NBIN;
-    float flat = 0.f;
-    if (am >= EPS) flat = fminf(fmaxf(expf(tot_l / (float)NBIN) / am, 0.f), 1.f);
-    float bw = 0.f;
-    if (live) bw = (bw_p == 2.f) ? sqrtf(fmaxf(tot_d / tot_m, 0.f)) : powf(fmaxf(tot_d / tot_m, 0.f), 1.f / bw_p);
-    out[SYG_STAT_CENTROID * ostride] = cen_bin * binhz;
-    out[SYG_STAT_BANDWIDTH * ostride] = bw;
-    out[SYG_STAT_FLATNESS * ostride] = flat;
-    out[SYG_STAT_ROLLOFF_BIN * ostride] = (float)rbmin;
-    out[SYG_STAT_DOMINANT_BIN * ostride] = (float)cand;
-    out[SYG_STAT_MAG_SUM * ostride] = tot_m;
-    out[SYG_STAT_POWER_SUM * ostride] = tot_p;
-    out[SYG_STAT_ROLLOFF_MARGIN * ostride] = (tot_p > 0.f) ? mg / tot_p : 0.f;
+    for (int o = 32; o > 0; o >>= 1) mg = fminf(mg, __shfl_xor(mg, o, 64));
+    if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
+    if (lane == 0) {
+      out[SYG_STAT_ROLLOFF_BIN * ostride] = (float)rbmin;
+      out[SYG_STAT_POWER_SUM * ostride] = tot_p;
+      out[SYG_STAT_ROLLOFF_MARGIN * ostride] = (tot_p > 0.f) ? mg / tot_p : 0.f;
+    }
   }
 }
 
-// mean of the k smallest and k largest magnitudes of bins [lo, hi) of one LDS power row.
-// Values are non-negative so their float bit patterns order like unsigned integers:
-// a 32-step bitwise radix select finds the k-th order statistic exactly, then the tail
-// sum is closed with the tie count (identical to sorting, as librosa does).
+// k-th order statistic of the powers of bins [lo, hi) by a 32-step radix select on the float bit patterns
+// (fallback for long bands / large k)
+__device__ uint32_t row_kth(const float* __restrict__ prow, int lane, int lo, int n, int kk, bool largest) {
+  uint32_t prefix = 0;
+  int remaining = kk;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t mask = ~((1u << bit) - 1u);
+    const uint32_t want = largest ? (prefix | (1u << bit)) : prefix;
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) cnt += ((__float_as_uint(prow[ppos(lo + i)]) & mask) == want) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (largest) {
+      if (cnt >= remaining) prefix |= (1u << bit); else remaining -= cnt;
+    } else {
+      if (cnt < remaining) { remaining -= cnt; prefix |= (1u << bit); }
+    }
+  }
+  return prefix;
+}
+
+// mean of the k smallest and k largest MAGNITUDES of bins [lo, hi) of one LDS power row (identical to sorting,
+// as librosa does: values are non-negative, selection on power == selection on magnitude).
+//   short bands / small k : the band sits in <= 12 registers per lane (bin lo + 64 r + lane in register r) and the
+//                           k extremes are extracted one by one (wave max / min, first owner removes its element);
+//   otherwise             : radix select of the k-th order statistic + tail sum closed with the tie count.
 __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, int hi, int k, float& peak,
                              float& valley) {
+  constexpr int RMAX = 12;
   const int n = hi - lo;
-  // ---- k-th smallest (1-based k) threshold on power bits
-  auto kth = [&](int kk, bool largest) -> uint32_t {
-    uint32_t prefix = 0;
-    int remaining = kk;
-    for (int bit = 31; bit >= 0; --bit) {
-      const uint32_t mask = ~((1u << bit) - 1u);        // bits above and including `bit`
-      const uint32_t want = largest ? (prefix | (1u << bit)) : prefix;
-      int cnt = 0;
-      for (int i = lane; i < n; i += 64) {
-        const uint32_t u = __float_as_uint(prow[ppos(lo + i)]);
-        cnt += ((u & mask) == want) ? 1 : 0;
-      }
+  if (n <= 64 * RMAX && k <= 16) {
+    float vals[RMAX];
+    float spk = 0.f, svl = 0.f;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-      if (largest) {
-        if (cnt >= remaining) prefix |= (1u << bit); else remaining -= cnt;
-      } else {
-        if (cnt >= remaining) { /* stay in the 0 branch */ } else { remaining -= cnt; prefix |= (1u << bit); }
+    for (int side = 0; side < 2; ++side) {       // 0: peak (largest), 1: valley (smallest)
+      const float sent = side == 0 ? -1.f : 3.4e38f;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        const int i = r * 64 + lane;
+        vals[r] = (i < n) ? prow[ppos(lo + i)] : sent;
+      }
+      for (int it = 0; it < k; ++it) {
+        float m = vals[0];
+#pragma unroll
+        for (int r = 1; r < RMAX; ++r) m = side == 0 ? fmaxf(m, vals[r]) : fminf(m, vals[r]);
+        float M = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float t = __shfl_xor(M, o, 64);
+          M = side == 0 ? fmaxf(M, t) : fminf(M, t);
+        }
+        const unsigned long long owners = __ballot(m == M);
+        const int first = __ffsll((long long)owners) - 1;
+        if (lane == first) {
+          bool done = false;
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) {
+            const bool hit = !done && vals[r] == M;
+            vals[r] = hit ? sent : vals[r];
+            done = done || hit;
+          }
+        }
+        if (side == 0) spk += sqrtf(M); else svl += sqrtf(M);
       }
     }
-    return prefix;
-  };
-  const uint32_t tlo = kth(k, false), thi = kth(k, true);
+    peak = spk / (float)k;
+    valley = svl / (float)k;
+    return;
+  }
+  const uint32_t tlo = row_kth(prow, lane, lo, n, k, false), thi = row_kth(prow, lane, lo, n, k, true);
   float slo = 0.f, shi = 0.f;
   int clo = 0, chi = 0;
   for (int i = lane; i < n; i += 64) {
@@ -397,7 +453,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int tiles_per_clip,
     int64_t total_tiles, int tiles_per_wg, const float2* __restrict__ win2, const float2* __restrict__ twid,
     const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
-    float roll_percent, float bw_p, float* __restrict__ stats_out, ContrastPlan cplan,
+    float roll_percent, float bw_p, int smask, float* __restrict__ stats_out, ContrastPlan cplan,
     float* __restrict__ contrast_out, float2* __restrict__ cout) {
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
@@ -532,7 +588,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     if (MODE == 1 && (stats_out != nullptr || contrast_out != nullptr)) {
       if (t < T) {
         if (stats_out != nullptr)
-          row_stats(prow, lane, binhz, roll_percent, bw_p, stats_out + (b * SYG_NSTAT) * T + t, T);
+          row_stats(prow, lane, binhz, roll_percent, bw_p, smask, stats_out + (b * SYG_NSTAT) * T + t, T);
         if (contrast_out != nullptr) {
           for (int r = 0; r < cplan.n_rows; ++r) {
             float pk, vl;
@@ -588,7 +644,8 @@ int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int
 template <int WAVES, int MODE>
 int launch(bool vec2, const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
            const float* window, const float* twiddle, const float* wpacked, const MelPlan& plan, int n_mels,
-           float* mel_out, float binhz, float roll_percent, float bw_p, float* stats_out, const ContrastPlan& cp,
+           float* mel_out, float binhz, float roll_percent, float bw_p, int smask, float* stats_out,
+           const ContrastPlan& cp,
            float* contrast_out, float* cout, hipStream_t st) {
   const int pad = center ? NFFT / 2 : 0;
   const int tiles = (int)((T + WAVES - 1) / WAVES);
@@ -608,7 +665,7 @@ int launch(bool vec2, const float* y, int64_t B, int64_t L, int64_t ldy, int hop
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes<WAVES>(), st, y, L, ldy, hop, pad, T,
                      tiles, total_tiles, per, (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels,
-                     mel_out, binhz, roll_percent, bw_p, stats_out, cp, contrast_out, (float2*)cout);
+                     mel_out, binhz, roll_percent, bw_p, smask, stats_out, cp, contrast_out, (float2*)cout);
   SYG_CHECK_LAUNCH("stft2048");
   return SYG_OK;
 }
@@ -621,7 +678,8 @@ using namespace syg;
 extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
                                     int64_t T, const float* window, const float* twiddle, const float* wpacked,
                                     const int32_t* plan_host, int n_mels, float* mel_out, float sr,
-                                    float roll_percent, float bw_p, float* stats_out, const int32_t* cplan_host,
+                                    float roll_percent, float bw_p, int stats_mask, float* stats_out,
+                                    const int32_t* cplan_host,
                                     float* contrast_out, void* stream) {
   SYG_REQUIRE(wpacked && plan_host && mel_out, "stft2048_mel: null pointer argument");
   const int waves = plan_host[1];
@@ -662,7 +720,8 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
                   "stft2048_mel: contrast band %d invalid (lo=%d hi=%d k=%d)", r, cp.lo[r], cp.hi[r], cp.k[r]);
     }
   }
-  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f,
+  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f &&
+                                 stats_mask > 0 && stats_mask < 32,
                              "stft2048_mel: invalid statistics parameters");
   const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
   const bool extra = (stats_out != nullptr) || (contrast_out != nullptr);
@@ -670,7 +729,7 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
   hipStream_t st = (hipStream_t)stream;
 #define SYG_LAUNCH(W, M)                                                                                        \
   launch<W, M>(vec2, y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out, binhz,      \
-               roll_percent, bw_p, stats_out, cp, contrast_out, nullptr, st)
+               roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr, st)
   if (waves == 8) return extra ? SYG_LAUNCH(8, 1) : SYG_LAUNCH(8, 0);
   return extra ? SYG_LAUNCH(16, 1) : SYG_LAUNCH(16, 0);
 #undef SYG_LAUNCH
@@ -687,6 +746,6 @@ extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_
   ContrastPlan cp;
   memset(&plan, 0, sizeof(plan));
   memset(&cp, 0, sizeof(cp));
-  return launch<8, 2>(vec2, y, B, L, ldy, hop, center, T, window, twiddle, nullptr, plan, 0, nullptr, 0.f, 0.f, 0.f,
+  return launch<8, 2>(vec2, y, B, L, ldy, hop, center, T, window, twiddle, nullptr, plan, 0, nullptr, 0.f, 0.f, 0.f, 0,
                       nullptr, cp, nullptr, out, (hipStream_t)stream);
 }

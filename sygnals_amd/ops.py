@@ -121,10 +121,12 @@ def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> MelConfig:
 
 def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
                  win_length: int = 2048, n_mels: int = 128, fmin: float = 0.0, fmax=None,
-                 want_stats: bool = False, roll_percent: float = 0.85, bw_p: float = 2.0,
+                 want_stats=False, roll_percent: float = 0.85, bw_p: float = 2.0,
                  contrast: Optional[np.ndarray] = None):
     """Fused STFT(2048) -> power -> mel.  Returns (mel [B, M, T], stats [B, 8, T] | None,
-    contrast_pv [B, 2, R, T] | None)."""
+    contrast_pv [B, 2, R, T] | None).  `want_stats`: False, True (all rows) or a bit mask (1 centroid,
+    2 bandwidth, 4 flatness, 8 rolloff, 16 dominant): only the selected rows are computed / written."""
+    smask = 31 if want_stats is True else int(want_stats or 0)
     require_gpu()
     if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
         raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
@@ -140,7 +142,7 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
     win = window_dev(window, win_length, 2048)
     tw = twiddle_dev(2048)
     mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
-    stats = torch.empty((B, 8, Tn), dtype=torch.float32, device=y.device) if want_stats else None
+    stats = torch.zeros((B, 8, Tn), dtype=torch.float32, device=y.device) if smask else None
     cpv = None
     cplan_p = None
     if contrast is not None:
@@ -150,7 +152,7 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
     rc = lib().syg_stft2048_mel_f32(
         _ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(cfg.wpacked),
         cfg.plan.ctypes.data_as(C.c_void_p), n_mels, _ptr(mel), float(sr), float(roll_percent), float(bw_p),
-        _ptr(stats), cplan_p, _ptr(cpv), C.c_void_p(_stream_ptr()))
+        smask, _ptr(stats), cplan_p, _ptr(cpv), C.c_void_p(_stream_ptr()))
     check(rc, "syg_stft2048_mel_f32")
     return mel, stats, cpv
 

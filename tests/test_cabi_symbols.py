@@ -37,7 +37,7 @@ def test_argument_errors_are_reported_without_device_work():
     from sygnals_amd import _lib
     h = _lib.lib()
     rc = h.syg_stft2048_mel_f32(None, 1, 48000, 48000, 512, 1, 94, None, None, None, None, 40, None, 48000.0, 0.85, 2.0,
-                                None, None, None, None)
+                                0, None, None, None, None)
     assert rc == -1 and b"null pointer" in h.syg_last_error()
     buf = (C.c_float * 16)()
     p = C.cast(buf, C.c_void_p)

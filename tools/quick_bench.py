@@ -7,12 +7,16 @@ from oracle import cpu_ref as O
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 Y = O.synth_clips(32, 48000, 48000, seed=1)
 y = ops.to_device_f32(np.tile(Y, (B // 32, 1)))
+from sygnals_amd import _tables as TT
+CPLAN = TT.contrast_plan(np.fft.rfftfreq(2048, 1/48000), 48000)
 for _ in range(3):
     ops.mfcc_batch(y, 48000, n_mels=40)
 torch.cuda.synchronize()
 for name, fn in (("mfcc", lambda: ops.mfcc_batch(y, 48000, n_mels=40)),
                  ("mel only", lambda: ops.stft2048_mel(y, 48000, n_mels=40)),
-                 ("mel+stats", lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=True))):
+                 ("mel+stats(all)", lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=True)),
+                 ("mel+centroid+rolloff", lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9)),
+                 ("C4: mel+cen+roll+contrast", lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CPLAN))):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
