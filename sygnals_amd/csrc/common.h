@@ -82,15 +82,71 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-wide (64-lane) reductions and scans on the DPP path.  hipcc lowers __shfl_xor to ds_bpermute_b32
+// (the LDS crossbar, >100 cycles per hop, six dependent hops per reduction); the DPP row operations below
+// cost a few cycles each: butterfly inside each row of 16 lanes (quad_perm, row_half_mirror, row_mirror),
+// then the four row results are combined through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+constexpr int DPP_QP_1032 = 0xB1, DPP_QP_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<DPP_QP_1032>(v);
+  v += dpp_f<DPP_QP_2301>(v);
+  v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_f<DPP_ROW_MIRROR>(v);
+  return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f<DPP_QP_1032>(v));
+  v = fmaxf(v, dpp_f<DPP_QP_2301>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+  return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ __forceinline__ float wave_min(float v) {
+  v = fminf(v, dpp_f<DPP_QP_1032>(v));
+  v = fminf(v, dpp_f<DPP_QP_2301>(v));
+  v = fminf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+  v = fminf(v, dpp_f<DPP_ROW_MIRROR>(v));
+  return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, dpp_i<DPP_QP_1032>(v));
+  v = min(v, dpp_i<DPP_QP_2301>(v));
+  v = min(v, dpp_i<DPP_ROW_HALF_MIRROR>(v));
+  v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+  v += dpp_i<DPP_QP_1032>(v);
+  v += dpp_i<DPP_QP_2301>(v);
+  v += dpp_i<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_i<DPP_ROW_MIRROR>(v);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+// exclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr with zero fill),
+// then the sums of the lower rows are added
+__device__ __forceinline__ float wave_excl_scan(float v, int lane) {
+  float s = v;
+  s += dpp_f<DPP_ROW_SHR1>(s);
+  s += dpp_f<DPP_ROW_SHR2>(s);
+  s += dpp_f<DPP_ROW_SHR4>(s);
+  s += dpp_f<DPP_ROW_SHR8>(s);
+  const float r0 = rl_f(s, 15), r1 = rl_f(s, 31), r2 = rl_f(s, 47);
+  const int row = lane >> 4;
+  const float off = (row >= 1 ? r0 : 0.f) + (row >= 2 ? r1 : 0.f) + (row >= 3 ? r2 : 0.f);
+  return s + off - v;
 }
 
 }  // namespace syg

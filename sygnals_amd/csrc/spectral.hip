@@ -13,16 +13,6 @@ namespace {
 
 constexpr float EPS64 = 2.220446049250313e-16f;
 
-__device__ __forceinline__ float wave_excl_scan(float v, int lane) {
-  float s = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    float t = __shfl_up(s, o, 64);
-    if (lane >= o) s += t;
-  }
-  return s - v;
-}
-
 __global__ __launch_bounds__(256) void spectral_stats_kernel(const float* __restrict__ mag, int64_t N, int F,
                                                              const float* __restrict__ freqs, float roll_percent,
                                                              float bw_p, float* __restrict__ out) {
@@ -44,9 +34,7 @@ __global__ __launch_bounds__(256) void spectral_stats_kernel(const float* __rest
   }
   const float tot_m = wave_sum(msum), tot_f = wave_sum(fsum), tot_p = wave_sum(psum), tot_l = wave_sum(lsum);
   const float gm = wave_max(mmax);
-  int cand = (mmax == gm && b0 < b1) ? amax : 0x7fffffff;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+  const int cand = wave_min_i((mmax == gm && b0 < b1) ? amax : 0x7fffffff);
   const bool live = tot_m >= EPS64;
   const float cen = live ? tot_f / tot_m : 0.f;
   float dsum = 0.f;
@@ -71,12 +59,8 @@ __global__ __launch_bounds__(256) void spectral_stats_kernel(const float* __rest
       }
     }
   }
-  int rbmin = rb;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) rbmin = min(rbmin, __shfl_xor(rbmin, o, 64));
-  float mg = (rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mg = fminf(mg, __shfl_xor(mg, o, 64));
+  int rbmin = wave_min_i(rb);
+  const float mg = wave_min((rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f);
   if (rbmin == 0x7fffffff || tot_p < EPS64) rbmin = F - 1;
   if (lane == 0) {
     const float am = tot_m / (float)F;
@@ -111,8 +95,7 @@ __device__ uint32_t kth_bits(const float* __restrict__ v, int n, int kk, bool la
     const uint32_t want = largest ? (prefix | (1u << bit)) : prefix;
     int cnt = 0;
     for (int i = lane; i < n; i += 64) cnt += ((__float_as_uint(fabsf(v[i])) & mask) == want) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    cnt = wave_sum_i(cnt);
     if (largest) {
       if (cnt >= remaining) prefix |= (1u << bit); else remaining -= cnt;
     } else {
@@ -146,8 +129,7 @@ __global__ __launch_bounds__(256) void contrast_pv_kernel(const float* __restric
       if (u > thi) { shi += x; ++chi; }
     }
     slo = wave_sum(slo); shi = wave_sum(shi);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { clo += __shfl_xor(clo, o, 64); chi += __shfl_xor(chi, o, 64); }
+    clo = wave_sum_i(clo); chi = wave_sum_i(chi);
     if (lane == 0) {
       out[((int64_t)0 * cp.n_rows + r) * N + row] = (shi + (float)(k - chi) * __uint_as_float(thi)) / (float)k;
       out[((int64_t)1 * cp.n_rows + r) * N + row] = (slo + (float)(k - clo) * __uint_as_float(tlo)) / (float)k;

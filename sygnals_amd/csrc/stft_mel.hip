@@ -247,19 +247,9 @@ __device__ __forceinline__ void load_frame(float2 (&v)[16], const float* __restr
 // ----------------------------------------------------------------------------------
 // per-row statistics from an LDS power row (one wave per row)
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_excl_scan(float v, int lane) {
-  float s = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    float t = __shfl_up(s, o, 64);
-    if (lane >= o) s += t;
-  }
-  return s - v;
-}
-
 // smask bits: 1 centroid, 2 bandwidth, 4 flatness, 8 rolloff, 16 dominant (only the requested rows are
 // computed and written; MAG_SUM / POWER_SUM / margin ride along with centroid / rolloff)
-__device__ void row_stats(const float* __restrict__ prow, int lane, float binhz, float roll_percent, float bw_p,
+__device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane, float binhz, float roll_percent, float bw_p,
                           int smask, float* __restrict__ out, int64_t ostride) {
   // lane owns the contiguous bins [17*lane, 17*lane+17) (64*17 = 1088 >= 1025)
   constexpr int CH = 17;
@@ -298,9 +288,7 @@ __device__ void row_stats(const float* __restrict__ prow, int lane, float binhz,
   }
   if (smask & 16) {   // argmax (first occurrence)
     const float gm = wave_max(mmax);
-    int cand = (mmax == gm) ? amax : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    const int cand = wave_min_i((mmax == gm) ? amax : 0x7fffffff);
     if (lane == 0) out[SYG_STAT_DOMINANT_BIN * ostride] = (float)cand;
   }
   if (smask & 4) {
@@ -345,12 +333,8 @@ __device__ void row_stats(const float* __restrict__ prow, int lane, float binhz,
         }
       }
     }
-    int rbmin = rb;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) rbmin = min(rbmin, __shfl_xor(rbmin, o, 64));
-    float mg = (rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mg = fminf(mg, __shfl_xor(mg, o, 64));
+    int rbmin = wave_min_i(rb);
+    const float mg = wave_min((rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f);
     if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
     if (lane == 0) {
       out[SYG_STAT_ROLLOFF_BIN * ostride] = (float)rbmin;
@@ -362,7 +346,7 @@ __device__ void row_stats(const float* __restrict__ prow, int lane, float binhz,
 
 // k-th order statistic of the powers of bins [lo, hi) by a 32-step radix select on the float bit patterns
 // (fallback for long bands / large k)
-__device__ uint32_t row_kth(const float* __restrict__ prow, int lane, int lo, int n, int kk, bool largest) {
+__device__ __noinline__ uint32_t row_kth(const float* __restrict__ prow, int lane, int lo, int n, int kk, bool largest) {
   uint32_t prefix = 0;
   int remaining = kk;
   for (int bit = 31; bit >= 0; --bit) {
@@ -370,8 +354,7 @@ __device__ uint32_t row_kth(const float* __restrict__ prow, int lane, int lo, in
     const uint32_t want = largest ? (prefix | (1u << bit)) : prefix;
     int cnt = 0;
     for (int i = lane; i < n; i += 64) cnt += ((__float_as_uint(prow[ppos(lo + i)]) & mask) == want) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    cnt = wave_sum_i(cnt);
     if (largest) {
       if (cnt >= remaining) prefix |= (1u << bit); else remaining -= cnt;
     } else {
@@ -386,7 +369,7 @@ __device__ uint32_t row_kth(const float* __restrict__ prow, int lane, int lo, in
 //   short bands / small k : the band sits in <= 12 registers per lane (bin lo + 64 r + lane in register r) and the
 //                           k extremes are extracted one by one (wave max / min, first owner removes its element);
 //   otherwise             : radix select of the k-th order statistic + tail sum closed with the tie count.
-__device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, int hi, int k, float& peak,
+__device__ __noinline__ void row_contrast(const float* __restrict__ prow, int lane, int lo, int hi, int k, float& peak,
                              float& valley) {
   constexpr int RMAX = 12;
   const int n = hi - lo;
@@ -405,12 +388,7 @@ __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, i
         float m = vals[0];
 #pragma unroll
         for (int r = 1; r < RMAX; ++r) m = side == 0 ? fmaxf(m, vals[r]) : fminf(m, vals[r]);
-        float M = m;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float t = __shfl_xor(M, o, 64);
-          M = side == 0 ? fmaxf(M, t) : fminf(M, t);
-        }
+        const float M = side == 0 ? wave_max(m) : wave_min(m);
         const unsigned long long owners = __ballot(m == M);
         const int first = __ffsll((long long)owners) - 1;
         if (lane == first) {
@@ -440,8 +418,7 @@ __device__ void row_contrast(const float* __restrict__ prow, int lane, int lo, i
     if (u > thi) { shi += m; ++chi; }
   }
   slo = wave_sum(slo); shi = wave_sum(shi);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { clo += __shfl_xor(clo, o, 64); chi += __shfl_xor(chi, o, 64); }
+  clo = wave_sum_i(clo); chi = wave_sum_i(chi);
   valley = (slo + (float)(k - clo) * sqrtf(__uint_as_float(tlo))) / (float)k;
   peak = (shi + (float)(k - chi) * sqrtf(__uint_as_float(thi))) / (float)k;
 }
