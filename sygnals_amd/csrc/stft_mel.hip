@@ -247,31 +247,41 @@ __device__ __forceinline__ void load_frame(float2 (&v)[16], const float* __restr
 // ----------------------------------------------------------------------------------
 // per-row statistics from an LDS power row (one wave per row)
 // ----------------------------------------------------------------------------------
+// Hardware transcendental forms (v_sqrt / v_log / v_exp / v_rcp_f32, <= 1 ulp): the IEEE-exact library
+// versions expand to 15-200 instructions each, and 17 inlined copies overflow the instruction cache.
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }  // ln
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float fpow(float x, float p) {    // x >= 0
+  return (x > 0.f) ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : 0.f;
+}
+
 // smask bits: 1 centroid, 2 bandwidth, 4 flatness, 8 rolloff, 16 dominant (only the requested rows are
 // computed and written; MAG_SUM / POWER_SUM / margin ride along with centroid / rolloff)
-__device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane, float binhz, float roll_percent, float bw_p,
-                          int smask, float* __restrict__ out, int64_t ostride) {
+__device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane, float binhz, float roll_percent,
+                                       float bw_p, int smask, float* __restrict__ out, int64_t ostride) {
   // lane owns the contiguous bins [17*lane, 17*lane+17) (64*17 = 1088 >= 1025)
   constexpr int CH = 17;
   const int b0 = lane * CH;
   const float EPS = 2.220446049250313e-16f;
   const bool want_mag = (smask & (1 | 2 | 4 | 16)) != 0;
+  const bool want_log = (smask & 4) != 0;
   float pl[CH];
   float msum = 0.f, fsum = 0.f, psum = 0.f, lsum = 0.f, mmax = -1.f;
   int amax = 0;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int k = b0 + i;
-    const float p = (k < NBIN) ? prow[ppos(k)] : 0.f;
+    const bool in = k < NBIN;
+    const float p = in ? prow[ppos(k)] : 0.f;
     pl[i] = p;
     psum += p;
-    if (want_mag && k < NBIN) {
-      const float m = sqrtf(p);
-      msum += m;
-      fsum = fmaf(m, (float)k, fsum);
-      if (smask & 4) lsum += logf(m + EPS);
-      if (m > mmax) { mmax = m; amax = k; }
-    }
+    const float m = fsqrt(p);
+    msum += m;
+    fsum = fmaf(m, (float)k, fsum);
+    if (want_log && in) lsum += flog(m + EPS);
+    if (in && m > mmax) { mmax = m; amax = k; }
   }
   const float tot_p = wave_sum(psum);
   float tot_m = 0.f, cen_bin = 0.f;
@@ -280,7 +290,7 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
     tot_m = wave_sum(msum);
     live = tot_m >= EPS;
     const float tot_f = wave_sum(fsum);
-    cen_bin = live ? tot_f / tot_m : 0.f;
+    cen_bin = live ? tot_f * frcp(tot_m) : 0.f;
     if (lane == 0 && (smask & 1)) {
       out[SYG_STAT_CENTROID * ostride] = cen_bin * binhz;
       out[SYG_STAT_MAG_SUM * ostride] = tot_m;
@@ -291,28 +301,28 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
     const int cand = wave_min_i((mmax == gm) ? amax : 0x7fffffff);
     if (lane == 0) out[SYG_STAT_DOMINANT_BIN * ostride] = (float)cand;
   }
-  if (smask & 4) {
+  if (want_log) {
     const float tot_l = wave_sum(lsum);
     if (lane == 0) {
-      const float am = tot_m / (float)NBIN;
-      out[SYG_STAT_FLATNESS * ostride] = (am >= EPS) ? fminf(fmaxf(expf(tot_l / (float)NBIN) / am, 0.f), 1.f) : 0.f;
+      const float am = tot_m * (1.f / (float)NBIN);
+      out[SYG_STAT_FLATNESS * ostride] =
+          (am >= EPS) ? fminf(fmaxf(fexp(tot_l * (1.f / (float)NBIN)) * frcp(am), 0.f), 1.f) : 0.f;
     }
   }
   if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p)
+    const int pmode = (bw_p == 2.f) ? 2 : (bw_p == 1.f) ? 1 : 0;
     float dsum = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int k = b0 + i;
-      if (k < NBIN) {
-        const float d = fabsf((float)k - cen_bin) * binhz;
-        dsum = fmaf(sqrtf(pl[i]), (bw_p == 2.f) ? d * d : powf(d, bw_p), dsum);
-      }
+      const float d = fabsf((float)k - cen_bin) * binhz;
+      const float dp = pmode == 2 ? d * d : pmode == 1 ? d : fpow(d, bw_p);
+      dsum = fmaf(fsqrt(pl[i]), dp, dsum);          // bins >= NBIN hold p = 0
     }
     const float tot_d = wave_sum(dsum);
     if (lane == 0) {
-      float bw = 0.f;
-      if (live) bw = (bw_p == 2.f) ? sqrtf(fmaxf(tot_d / tot_m, 0.f)) : powf(fmaxf(tot_d / tot_m, 0.f), 1.f / bw_p);
-      out[SYG_STAT_BANDWIDTH * ostride] = bw;
+      const float r = live ? fmaxf(tot_d * frcp(tot_m), 0.f) : 0.f;
+      out[SYG_STAT_BANDWIDTH * ostride] = pmode == 2 ? fsqrt(r) : pmode == 1 ? r : fpow(r, frcp(bw_p));
     }
   }
   if (smask & 8) {    // rolloff: first bin with cumsum(power) >= roll * total
@@ -324,13 +334,11 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int k = b0 + i;
-      if (k < NBIN) {
-        const float cprev = c;
-        c += pl[i];
-        if (c >= thr && rb == 0x7fffffff) {
-          rb = k;
-          margin = fminf(c - thr, (k > 0) ? thr - cprev : 3.4e38f);
-        }
+      const float cprev = c;
+      c += pl[i];
+      if (k < NBIN && c >= thr && rb == 0x7fffffff) {
+        rb = k;
+        margin = fminf(c - thr, (k > 0) ? thr - cprev : 3.4e38f);
       }
     }
     int rbmin = wave_min_i(rb);
@@ -339,7 +347,7 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
     if (lane == 0) {
       out[SYG_STAT_ROLLOFF_BIN * ostride] = (float)rbmin;
       out[SYG_STAT_POWER_SUM * ostride] = tot_p;
-      out[SYG_STAT_ROLLOFF_MARGIN * ostride] = (tot_p > 0.f) ? mg / tot_p : 0.f;
+      out[SYG_STAT_ROLLOFF_MARGIN * ostride] = (tot_p > 0.f) ? mg * frcp(tot_p) : 0.f;
     }
   }
 }
@@ -400,11 +408,12 @@ __device__ __noinline__ void row_contrast(const float* __restrict__ prow, int la
             done = done || hit;
           }
         }
-        if (side == 0) spk += sqrtf(M); else svl += sqrtf(M);
+        if (side == 0) spk += fsqrt(M); else svl += fsqrt(M);
       }
     }
-    peak = spk / (float)k;
-    valley = svl / (float)k;
+    const float rk = frcp((float)k);
+    peak = spk * rk;
+    valley = svl * rk;
     return;
   }
   const uint32_t tlo = row_kth(prow, lane, lo, n, k, false), thi = row_kth(prow, lane, lo, n, k, true);
