@@ -25,6 +25,22 @@
 #ifndef SYG_ABL
 #define SYG_ABL 0   // development ablations (tools/ablate.sh); 0 = product build
 #endif
+#if SYG_ABL == 9
+// timeline mode: per-wave cycle accumulators per phase, dumped into stats_out (tools/timeline.py)
+#define TICK(slot, reg)                                                                                         \
+  do {                                                                                                          \
+    unsigned long long _t;                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t), "+v"(reg)::"memory"); \
+    tacc[slot] += _t - tprev;                                                                                   \
+    tprev = _t;                                                                                                 \
+  } while (0)
+#define TARGS , unsigned long long (&tacc)[12], unsigned long long& tprev
+#define TPASS , tacc, tprev
+#else
+#define TICK(slot, reg)
+#define TARGS
+#define TPASS
+#endif
 
 namespace syg {
 namespace {
@@ -103,7 +119,7 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
 // k = 0, 256, 128, 384); lane 0 also returns X[512].
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
                                              const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
-                                             int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512) {
+                                             int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512 TARGS) {
   const int cl = lane >> 2, bp = lane & 3;
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
   dft16(v);
@@ -118,6 +134,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   // b = 32h..32h+31 (those 32 lanes store their 16 values, y[c][b] at c*32 + ((b & 31) ^ 4(c & 7))); every
   // lane then reads the 8 operands y[lane>>2][4a + b'], a = 8h..8h+7, that live in this half -- the reads
   // are not divergent and land in fixed registers
+  TICK(1, v[1].x);
   float2 t[16];
   {
     const int wcol = lane & 31;
@@ -140,6 +157,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
     }
 #endif
   }
+  TICK(2, t[0].x);
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
   dft16(t);
   {
@@ -154,6 +172,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   }
   // ---- exchange 2 in two half-rounds (c' < 8, then c' >= 8); every unit's primary group has c' < 8 and its
   // mirror c' >= 8, so round 0 delivers all primaries and round 1 all mirrors.  Pass 3 = radix-4 over b'.
+  TICK(3, t[1].x);
   float2 G[2][4], H[2][4];
   {
     const int wbase = bp * PL2;
@@ -179,6 +198,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
     }
 #endif
   }
+  TICK(4, G[0][0].x);
   // ---- real split on mirror pairs
   x512 = make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
 #pragma unroll
@@ -215,32 +235,65 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   }
 }
 
-// Windowed samples of one frame: element n = 64a + lane of the packed complex frame covers samples
-// s0 + 2n, s0 + 2n + 1; samples outside [0, L) are the zero padding of center=True.
-template <bool VEC2>
-__device__ __forceinline__ void load_frame(float2 (&v)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
-                                           const float2* __restrict__ win2, int lane) {
+// Raw samples of one frame: element n = 64a + lane of the packed complex frame covers samples s0 + 2n,
+// s0 + 2n + 1; samples outside [0, L) are the zero padding of center=True.  The loads are only issued here;
+// the analysis window (LDS copy) is applied by apply_window() when the frame is consumed.
+//   LOAD 0 / 1: straight from global memory (scalar / 8-byte loads)
+//   LOAD 2    : from the tile's staged sample run in LDS (filled by LDS-DMA, stage_tile())
+template <int LOAD>
+__device__ __forceinline__ void fetch_frame(float2 (&v)[16], const float* __restrict__ yb, int64_t L, int64_t s0,
+                                            const float* __restrict__ stage_frame, int lane) {
+  if (LOAD == 2) {
+    const float2* sf = reinterpret_cast<const float2*>(stage_frame);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v[a] = sf[64 * a + lane];
+    return;
+  }
   const bool interior = (s0 >= 0) && (s0 + NFFT <= L);
   if (interior) {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
       const int n = 64 * a + lane;
-      float2 x;
-      if (VEC2) x = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
-      else x = make_float2(yb[s0 + 2 * n], yb[s0 + 2 * n + 1]);
-      const float2 wv = win2[n];
-      v[a] = make_float2(x.x * wv.x, x.y * wv.y);
+      if (LOAD == 1) v[a] = *reinterpret_cast<const float2*>(yb + s0 + 2 * n);
+      else v[a] = make_float2(yb[s0 + 2 * n], yb[s0 + 2 * n + 1]);
     }
   } else {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-      const int n = 64 * a + lane;
-      const int64_t s = s0 + 2 * n;
-      const float x0 = (s >= 0 && s < L) ? yb[s] : 0.f;
-      const float x1v = (s + 1 >= 0 && s + 1 < L) ? yb[s + 1] : 0.f;
-      const float2 wv = win2[n];
-      v[a] = make_float2(x0 * wv.x, x1v * wv.y);
+      const int64_t s = s0 + 2 * (64 * a + lane);
+      v[a].x = (s >= 0 && s < L) ? yb[s] : 0.f;
+      v[a].y = (s + 1 >= 0 && s + 1 < L) ? yb[s + 1] : 0.f;
     }
+  }
+}
+
+__device__ __forceinline__ void apply_window(float2 (&v)[16], const float2* __restrict__ winl, int lane) {
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    const float2 wv = winl[64 * a + lane];
+    v[a] = make_float2(v[a].x * wv.x, v[a].y * wv.y);
+  }
+}
+
+// LDS-DMA of the sample run [s_begin, s_begin + 256 n_chunks) of one clip into the stage buffer: the buffer
+// descriptor's range check returns zeros for samples before the clip (negative offsets wrap to huge unsigned
+// ones) and past its end -- exactly the zero padding of center=True.  wide: 16 B per lane (needs 16-byte
+// aligned runs), else 4 B per lane.
+template <int WAVES>
+__device__ __forceinline__ void stage_tile(const float* yb, int clip_bytes, float* stage, int s_begin, int span,
+                                           bool wide, int w, int lane) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(yb), 0, clip_bytes, 0x00020000);
+  if (wide) {
+    const int n = (span + 255) >> 8;
+    for (int c = w; c < n; c += WAVES)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(stage + c * 256), 16, (s_begin + c * 256 + lane * 4) * 4,
+                                               0, 0, 0);
+  } else {
+    const int n = (span + 63) >> 6;
+    for (int c = w; c < n; c += WAVES)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(stage + c * 64), 4, (s_begin + c * 64 + lane) * 4, 0, 0,
+                                               0);
   }
 }
 
@@ -434,46 +487,91 @@ __device__ __noinline__ void row_contrast(const float* __restrict__ prow, int la
 
 // ----------------------------------------------------------------------------------
 // MODE 0: mel only   MODE 1: mel + per-frame statistics / contrast   MODE 2: complex STFT output
-template <int WAVES, bool VEC2, int MODE>
+// LOAD 0 / 1: frames read straight from global memory   LOAD 2: tiles staged in LDS by LDS-DMA (hop <= 512)
+//
+// LDS map (floats):  Pbuf [TILE_T][P_STRIDE] + 16   power rows; a wave's exchange scratch aliases ITS OWN row
+//                                                   (the row is only written after the last scratch read, and
+//                                                   nobody reads rows while an FFT phase is running)
+//                    slab [WAVES][16][TILE_T]       per-wave partial mel tiles
+//                    tw2l, tw1l                     twiddle tables        cpl: contrast plan
+//                    winl [2048]                    analysis window
+//                    stage [(WAVES-1)*512 + 2048]   the tile's contiguous sample run (LOAD 2)
+// Per tile: FFT(v) -> rows | barrier A | MFMA -> slab ; fetch the next frame into v | barrier B |
+//           start the DMA of the tile after next ; reduce + store [; statistics | barrier].
+// The DMA therefore runs behind the reduce and the whole next FFT phase, and is drained at barrier A.
+template <int WAVES>
+struct Lds {
+  static constexpr int TILE_T = WAVES;
+  static constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
+  static constexpr int SLAB_FLOATS = WAVES * 16 * TILE_T;
+  static constexpr int CPL_FLOATS = 3 * SYG_MAX_BANDS;
+  static constexpr int STAGE_FLOATS = (WAVES - 1) * 512 + NFFT;
+  static constexpr int O_SLAB = P_FLOATS;
+  static constexpr int O_TW2 = O_SLAB + SLAB_FLOATS;
+  static constexpr int O_TW1 = O_TW2 + TW2_FLOATS;
+  static constexpr int O_CPL = O_TW1 + TW1_FLOATS;
+  static constexpr int O_WIN = O_CPL + CPL_FLOATS;
+  static constexpr int O_STAGE = O_WIN + NFFT;
+  static constexpr int TOTAL = O_STAGE + STAGE_FLOATS;
+  static_assert(SC_COMPLEX * 2 <= P_STRIDE, "exchange scratch must fit inside a power row");
+  static_assert(O_TW2 % 4 == 0 && O_WIN % 4 == 0 && O_STAGE % 4 == 0, "16-byte aligned LDS sections");
+};
+
+template <int WAVES, int LOAD, int MODE>
 __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int tiles_per_clip,
     int64_t total_tiles, int tiles_per_wg, const float2* __restrict__ win2, const float2* __restrict__ twid,
     const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
     float roll_percent, float bw_p, int smask, float* __restrict__ stats_out, ContrastPlan cplan,
-    float* __restrict__ contrast_out, float2* __restrict__ cout) {
+    float* __restrict__ contrast_out, float2* __restrict__ cout, int dma_wide) {
+  typedef Lds<WAVES> LM;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
-  constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
-  constexpr int SLAB_FLOATS = WAVES * 16 * TILE_T;
   constexpr bool COMPLEX_OUT = (MODE == 2);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float2* scratch = reinterpret_cast<float2*>(lds);                 // [WAVES][528] complex
-  float* Pbuf = lds + WAVES * SC_COMPLEX * 2;                       // [TILE_T][P_STRIDE] (+16)
-  float* slab = Pbuf + P_FLOATS;                                    // [WAVES][16][TILE_T]
-  float2* tw2l = reinterpret_cast<float2*>(slab + SLAB_FLOATS);     // [4][18] complex
-  float2* tw1l = tw2l + TW2_FLOATS / 2;                             // [15][64] complex
-  int* cpl = reinterpret_cast<int*>(slab + SLAB_FLOATS + TW2_FLOATS + TW1_FLOATS);  // contrast plan
+  float* Pbuf = lds;
+  float* slab = lds + LM::O_SLAB;
+  float2* tw2l = reinterpret_cast<float2*>(lds + LM::O_TW2);        // [4][18] complex
+  float2* tw1l = reinterpret_cast<float2*>(lds + LM::O_TW1);        // [15][64] complex
+  int* cpl = reinterpret_cast<int*>(lds + LM::O_CPL);
+  float2* winl = reinterpret_cast<float2*>(lds + LM::O_WIN);
+  float* stage = lds + LM::O_STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps frame addressing on the scalar unit
 
   // persistent workgroup: a contiguous chunk of tiles (consecutive tiles of a clip share part of their
-  // samples, so the re-reads of the frame overlap stay in this CU's L1 / this XCD's L2)
+  // samples, so the re-reads of the frame overlap stay in this XCD's L2)
   const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
   const int64_t tile_end = (tile_begin + tiles_per_wg < total_tiles) ? tile_begin + tiles_per_wg : total_tiles;
   if (tile_begin >= tile_end) return;
 
+  // tile -> (clip, first frame); total_tiles < 2^31 (checked on the host)
+  auto clip_of = [&](int64_t tile) { return (uint32_t)tile / (uint32_t)tiles_per_clip; };
+  auto t0_of = [&](int64_t tile, uint32_t cq) {
+    return (int64_t)((uint32_t)tile - cq * (uint32_t)tiles_per_clip) * TILE_T;
+  };
+  const int span = (TILE_T - 1) * hop + NFFT;              // samples a tile touches
+  auto dma = [&](int64_t tile) {
+    const uint32_t cq = clip_of(tile);
+    stage_tile<WAVES>(y + (int64_t)cq * ldy, (int)(L * 4), stage, (int)(t0_of(tile, cq) * hop) - pad, span,
+                      dma_wide != 0, w, lane);
+  };
+  if (LOAD == 2) dma(tile_begin);
+
   LaneConst lc;
   init_lane_const(lc, lane, twid);
-  float2* sc = scratch + w * SC_COMPLEX;
+  float* prow = Pbuf + w * P_STRIDE;
+  float2* sc = reinterpret_cast<float2*>(prow);
   if (tid < 64) tw2l[(tid >> 4) * TW2_STRIDE + (tid & 15)] = twid[32 * (tid >> 4) * (tid & 15)];
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
+  for (int i = tid; i < NFFT / 2; i += NTHREADS) winl[i] = win2[i];
 
   int ns = 0, woff = 0, k0 = 0;
   if (!COMPLEX_OUT) {
     // pad words of the skewed rows, the row tails and the slack are read against zero weights: they must
     // hold finite values, so the whole buffer (and the slab behind it) is cleared once
-    for (int i = tid; i < P_FLOATS + SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
+    for (int i = tid; i < LM::P_FLOATS + LM::SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
 #pragma unroll
     for (int r = 0; r < SYG_MAX_BANDS; ++r)
       if (tid == r) { cpl[r] = cplan.lo[r]; cpl[SYG_MAX_BANDS + r] = cplan.hi[r]; cpl[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
@@ -481,30 +579,52 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     for (int ww = 0; ww < WAVES; ++ww)
       if (w == ww) { ns = plan.nsteps[ww]; woff = plan.woff[ww]; k0 = plan.k0[ww]; }
   }
+  if (LOAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // staged mode: the frame of the NEXT tile is fetched (LDS -> registers) one phase ahead, so that the stage
+  // buffer can be refilled behind the FFT phase; direct modes load at the top of the tile loop
+  float2 v[16];
+  bool have = false;
+  auto fetch = [&](int64_t tile) {
+    const uint32_t cq = clip_of(tile);
+    const int64_t t = t0_of(tile, cq) + w;
+    have = t < T;
+    int lf = lane;                    // laundered like lv below: no hoisted per-lane addresses
+    asm volatile("" : "+v"(lf));
+    if (have) fetch_frame<LOAD>(v, y + (int64_t)cq * ldy, L, t * (int64_t)hop - pad, stage + w * hop, lf);
+  };
+  if (LOAD == 2) {
+    fetch(tile_begin);
+    __syncthreads();                                  // every wave holds its frame: the stage may be refilled
+    if (tile_begin + 1 < tile_end) dma(tile_begin + 1);
+  }
+
+#if SYG_ABL == 9
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
 #pragma unroll 1
   for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
-    const uint32_t cq = (uint32_t)tile / (uint32_t)tiles_per_clip;      // total_tiles < 2^31 (checked on the host)
+    const uint32_t cq = clip_of(tile);
     const int64_t b = cq;
-    const int64_t t0 = (int64_t)((uint32_t)tile - cq * (uint32_t)tiles_per_clip) * TILE_T;
+    const int64_t t0 = t0_of(tile, cq);
     const int64_t t = t0 + w;
-    float* prow = Pbuf + w * P_STRIDE;
-    if (t < T) {
+    if (LOAD != 2) fetch(tile);
+    if (have) {
       // the lane id is laundered through an empty asm each iteration: the LDS / global addresses derived
       // from it are then recomputed per frame (a few integer ops) instead of being hoisted out of the tile
       // loop as ~100 loop-invariant registers that would spill
       int lv = lane;
       asm volatile("" : "+v"(lv));
-      float2 v[16];
 #if SYG_ABL == 1
 #pragma unroll
       for (int a = 0; a < 16; ++a) v[a] = make_float2((float)(lv + a) * 1e-3f, (float)(lv - a) * 1e-3f);
-#else
-      load_frame<VEC2>(v, y + b * ldy, L, t * (int64_t)hop - pad, win2, lv);
 #endif
+      apply_window(v, winl, lv);
+      TICK(0, v[0].x);
       float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512);
+      wave_rfft2048(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512 TPASS);
       if (COMPLEX_OUT) {
         float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll
@@ -532,7 +652,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
     }
     if (COMPLEX_OUT) continue;
-    __syncthreads();
+#if SYG_ABL == 9
+    int tdep = lane;
+    TICK(5, tdep);
+#endif
+    if (LOAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's samples have landed
+    __syncthreads();                                                   // barrier A: rows complete
+    TICK(6, tdep);
 
     // ---- phase 2: block-sparse mel projection on the matrix cores
     {
@@ -558,20 +684,44 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) sl[(4 * g + r) * TILE_T + f] = acc[r];
       }
+      TICK(7, acc[0]);
     }
-    __syncthreads();
-    for (int i = tid; i < plan.n_tiles * 16 * TILE_T; i += NTHREADS) {
-      const int mt = i / (16 * TILE_T), m = (i / TILE_T) & 15, tt = i & (TILE_T - 1);
-      float sum = 0.f;
+    // ---- staged mode: the next tile's frame (LDS -> registers); once every wave holds its frame (barrier B)
+    // the stage is refilled with the tile after next.  With statistics the fetch waits until after them
+    // (the registers are needed there) and the refill starts behind the closing barrier instead.
+    constexpr bool FETCH_EARLY = (LOAD == 2) && (MODE == 0);
+    if (FETCH_EARLY) {
+      have = false;
+      if (tile + 1 < tile_end) fetch(tile + 1);
+    }
+    __syncthreads();                // barrier B: slab complete (and every wave has read its staged frame)
+    TICK(8, tdep);
+    if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
+
+    // ---- reduce the per-wave partial tiles in a fixed order; a wave handles 64 consecutive outputs of one
+    // mel tile, so the segment test is wave-uniform
+    {
+      constexpr int WPT = TILE_T / 4;             // waves per 16 x TILE_T mel tile
+      for (int e = w; e < plan.n_tiles * WPT; e += WAVES) {
+        const int mt = e / WPT;
+        const int idx = (e - mt * WPT) * 64 + lane;
+        const int m = idx / TILE_T, tt = idx & (TILE_T - 1);
+        float sum = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < WAVES; ++ww)
-        if (plan.tile[ww] == mt) sum += slab[ww * (16 * TILE_T) + m * TILE_T + tt];
-      const int mel = mt * 16 + m;
-      if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+        for (int ww = 0; ww < WAVES; ++ww)
+          if (plan.tile[ww] == mt) sum += slab[ww * (16 * TILE_T) + idx];
+        const int mel = mt * 16 + m;
+        if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+      }
     }
 
+    TICK(9, tdep);
+#if SYG_ABL == 9
+    if (false) {
+#else
     // ---- phase 2b: per-frame statistics / contrast means from the same LDS rows
     if (MODE == 1 && (stats_out != nullptr || contrast_out != nullptr)) {
+#endif
       if (t < T) {
         if (stats_out != nullptr)
           row_stats(prow, lane, binhz, roll_percent, bw_p, smask, stats_out + (b * SYG_NSTAT) * T + t, T);
@@ -586,15 +736,29 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           }
         }
       }
+      if (LOAD == 2) {
+        have = false;
+        if (tile + 1 < tile_end) fetch(tile + 1);
+      }
       __syncthreads();   // the rows are overwritten by the next tile's FFT phase
+      if (LOAD == 2 && tile + 2 < tile_end) dma(tile + 2);
+    } else if (LOAD == 2 && MODE == 1) {
+      // (MODE 1 launched without statistics outputs does not happen; keep the pipeline correct anyway)
+      have = false;
+      if (tile + 1 < tile_end) fetch(tile + 1);
+      __syncthreads();
+      if (tile + 2 < tile_end) dma(tile + 2);
     }
   }
+#if SYG_ABL == 9
+  if (MODE == 1 && lane < 12)
+    stats_out[((int64_t)blockIdx.x * WAVES + w) * 16 + lane] = (float)tacc[lane] / (float)(tile_end - tile_begin);
+#endif
 }
 
 template <int WAVES>
 constexpr size_t lds_bytes() {
-  return (size_t)(WAVES * SC_COMPLEX * 2 + WAVES * P_STRIDE + 16 + WAVES * 16 * WAVES + TW2_FLOATS + TW1_FLOATS +
-                  3 * SYG_MAX_BANDS) * sizeof(float);
+  return (size_t)Lds<WAVES>::TOTAL * sizeof(float);
 }
 
 // Workgroups per CU: two of 8 waves or one of 16; each takes a contiguous chunk of tiles.
@@ -614,6 +778,16 @@ void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
   wgs = (int)((total_tiles + p - 1) / p);
 }
 
+// SYGNALS_AMD_LOAD = 0 | 1 | 2 forces the frame load path (development aid); default: staged tiles
+int load_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SYGNALS_AMD_LOAD");
+    mode = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
+  }
+  return mode;
+}
+
 int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                  const float* window, const float* twiddle, int waves) {
   SYG_REQUIRE(y && window && twiddle, "stft2048: null pointer argument");
@@ -628,7 +802,7 @@ int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int
 }
 
 template <int WAVES, int MODE>
-int launch(bool vec2, const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
            const float* window, const float* twiddle, const float* wpacked, const MelPlan& plan, int n_mels,
            float* mel_out, float binhz, float roll_percent, float bw_p, int smask, float* stats_out,
            const ContrastPlan& cp,
@@ -638,20 +812,27 @@ int launch(bool vec2, const float* y, int64_t B, int64_t L, int64_t ldy, int hop
   const int64_t total_tiles = B * tiles;
   int wgs = 0, per = 0;
   persistent_grid(total_tiles, WAVES, wgs, per);
-  auto kern = vec2 ? stft2048_kernel<WAVES, true, MODE> : stft2048_kernel<WAVES, false, MODE>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[vec2]) {
+  // staged tiles (LDS-DMA) need the tile's sample run to fit the stage buffer and 32-bit byte offsets
+  const bool can_stage = (MODE != 2) && hop <= 512 && L < ((int64_t)1 << 28);
+  if (load == 2 && !can_stage) load = 1;
+  const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
+  if (load == 1 && !vec2) load = 0;
+  const int dma_wide = (hop % 4 == 0) && (pad % 4 == 0) && (ldy % 4 == 0) && (L % 4 == 0) && (((uintptr_t)y) % 16 == 0);
+  auto kern = load == 2 ? stft2048_kernel<WAVES, 2, MODE>
+                        : load == 1 ? stft2048_kernel<WAVES, 1, MODE> : stft2048_kernel<WAVES, 0, MODE>;
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[load]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes<WAVES>());
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", lds_bytes<WAVES>(), hipGetErrorString(e));
       return SYG_E_LAUNCH;
     }
-    attr_set[vec2] = true;
+    attr_set[load] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes<WAVES>(), st, y, L, ldy, hop, pad, T,
                      tiles, total_tiles, per, (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels,
-                     mel_out, binhz, roll_percent, bw_p, smask, stats_out, cp, contrast_out, (float2*)cout);
+                     mel_out, binhz, roll_percent, bw_p, smask, stats_out, cp, contrast_out, (float2*)cout, dma_wide);
   SYG_CHECK_LAUNCH("stft2048");
   return SYG_OK;
 }
@@ -709,12 +890,12 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
   if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f &&
                                  stats_mask > 0 && stats_mask < 32,
                              "stft2048_mel: invalid statistics parameters");
-  const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
   const bool extra = (stats_out != nullptr) || (contrast_out != nullptr);
+  const int load = load_mode();
   const float binhz = sr / (float)NFFT;
   hipStream_t st = (hipStream_t)stream;
 #define SYG_LAUNCH(W, M)                                                                                        \
-  launch<W, M>(vec2, y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out, binhz,      \
+  launch<W, M>(load, y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out, binhz,      \
                roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr, st)
   if (waves == 8) return extra ? SYG_LAUNCH(8, 1) : SYG_LAUNCH(8, 0);
   return extra ? SYG_LAUNCH(16, 1) : SYG_LAUNCH(16, 0);
@@ -727,11 +908,10 @@ extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_
   int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 8);
   if (rc) return rc;
   SYG_REQUIRE(out, "stft2048_c2c: null output");
-  const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
   MelPlan plan;
   ContrastPlan cp;
   memset(&plan, 0, sizeof(plan));
   memset(&cp, 0, sizeof(cp));
-  return launch<8, 2>(vec2, y, B, L, ldy, hop, center, T, window, twiddle, nullptr, plan, 0, nullptr, 0.f, 0.f, 0.f, 0,
+  return launch<8, 2>(1, y, B, L, ldy, hop, center, T, window, twiddle, nullptr, plan, 0, nullptr, 0.f, 0.f, 0.f, 0,
                       nullptr, cp, nullptr, out, (hipStream_t)stream);
 }

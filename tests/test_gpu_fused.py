@@ -75,7 +75,8 @@ def test_mfcc_degenerate_clips(ops):
 
 
 @pytest.mark.parametrize("L,hop,center", [(100, 512, True), (2048, 512, False), (5000, 160, True),
-                                          (4999, 441, True), (48000, 512, False), (3000, 1, False)])
+                                          (4999, 441, True), (48000, 512, False), (3000, 1, False),
+                                          (48000, 1024, True), (8001, 700, True), (22050, 256, True)])
 def test_ragged_lengths_and_hops(ops, L, hop, center):
     rng = np.random.default_rng(L + hop)
     Y = rng.normal(0, 0.2, (3, L)).astype(np.float32)
