@@ -45,7 +45,9 @@ const char* syg_last_error(void);
  *   y          [B, L] float32, row stride ldy            (clips)
  *   window     [2048] float32  periodic analysis window (already centre-padded)
  *   twiddle    [2048] complex  W_2048^k = exp(-2*pi*i*k/2048)
- *   wpacked    packed block-sparse mel weights, [group of 4 k-steps][lane][4] (see sygnals_amd/_tables.py)
+ *   wpacked    packed block-sparse mel weights, [group of 4 k-steps][lane][4] (see sygnals_amd/_tables.py);
+ *              the table must end with >= 20 all-zero rows (5 groups) after the last segment: every wave
+ *              pre-loads 5 groups from its woff unconditionally
  *   plan_host  HOST int32[2 + 4*16]: {n_tiles, n_waves (8 or 16), tile[16], k0[16], nsteps[16], woff[16]}
  *   mel_out    [B, n_mels, T] float32 mel POWER spectrogram
  *   stats_out  optional [B, SYG_NSTAT, T] float32 per-frame spectral statistics

@@ -124,7 +124,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
                 blocks.append(blk.reshape(n4 // 4, 4, 64).transpose(0, 2, 1).reshape(n4, 64))
                 off += n4
             w += 1
-    blocks.append(np.zeros((16, 64), np.float32))
+    blocks.append(np.zeros((32, 64), np.float32))      # tail: the kernel pre-loads 5 groups unconditionally
     wpacked = np.concatenate(blocks, axis=0)
     plan = np.concatenate([[nt, waves], tile, k0, ns, woff]).astype(np.int32)
     return np.ascontiguousarray(wpacked), plan

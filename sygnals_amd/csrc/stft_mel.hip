@@ -621,7 +621,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #pragma unroll
       for (int a = 0; a < 16; ++a) v[a] = make_float2((float)(lv + a) * 1e-3f, (float)(lv - a) * 1e-3f);
 #endif
+#if SYG_ABL == 5
+      apply_window(v, win2, lv);
+#else
       apply_window(v, winl, lv);
+#endif
       TICK(0, v[0].x);
       float2 xs[2][4], xm[2][4], x512;
       wave_rfft2048(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512 TPASS);
@@ -656,24 +660,43 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     int tdep = lane;
     TICK(5, tdep);
 #endif
-    if (LOAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's samples have landed
-    __syncthreads();                                                   // barrier A: rows complete
+    // The filterbank operands of this wave's segment are the same for every tile but cannot stay resident
+    // (the FFT phase needs all 128 VGPRs): the first NPRE groups are re-fetched here, where the registers are
+    // free again, so that their L2 latency overlaps the wait at barrier A.
+    constexpr int NPRE = 5;            // unconditional: the packed table ends with NPRE groups of zero rows
+    int la = lane;                     // laundered: keeps the (tile-invariant) loads inside the loop, and
+    asm volatile("" : "+v"(la)::"memory");   // behind the row stores (the FFT results are dead by now)
+    const int f = la & 15, g = la >> 4;
+    const float4* wp4 = reinterpret_cast<const float4*>(wpacked) + (int64_t)(woff >> 2) * 64 + la;
+    const int ng = ns >> 2;
+    float4 apre[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) apre[q] = wp4[q * 64];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (staged mode: the next tile's samples have landed too)
+    __syncthreads();                                    // barrier A: rows complete
     TICK(6, tdep);
 
     // ---- phase 2: block-sparse mel projection on the matrix cores
     {
-      const int f = lane & 15, g = lane >> 4;
       // k0 is a multiple of 16, so ppos(k0 + 4i) = ppos(k0) + 4i + (i >> 2): one base register and
       // compile-time offsets.  The A operands are packed four steps per lane (one 16-byte load feeds
       // four MFMAs); the step count of a segment is a multiple of 4 (zero-weight padding).
       const float* pq = Pbuf + (f & (TILE_T - 1)) * P_STRIDE + g + ppos(k0);
-      const float4* wp4 = reinterpret_cast<const float4*>(wpacked) + (int64_t)(woff >> 2) * 64 + lane;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
-      const int ng = ns >> 2;
-#pragma unroll 4
-      for (int q = 0; q < ng; ++q) {
+#pragma unroll
+      for (int q = 0; q < NPRE; ++q) {
+        if (q < ng) {
+          const float* pb = pq + 17 * q;          // 16 bins + 1 pad word per group of four steps
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].x, pb[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].y, pb[4], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].z, pb[8], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].w, pb[12], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll 2
+      for (int q = NPRE; q < ng; ++q) {
         const float4 a4 = wp4[q * 64];
-        const float* pb = pq + 17 * q;          // 16 bins + 1 pad word per group of four steps
+        const float* pb = pq + 17 * q;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, pb[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, pb[4], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, pb[8], acc, 0, 0, 0);
