@@ -310,36 +310,43 @@ __device__ __forceinline__ float fpow(float x, float p) {    // x >= 0
   return (x > 0.f) ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : 0.f;
 }
 
+// The row functions stay out of line (inlined, their registers would spill the FFT loop).  Their pointers
+// carry the address space: a generic pointer would turn every row read into a flat_load.
+typedef const __attribute__((address_space(3))) float* lds_row;
+typedef __attribute__((address_space(1))) float* gptr;
+
 // smask bits: 1 centroid, 2 bandwidth, 4 flatness, 8 rolloff, 16 dominant (only the requested rows are
 // computed and written; MAG_SUM / POWER_SUM / margin ride along with centroid / rolloff)
-__device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane, float binhz, float roll_percent,
-                                       float bw_p, int smask, float* __restrict__ out, int64_t ostride) {
-  // lane owns the contiguous bins [17*lane, 17*lane+17) (64*17 = 1088 >= 1025)
+__device__ __noinline__ void row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask,
+                                       gptr out, int ostride) {
+  // lane owns the 16 contiguous bins [16 lane, 16 lane + 16) -- 16 consecutive words at 17 lane of the skewed
+  // row: immediate offsets, no bank conflicts -- and lane 63 also the Nyquist bin 1024 (lanes < 63: p = 0, with
+  // k = 1024 all the same).  Every pass re-reads its powers from LDS (the lane offset is laundered so that the
+  // loads are not merged into one register array): the function then stays inside the caller-saved registers
+  // -- an out-of-line function that needs more must save and restore the rest through scratch on every call.
   constexpr int CH = 17;
-  const int b0 = lane * CH;
+  const int b0 = lane * 16;
   const float EPS = 2.220446049250313e-16f;
-  const bool want_mag = (smask & (1 | 2 | 4 | 16)) != 0;
-  const bool want_log = (smask & 4) != 0;
-  float pl[CH];
-  float msum = 0.f, fsum = 0.f, psum = 0.f, lsum = 0.f, mmax = -1.f;
-  int amax = 0;
-#pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int k = b0 + i;
-    const bool in = k < NBIN;
-    const float p = in ? prow[ppos(k)] : 0.f;
-    pl[i] = p;
-    psum += p;
-    const float m = fsqrt(p);
-    msum += m;
-    fsum = fmaf(m, (float)k, fsum);
-    if (want_log && in) lsum += flog(m + EPS);
-    if (in && m > mmax) { mmax = m; amax = k; }
+#define SYG_ROW_PASS(body)                                                        \
+  {                                                                               \
+    int lb = lane;                                                                \
+    asm volatile("" : "+v"(lb));                                                  \
+    lds_row pr = prow + 17 * lb;                                                  \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                              \
+      const int k = (i < 16) ? b0 + i : NBIN - 1;                                 \
+      const bool in = (i < 16) || lb == 63;                                       \
+      const float p = (i < 16) ? pr[i] : (lb == 63 ? prow[ppos(NBIN - 1)] : 0.f); \
+      body                                                                        \
+    }                                                                             \
   }
+  float psum = 0.f;
+  SYG_ROW_PASS(psum += p;)
   const float tot_p = wave_sum(psum);
   float tot_m = 0.f, cen_bin = 0.f;
   bool live = false;
-  if (want_mag) {
+  if (smask & (1 | 2 | 4)) {        // magnitude sums
+    float msum = 0.f, fsum = 0.f;
+    SYG_ROW_PASS(const float m = fsqrt(p); msum += m; fsum = fmaf(m, (float)k, fsum);)
     tot_m = wave_sum(msum);
     live = tot_m >= EPS;
     const float tot_f = wave_sum(fsum);
@@ -349,12 +356,17 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
       out[SYG_STAT_MAG_SUM * ostride] = tot_m;
     }
   }
-  if (smask & 16) {   // argmax (first occurrence)
-    const float gm = wave_max(mmax);
-    const int cand = wave_min_i((mmax == gm) ? amax : 0x7fffffff);
+  if (smask & 16) {   // argmax of the magnitude == argmax of the power (first occurrence)
+    float pmax = -1.f;
+    int amax = 0;
+    SYG_ROW_PASS(const bool up = in && p > pmax; pmax = up ? p : pmax; amax = up ? k : amax;)
+    const float gm = wave_max(pmax);
+    const int cand = wave_min_i((pmax == gm) ? amax : 0x7fffffff);
     if (lane == 0) out[SYG_STAT_DOMINANT_BIN * ostride] = (float)cand;
   }
-  if (want_log) {
+  if (smask & 4) {    // flatness: exp(mean log(m + eps)) / mean(m)
+    float lsum = 0.f;
+    SYG_ROW_PASS(const float lg = flog(fsqrt(p) + EPS); lsum += in ? lg : 0.f;)
     const float tot_l = wave_sum(lsum);
     if (lane == 0) {
       const float am = tot_m * (1.f / (float)NBIN);
@@ -362,15 +374,14 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
           (am >= EPS) ? fminf(fmaxf(fexp(tot_l * (1.f / (float)NBIN)) * frcp(am), 0.f), 1.f) : 0.f;
     }
   }
-  if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p)
+  if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p);  bins >= NBIN hold p = 0
     const int pmode = (bw_p == 2.f) ? 2 : (bw_p == 1.f) ? 1 : 0;
     float dsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int k = b0 + i;
-      const float d = fabsf((float)k - cen_bin) * binhz;
-      const float dp = pmode == 2 ? d * d : pmode == 1 ? d : fpow(d, bw_p);
-      dsum = fmaf(fsqrt(pl[i]), dp, dsum);          // bins >= NBIN hold p = 0
+    if (pmode == 2) {
+      SYG_ROW_PASS(const float d = ((float)k - cen_bin) * binhz; dsum = fmaf(fsqrt(p), d * d, dsum);)
+    } else {
+      SYG_ROW_PASS(const float d = fabsf((float)k - cen_bin) * binhz;
+                   dsum = fmaf(fsqrt(p), pmode == 1 ? d : fpow(d, bw_p), dsum);)
     }
     const float tot_d = wave_sum(dsum);
     if (lane == 0) {
@@ -379,21 +390,13 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
     }
   }
   if (smask & 8) {    // rolloff: first bin with cumsum(power) >= roll * total
-    const float excl = wave_excl_scan(psum, lane);
     const float thr = roll_percent * tot_p;
     int rb = 0x7fffffff;
     float margin = 3.4e38f;
-    float c = excl;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int k = b0 + i;
-      const float cprev = c;
-      c += pl[i];
-      if (k < NBIN && c >= thr && rb == 0x7fffffff) {
-        rb = k;
-        margin = fminf(c - thr, (k > 0) ? thr - cprev : 3.4e38f);
-      }
-    }
+    float c = wave_excl_scan(psum, lane);
+    SYG_ROW_PASS(const float cprev = c; c += p; const bool hit = in && (c >= thr) && (rb == 0x7fffffff);
+                 rb = hit ? k : rb;
+                 margin = hit ? fminf(c - thr, (k > 0) ? thr - cprev : 3.4e38f) : margin;)
     int rbmin = wave_min_i(rb);
     const float mg = wave_min((rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f);
     if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
@@ -403,11 +406,12 @@ __device__ __noinline__ void row_stats(const float* __restrict__ prow, int lane,
       out[SYG_STAT_ROLLOFF_MARGIN * ostride] = (tot_p > 0.f) ? mg * frcp(tot_p) : 0.f;
     }
   }
+#undef SYG_ROW_PASS
 }
 
-// k-th order statistic of the powers of bins [lo, hi) by a 32-step radix select on the float bit patterns
+// k-th order statistic of the powers of bins [lo, lo + n) by a 32-step radix select on the float bit patterns
 // (fallback for long bands / large k)
-__device__ __noinline__ uint32_t row_kth(const float* __restrict__ prow, int lane, int lo, int n, int kk, bool largest) {
+__device__ __noinline__ uint32_t row_kth(lds_row prow, int lane, int lo, int n, int kk, bool largest) {
   uint32_t prefix = 0;
   int remaining = kk;
   for (int bit = 31; bit >= 0; --bit) {
@@ -425,49 +429,56 @@ __device__ __noinline__ uint32_t row_kth(const float* __restrict__ prow, int lan
   return prefix;
 }
 
+// The band sits in R registers per lane (bin lo + 64 r + lane in register r); the k largest and k smallest are
+// extracted one by one, both tails interleaved: wave max / min, the first owning lane retires its element.
+template <int R>
+__device__ __forceinline__ void contrast_extract(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
+  float hi[R], lw[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = r * 64 + lane;
+    const float p = prow[ppos(lo + (i < n ? i : 0))];
+    hi[r] = (i < n) ? p : -1.f;
+    lw[r] = (i < n) ? p : 3.4e38f;
+  }
+  spk = 0.f; svl = 0.f;
+  for (int it = 0; it < k; ++it) {
+    float mh = hi[0], ml = lw[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) { mh = fmaxf(mh, hi[r]); ml = fminf(ml, lw[r]); }
+    const float MH = wave_max(mh), ML = wave_min(ml);
+    const int fh = __ffsll((long long)__ballot(mh == MH)) - 1, fl = __ffsll((long long)__ballot(ml == ML)) - 1;
+    bool doneh = lane != fh, donel = lane != fl;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool hh = !doneh && hi[r] == MH;
+      hi[r] = hh ? -1.f : hi[r];
+      doneh = doneh || hh;
+      const bool hl = !donel && lw[r] == ML;
+      lw[r] = hl ? 3.4e38f : lw[r];
+      donel = donel || hl;
+    }
+    spk += fsqrt(MH);
+    svl += fsqrt(ML);
+  }
+}
+
 // mean of the k smallest and k largest MAGNITUDES of bins [lo, hi) of one LDS power row (identical to sorting,
 // as librosa does: values are non-negative, selection on power == selection on magnitude).
-//   short bands / small k : the band sits in <= 12 registers per lane (bin lo + 64 r + lane in register r) and the
-//                           k extremes are extracted one by one (wave max / min, first owner removes its element);
-//   otherwise             : radix select of the k-th order statistic + tail sum closed with the tie count.
-__device__ __noinline__ void row_contrast(const float* __restrict__ prow, int lane, int lo, int hi, int k, float& peak,
-                             float& valley) {
-  constexpr int RMAX = 12;
+//   bands of <= 768 bins with k <= 16 : register extraction, specialised by registers per lane;
+//   otherwise                         : radix select of the k-th order statistic + tail sum closed with the
+//                                       tie count.
+__device__ __noinline__ float2 row_contrast(lds_row prow, int lane, int lo, int hi, int k) {   // (peak, valley)
   const int n = hi - lo;
-  if (n <= 64 * RMAX && k <= 16) {
-    float vals[RMAX];
-    float spk = 0.f, svl = 0.f;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {       // 0: peak (largest), 1: valley (smallest)
-      const float sent = side == 0 ? -1.f : 3.4e38f;
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        const int i = r * 64 + lane;
-        vals[r] = (i < n) ? prow[ppos(lo + i)] : sent;
-      }
-      for (int it = 0; it < k; ++it) {
-        float m = vals[0];
-#pragma unroll
-        for (int r = 1; r < RMAX; ++r) m = side == 0 ? fmaxf(m, vals[r]) : fminf(m, vals[r]);
-        const float M = side == 0 ? wave_max(m) : wave_min(m);
-        const unsigned long long owners = __ballot(m == M);
-        const int first = __ffsll((long long)owners) - 1;
-        if (lane == first) {
-          bool done = false;
-#pragma unroll
-          for (int r = 0; r < RMAX; ++r) {
-            const bool hit = !done && vals[r] == M;
-            vals[r] = hit ? sent : vals[r];
-            done = done || hit;
-          }
-        }
-        if (side == 0) spk += fsqrt(M); else svl += fsqrt(M);
-      }
-    }
+  if (n <= 768 && k <= 16) {
+    float spk, svl;
+    if (n <= 64) contrast_extract<1>(prow, lane, lo, n, k, spk, svl);
+    else if (n <= 128) contrast_extract<2>(prow, lane, lo, n, k, spk, svl);
+    else if (n <= 256) contrast_extract<4>(prow, lane, lo, n, k, spk, svl);
+    else if (n <= 448) contrast_extract<7>(prow, lane, lo, n, k, spk, svl);
+    else contrast_extract<12>(prow, lane, lo, n, k, spk, svl);
     const float rk = frcp((float)k);
-    peak = spk * rk;
-    valley = svl * rk;
-    return;
+    return make_float2(spk * rk, svl * rk);
   }
   const uint32_t tlo = row_kth(prow, lane, lo, n, k, false), thi = row_kth(prow, lane, lo, n, k, true);
   float slo = 0.f, shi = 0.f;
@@ -481,8 +492,8 @@ __device__ __noinline__ void row_contrast(const float* __restrict__ prow, int la
   }
   slo = wave_sum(slo); shi = wave_sum(shi);
   clo = wave_sum_i(clo); chi = wave_sum_i(chi);
-  valley = (slo + (float)(k - clo) * sqrtf(__uint_as_float(tlo))) / (float)k;
-  peak = (shi + (float)(k - chi) * sqrtf(__uint_as_float(thi))) / (float)k;
+  return make_float2((shi + (float)(k - chi) * sqrtf(__uint_as_float(thi))) / (float)k,
+                     (slo + (float)(k - clo) * sqrtf(__uint_as_float(tlo))) / (float)k);
 }
 
 // ----------------------------------------------------------------------------------
@@ -747,14 +758,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
       if (t < T) {
         if (stats_out != nullptr)
-          row_stats(prow, lane, binhz, roll_percent, bw_p, smask, stats_out + (b * SYG_NSTAT) * T + t, T);
+          row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask,
+                    (gptr)(stats_out + (b * SYG_NSTAT) * T + t), (int)T);
         if (contrast_out != nullptr) {
           for (int r = 0; r < cplan.n_rows; ++r) {
-            float pk, vl;
-            row_contrast(prow, lane, cpl[r], cpl[SYG_MAX_BANDS + r], cpl[2 * SYG_MAX_BANDS + r], pk, vl);
+            const float2 pv = row_contrast((lds_row)prow, lane, cpl[r], cpl[SYG_MAX_BANDS + r], cpl[2 * SYG_MAX_BANDS + r]);
             if (lane == 0) {
-              contrast_out[((b * 2 + 0) * cplan.n_rows + r) * T + t] = pk;
-              contrast_out[((b * 2 + 1) * cplan.n_rows + r) * T + t] = vl;
+              contrast_out[((b * 2 + 0) * cplan.n_rows + r) * T + t] = pv.x;
+              contrast_out[((b * 2 + 1) * cplan.n_rows + r) * T + t] = pv.y;
             }
           }
         }
@@ -911,7 +922,7 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
     }
   }
   if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f &&
-                                 stats_mask > 0 && stats_mask < 32,
+                                 stats_mask > 0 && stats_mask < 32 && T < ((int64_t)1 << 27),
                              "stft2048_mel: invalid statistics parameters");
   const bool extra = (stats_out != nullptr) || (contrast_out != nullptr);
   const int load = load_mode();
