@@ -168,7 +168,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "stft2048_kernel<16,true,0>", "kernel_avg_us": round(kdur * 1e6, 2),
+                "kernel": "stft2048_kernel<16,2,0> (16 waves, staged tiles, mel only)", "kernel_avg_us": round(kdur * 1e6, 2),
                 "algorithmic_bytes_per_launch": kbytes}
 
     if rank == 0:
