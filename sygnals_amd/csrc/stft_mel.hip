@@ -25,6 +25,13 @@
 #ifndef SYG_ABL
 #define SYG_ABL 0   // development ablations (tools/ablate.sh); 0 = product build
 #endif
+// Issue priority falls as a wave advances through its frame: the SIMD's arbiter otherwise favours the oldest
+// wave, which then idles at barrier A while the youngest finishes alone with nothing to hide its LDS latency.
+#ifndef SYG_NOPRIO
+#define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define SETPRIO(n)
+#endif
 #if SYG_ABL == 9
 // timeline mode: per-wave cycle accumulators per phase, dumped into stats_out (tools/timeline.py)
 #define TICK(slot, reg)                                                                                         \
@@ -159,6 +166,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   }
   TICK(2, t[0].x);
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
+  SETPRIO(2);
   dft16(t);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
@@ -199,6 +207,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
 #endif
   }
   TICK(4, G[0][0].x);
+  SETPRIO(1);
   // ---- real split on mirror pairs
   x512 = make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
 #pragma unroll
@@ -622,6 +631,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const int64_t t0 = t0_of(tile, cq);
     const int64_t t = t0 + w;
     if (LOAD != 2) fetch(tile);
+    SETPRIO(3);
     if (have) {
       // the lane id is laundered through an empty asm each iteration: the LDS / global addresses derived
       // from it are then recomputed per frame (a few integer ops) instead of being hoisted out of the tile
@@ -666,6 +676,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     } else if (!COMPLEX_OUT) {
       for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
     }
+    SETPRIO(0);
     if (COMPLEX_OUT) continue;
 #if SYG_ABL == 9
     int tdep = lane;
