@@ -88,6 +88,26 @@ int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int 
                          const float* window, const float* twiddle, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Whole MFCC chain in one launch (the headline path): librosa.stft -> |.|^2 -> mel filterbank ->
+ * power_to_db(ref=np.max, top_db) -> DCT-II rows (+ lifter), i.e. manager.py:184-187, 198, 219-223 and
+ * cepstral.py:106-115.  A workgroup owns whole clips; the clip's [n_mels, T] mel matrix stays in LDS, so
+ * only the samples are read from and the MFCCs written to HBM.
+ *   y .. n_mels   as syg_stft2048_mel_f32 (the plan must be a 16-wave plan)
+ *   dct        [n_mfcc, n_mels] DCT matrix rows;  lifter: optional [n_mfcc] (NULL = none)
+ *   amin, top_db (< 0: no clamp), ref_is_max (1: per-clip max, 0: ref_value): as syg_logmel_dct_f32
+ *   mel_out    optional [B, n_mels, T] copy of the mel POWER (NULL = not stored)
+ *   mfcc_out   [B, n_mfcc, T]
+ * Fails (SYG_E_ARG) when n_mels * 16*ceil(T/16) floats do not fit the ~21 KiB of LDS left beside the
+ * transform buffers (e.g. n_mels=40: T <= 128 frames); callers then use the two-launch form
+ * syg_stft2048_mel_f32 + syg_logmel_dct_f32.
+ * ------------------------------------------------------------------------------- */
+int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
+                          int64_t T, const float* window, const float* twiddle, const float* wpacked,
+                          const int32_t* plan_host, int n_mels, const float* dct, int n_mfcc,
+                          const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
+                          float* mel_out, float* mfcc_out, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at
  * manager.py:223 and librosa.feature.mfcc(S=..) at cepstral.py:106-115.
  *   mel        [B, M, T] mel power; converted to dB IN PLACE unless logmel_out given

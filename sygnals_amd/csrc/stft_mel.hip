@@ -80,6 +80,18 @@ struct ContrastPlan {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// MODE 3 (clip-resident MFCC): the mel tiles of a clip stay in LDS; after the clip's last tile the workgroup
+// converts them to dB (per-clip max reference, top_db floor) and applies the DCT -- only MFCCs reach HBM.
+struct MfccArgs {
+  const float* dct;      // [n_mfcc, n_mels]
+  const float* lifter;   // [n_mfcc] or null
+  float* out;            // [B, n_mfcc, T]
+  int n_mfcc;
+  int ref_is_max;        // 1: reference = max of the clip's mel powers, 0: ref_value
+  float ref_value, amin, top_db;   // top_db < 0: no floor
+  int tp;                // padded frames per clip (tiles_per_clip * TILE_T): row stride of the LDS mel matrix
+};
+
 // exchange 2 (half buffer by c' & 7, planar in b'): slot of group (c, c') inside a plane
 __device__ __forceinline__ int x2g(int c, int cp) { return (cp & 7) * 16 + ((c + 4 * ((cp & 7) >> 1)) & 15); }
 // position of bin k inside an LDS power row: one pad word every 16 bins turns the stride-16 bin pattern
@@ -505,6 +517,91 @@ __device__ __noinline__ float2 row_contrast(lds_row prow, int lane, int lo, int 
                      (slo + (float)(k - clo) * sqrtf(__uint_as_float(tlo))) / (float)k);
 }
 
+// Arguments of an out-of-line device function travel in VGPRs; these put the wave-uniform ones back into
+// SGPRs so that the callee's loops and addresses stay scalar.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+template <typename P>
+__device__ __forceinline__ P* uni(P* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (P*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ MfccArgs uni(const MfccArgs& a) {
+  MfccArgs u;
+  u.dct = uni(a.dct); u.lifter = uni(a.lifter); u.out = uni(a.out); u.n_mfcc = uni(a.n_mfcc);
+  u.ref_is_max = uni(a.ref_is_max); u.ref_value = uni(a.ref_value); u.amin = uni(a.amin); u.top_db = uni(a.top_db);
+  u.tp = uni(a.tp);
+  return u;
+}
+
+// MODE 3 clip epilogue (a workgroup's chunk is whole clips): power_to_db + DCT-II (+ lifter) from the LDS mel
+// matrix -- librosa.power_to_db(S, ref=np.max) (manager.py:223) -> scipy.fft.dct rows (cepstral.py:106-115).
+// LDS behind the mel matrix: red[WAVES] (per-wave maxima of the clip's mel powers, written at the clip's last
+// reduce), then the DCT rows [n_mfcc][n_mels] and the lifter [n_mfcc] (copied once at kernel start).
+// The waves that own a 16 x 16 output tile run this in the NEXT tile's projection phase: barrier A of that tile
+// orders it behind the last reduce of the clip, barrier B ahead of the next reduce that overwrites the matrix.
+// The powers are converted to dB on the fly with the hardware log2: dB = 10 log10(2) (log2 x - log2 ref)
+// (v_log_f32, 1 ulp: ~6e-6 dB at -100 dB; inputs are >= amin, never denormal; exactly 0 when x == ref).
+// Out of line (inlined, its scalars push the tile loop's SGPRs into spills); uni() re-scalarises the arguments.
+typedef __attribute__((address_space(3))) float* lds_fptr;     // (a generic pointer would make every access a flat_*)
+template <int WAVES>
+__device__ __noinline__ void clip_dct(int clipmel_addr, MfccArgs mfv, int n_mels_v, int T_v, int b_v, int w_v, int lane) {
+  const MfccArgs mf = uni(mfv);
+  const int n_mels = uni(n_mels_v), T = uni(T_v), w = uni(w_v);
+  const int64_t b = uni(b_v);
+  lds_fptr clipmel = (lds_fptr)(uintptr_t)(uint32_t)uni(clipmel_addr);
+  lds_fptr red = clipmel + n_mels * mf.tp;
+  lds_fptr dctl = red + WAVES;
+  lds_fptr lifl = dctl + mf.n_mfcc * n_mels;
+  // clip maximum: one LDS read per lane (the WAVES per-wave maxima, one per lane of a DPP row) + row reduction
+  float m = red[lane & (WAVES - 1)];
+  m = fmaxf(m, dpp_f<DPP_QP_1032>(m));
+  m = fmaxf(m, dpp_f<DPP_QP_2301>(m));
+  m = fmaxf(m, dpp_f<DPP_ROW_HALF_MIRROR>(m));
+  m = fmaxf(m, dpp_f<DPP_ROW_MIRROR>(m));
+  constexpr float DB_PER_LOG2 = 3.01029995663981195f;
+  const float ref = mf.ref_is_max ? m : fabsf(mf.ref_value);
+  const float reflog = __builtin_amdgcn_logf(fmaxf(mf.amin, ref));
+  // log_spec.max() - top_db, with log_spec monotone in the power
+  const float flo = (mf.top_db >= 0.f) ? DB_PER_LOG2 * (__builtin_amdgcn_logf(fmaxf(mf.amin, m)) - reflog) - mf.top_db
+                                       : -3.4e38f;
+  // out[k, t] = sum_m dct[k, m] * dB[m, t]
+  const int ktiles = (mf.n_mfcc + 15) >> 4, ttiles = mf.tp >> 4;
+  const int f = lane & 15, g = lane >> 4;
+  for (int ot = w; ot < ktiles * ttiles; ot += WAVES) {
+    const int kt = ot / ttiles, tq = ot - kt * ttiles;
+    const int krow = kt * 16 + f, tcol = tq * 16 + f;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    // four steps per round: the operand reads of a round are in flight together (this wave is on the
+    // critical path to barrier B)
+    for (int m0 = 0; m0 < n_mels; m0 += 16) {
+      float a[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mm = m0 + 4 * i + g;
+        const bool ok = mm < n_mels;
+        a[i] = (krow < mf.n_mfcc && ok) ? dctl[krow * n_mels + mm] : 0.f;
+        bv[i] = ok ? clipmel[mm * mf.tp + tcol] : 1.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float db = fmaxf(DB_PER_LOG2 * (__builtin_amdgcn_logf(fmaxf(mf.amin, bv[i])) - reflog), flo);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], db, acc, 0, 0, 0);     // (rows past n_mels: a = 0)
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + 4 * g + r;
+      if (k < mf.n_mfcc && tcol < T) {
+        float val = acc[r];
+        if (mf.lifter) val *= lifl[k];
+        mf.out[(b * mf.n_mfcc + k) * (int64_t)T + tcol] = val;
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------
 // MODE 0: mel only   MODE 1: mel + per-frame statistics / contrast   MODE 2: complex STFT output
 // LOAD 0 / 1: frames read straight from global memory   LOAD 2: tiles staged in LDS by LDS-DMA (hop <= 512)
@@ -543,7 +640,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     int64_t total_tiles, int tiles_per_wg, const float2* __restrict__ win2, const float2* __restrict__ twid,
     const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
     float roll_percent, float bw_p, int smask, float* __restrict__ stats_out, ContrastPlan cplan,
-    float* __restrict__ contrast_out, float2* __restrict__ cout, int dma_wide) {
+    float* __restrict__ contrast_out, float2* __restrict__ cout, int dma_wide, MfccArgs mf) {
   typedef Lds<WAVES> LM;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
@@ -556,6 +653,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   int* cpl = reinterpret_cast<int*>(lds + LM::O_CPL);
   float2* winl = reinterpret_cast<float2*>(lds + LM::O_WIN);
   float* stage = lds + LM::O_STAGE;
+  float* clipmel = lds + LM::TOTAL;                 // MODE 3: [n_mels][mf.tp], red[WAVES], dct rows, lifter
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps frame addressing on the scalar unit
@@ -586,6 +684,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   if (tid < 64) tw2l[(tid >> 4) * TW2_STRIDE + (tid & 15)] = twid[32 * (tid >> 4) * (tid & 15)];
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
   for (int i = tid; i < NFFT / 2; i += NTHREADS) winl[i] = win2[i];
+  if (MODE == 3) {
+    float* dctl = clipmel + n_mels * mf.tp + WAVES;
+    for (int i = tid; i < mf.n_mfcc * n_mels; i += NTHREADS) dctl[i] = mf.dct[i];
+    if (mf.lifter != nullptr && tid < mf.n_mfcc) dctl[mf.n_mfcc * n_mels + tid] = mf.lifter[tid];
+  }
 
   int ns = 0, woff = 0, k0 = 0;
   if (!COMPLEX_OUT) {
@@ -602,6 +705,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   if (LOAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  float cmax = 0.f;       // MODE 3: running maximum of the clip's mel powers produced by this thread
+  int64_t pend_b = -1;    // MODE 3: clip whose dB matrix waits for its DCT
   // staged mode: the frame of the NEXT tile is fetched (LDS -> registers) one phase ahead, so that the stage
   // buffer can be refilled behind the FFT phase; direct modes load at the top of the tile loop
   float2 v[16];
@@ -697,6 +802,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (staged mode: the next tile's samples have landed too)
     __syncthreads();                                    // barrier A: rows complete
     TICK(6, tdep);
+    if (MODE == 3 && pend_b >= 0) {
+      if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6 && SYG_ABL != 7)
+        clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, w, lane);
+      pend_b = -1;
+      TICK(10, tdep);
+    }
 
     // ---- phase 2: block-sparse mel projection on the matrix cores
     {
@@ -734,13 +845,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // ---- staged mode: the next tile's frame (LDS -> registers); once every wave holds its frame (barrier B)
     // the stage is refilled with the tile after next.  With statistics the fetch waits until after them
     // (the registers are needed there) and the refill starts behind the closing barrier instead.
-    constexpr bool FETCH_EARLY = (LOAD == 2) && (MODE == 0);
+    constexpr bool FETCH_EARLY = (LOAD == 2) && (MODE == 0 || MODE == 3);
     if (FETCH_EARLY) {
       have = false;
       if (tile + 1 < tile_end) fetch(tile + 1);
     }
     __syncthreads();                // barrier B: slab complete (and every wave has read its staged frame)
     TICK(8, tdep);
+    const bool clip_done = (MODE == 3) && (t0 + TILE_T >= T);
     if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
 
     // ---- reduce the per-wave partial tiles in a fixed order; a wave handles 64 consecutive outputs of one
@@ -756,8 +868,24 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         for (int ww = 0; ww < WAVES; ++ww)
           if (plan.tile[ww] == mt) sum += slab[ww * (16 * TILE_T) + idx];
         const int mel = mt * 16 + m;
-        if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+        if (MODE == 3) {
+          if (mel < n_mels) {
+            clipmel[mel * mf.tp + (int)t0 + tt] = sum;     // frames >= T hold 0 (rows were cleared)
+            cmax = fmaxf(cmax, sum);                        // power is non-negative
+          }
+          if (SYG_ABL != 9 && mel_out != nullptr && mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+        } else {
+          if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+        }
       }
+    }
+    if (clip_done) {
+      // last tile of the clip: publish the per-wave maxima; the dB + DCT epilogue runs in the next tile's
+      // projection phase (or behind the loop)
+      const float cm = wave_max(cmax);
+      cmax = 0.f;
+      if (lane == 0) clipmel[n_mels * mf.tp + w] = cm;
+      pend_b = b;
     }
 
     TICK(9, tdep);
@@ -795,7 +923,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       if (tile + 2 < tile_end) dma(tile + 2);
     }
   }
+  if (MODE == 3 && pend_b >= 0) {
+    __syncthreads();
+    if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6)
+      clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, w, lane);
+  }
 #if SYG_ABL == 9
+  if (MODE == 3 && lane < 12)
+    mel_out[((int64_t)blockIdx.x * WAVES + w) * 16 + lane] = (float)tacc[lane] / (float)(tile_end - tile_begin);
   if (MODE == 1 && lane < 12)
     stats_out[((int64_t)blockIdx.x * WAVES + w) * 16 + lane] = (float)tacc[lane] / (float)(tile_end - tile_begin);
 #endif
@@ -846,17 +981,31 @@ int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int
   return SYG_OK;
 }
 
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
 template <int WAVES, int MODE>
 int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
            const float* window, const float* twiddle, const float* wpacked, const MelPlan& plan, int n_mels,
            float* mel_out, float binhz, float roll_percent, float bw_p, int smask, float* stats_out,
            const ContrastPlan& cp,
-           float* contrast_out, float* cout, hipStream_t st) {
+           float* contrast_out, float* cout, hipStream_t st, MfccArgs mf = MfccArgs()) {
   const int pad = center ? NFFT / 2 : 0;
   const int tiles = (int)((T + WAVES - 1) / WAVES);
   const int64_t total_tiles = B * tiles;
   int wgs = 0, per = 0;
   persistent_grid(total_tiles, WAVES, wgs, per);
+  size_t lds = lds_bytes<WAVES>();
+  if (MODE == 3) {
+    // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
+    int cw = 0, cper = 0;
+    persistent_grid(B, WAVES, cw, cper);
+    per = cper * tiles;
+    wgs = cw;
+    mf.tp = tiles * WAVES;
+    lds += ((size_t)n_mels * mf.tp + WAVES + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
+    SYG_REQUIRE(lds <= LDS_LIMIT, "stft2048_mfcc: the clip's mel matrix (%d x %d) does not fit the LDS left over (%zu B > %zu B); "
+                "use syg_stft2048_mel_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
+  }
   // staged tiles (LDS-DMA) need the tile's sample run to fit the stage buffer and 32-bit byte offsets
   const bool can_stage = (MODE != 2) && hop <= 512 && L < ((int64_t)1 << 28);
   if (load == 2 && !can_stage) load = 1;
@@ -867,17 +1016,17 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
                         : load == 1 ? stft2048_kernel<WAVES, 1, MODE> : stft2048_kernel<WAVES, 0, MODE>;
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[load]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes<WAVES>());
+    const size_t cap = (MODE == 3) ? LDS_LIMIT : lds_bytes<WAVES>();
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
-      set_error("stft2048: cannot reserve %zu B LDS: %s", lds_bytes<WAVES>(), hipGetErrorString(e));
+      set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
       return SYG_E_LAUNCH;
     }
     attr_set[load] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes<WAVES>(), st, y, L, ldy, hop, pad, T,
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(WAVES * 64), lds, st, y, L, ldy, hop, pad, T,
                      tiles, total_tiles, per, (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels,
-                     mel_out, binhz, roll_percent, bw_p, smask, stats_out, cp, contrast_out, (float2*)cout, dma_wide);
+                     mel_out, binhz, roll_percent, bw_p, smask, stats_out, cp, contrast_out, (float2*)cout, dma_wide, mf);
   SYG_CHECK_LAUNCH("stft2048");
   return SYG_OK;
 }
@@ -887,6 +1036,32 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
 
 using namespace syg;
 
+namespace syg {
+namespace {
+int parse_mel_plan(const char* who, const int32_t* plan_host, int n_mels, MelPlan& plan) {
+  const int waves = plan_host[1];
+  SYG_REQUIRE(waves == 8 || waves == 16, "%s: plan must be built for 8 or 16 waves (got %d)", who, waves);
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= 16 * waves, "%s: n_mels must be in [1, %d] (got %d)", who, 16 * waves, n_mels);
+  memset(&plan, 0, sizeof(plan));
+  plan.n_tiles = plan_host[0];
+  SYG_REQUIRE(plan.n_tiles == (n_mels + 15) / 16, "%s: plan has %d tiles, n_mels=%d needs %d", who, plan.n_tiles,
+              n_mels, (n_mels + 15) / 16);
+  for (int w = 0; w < MAXW; ++w) {
+    plan.tile[w] = plan_host[2 + w];
+    plan.k0[w] = plan_host[2 + MAXW + w];
+    plan.nsteps[w] = plan_host[2 + 2 * MAXW + w];
+    plan.woff[w] = plan_host[2 + 3 * MAXW + w];
+    if (w >= waves) { plan.tile[w] = -1; plan.nsteps[w] = 0; plan.k0[w] = 0; plan.woff[w] = 0; }
+    SYG_REQUIRE(plan.tile[w] >= -1 && plan.tile[w] < plan.n_tiles, "%s: bad tile in plan", who);
+    SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 15 &&
+                    plan.woff[w] >= 0 && plan.k0[w] % 16 == 0 && plan.nsteps[w] % 4 == 0 && plan.woff[w] % 4 == 0,
+                "%s: plan segment %d out of range (k0=%d nsteps=%d)", who, w, plan.k0[w], plan.nsteps[w]);
+  }
+  return SYG_OK;
+}
+}  // namespace
+}  // namespace syg
+
 extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
                                     int64_t T, const float* window, const float* twiddle, const float* wpacked,
                                     const int32_t* plan_host, int n_mels, float* mel_out, float sr,
@@ -894,28 +1069,12 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
                                     const int32_t* cplan_host,
                                     float* contrast_out, void* stream) {
   SYG_REQUIRE(wpacked && plan_host && mel_out, "stft2048_mel: null pointer argument");
-  const int waves = plan_host[1];
-  SYG_REQUIRE(waves == 8 || waves == 16, "stft2048_mel: plan must be built for 8 or 16 waves (got %d)", waves);
-  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, waves);
-  if (rc) return rc;
-  SYG_REQUIRE(n_mels >= 1 && n_mels <= 16 * waves, "stft2048_mel: n_mels must be in [1, %d] (got %d)", 16 * waves,
-              n_mels);
   MelPlan plan;
-  memset(&plan, 0, sizeof(plan));
-  plan.n_tiles = plan_host[0];
-  SYG_REQUIRE(plan.n_tiles == (n_mels + 15) / 16, "stft2048_mel: plan has %d tiles, n_mels=%d needs %d",
-              plan.n_tiles, n_mels, (n_mels + 15) / 16);
-  for (int w = 0; w < MAXW; ++w) {
-    plan.tile[w] = plan_host[2 + w];
-    plan.k0[w] = plan_host[2 + MAXW + w];
-    plan.nsteps[w] = plan_host[2 + 2 * MAXW + w];
-    plan.woff[w] = plan_host[2 + 3 * MAXW + w];
-    if (w >= waves) { plan.tile[w] = -1; plan.nsteps[w] = 0; plan.k0[w] = 0; plan.woff[w] = 0; }
-    SYG_REQUIRE(plan.tile[w] >= -1 && plan.tile[w] < plan.n_tiles, "stft2048_mel: bad tile in plan");
-    SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 15 &&
-                    plan.woff[w] >= 0 && plan.k0[w] % 16 == 0 && plan.nsteps[w] % 4 == 0 && plan.woff[w] % 4 == 0,
-                "stft2048_mel: plan segment %d out of range (k0=%d nsteps=%d)", w, plan.k0[w], plan.nsteps[w]);
-  }
+  int rc = parse_mel_plan("stft2048_mel", plan_host, n_mels, plan);
+  if (rc) return rc;
+  const int waves = plan_host[1];
+  rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, waves);
+  if (rc) return rc;
   ContrastPlan cp;
   memset(&cp, 0, sizeof(cp));
   if (contrast_out) {
@@ -945,6 +1104,32 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
   if (waves == 8) return extra ? SYG_LAUNCH(8, 1) : SYG_LAUNCH(8, 0);
   return extra ? SYG_LAUNCH(16, 1) : SYG_LAUNCH(16, 0);
 #undef SYG_LAUNCH
+}
+
+extern "C" int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
+                                     int64_t T, const float* window, const float* twiddle, const float* wpacked,
+                                     const int32_t* plan_host, int n_mels, const float* dct, int n_mfcc,
+                                     const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
+                                     float* mel_out, float* mfcc_out, void* stream) {
+  SYG_REQUIRE(wpacked && plan_host && dct && mfcc_out, "stft2048_mfcc: null pointer argument");
+  MelPlan plan;
+  int rc = parse_mel_plan("stft2048_mfcc", plan_host, n_mels, plan);
+  if (rc) return rc;
+  SYG_REQUIRE(plan_host[1] == 16, "stft2048_mfcc: needs a 16-wave plan (got %d)", plan_host[1]);
+  rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
+  if (rc) return rc;
+  SYG_REQUIRE(n_mfcc >= 1 && n_mfcc <= n_mels, "stft2048_mfcc: need 1 <= n_mfcc <= n_mels (n_mfcc=%d n_mels=%d)",
+              n_mfcc, n_mels);
+  SYG_REQUIRE(amin > 0.f, "stft2048_mfcc: amin must be strictly positive");
+  SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft2048_mfcc: ref_is_max must be 0 or 1");
+  SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_mfcc: clip too long");
+  ContrastPlan cp;
+  memset(&cp, 0, sizeof(cp));
+  MfccArgs mf;
+  mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
+  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0;
+  return launch<16, 3>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out, 0.f,
+                       0.f, 0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
 }
 
 extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,

@@ -98,11 +98,11 @@ def fused_waves() -> int:
 class MelConfig:
     """Device tables for one (sr, n_fft, n_mels, fmin, fmax) mel front end."""
 
-    def __init__(self, sr, n_fft, n_mels, fmin, fmax):
+    def __init__(self, sr, n_fft, n_mels, fmin, fmax, waves=None):
         basis = T.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
         self.basis_host = basis
         self.n_mels = n_mels
-        waves = fused_waves()
+        waves = fused_waves() if waves is None else waves
         if n_fft == 2048 and n_mels <= 16 * waves:
             wp, plan = T.pack_mel_plan(basis, waves)
             self.wpacked = _dev(wp)
@@ -113,10 +113,11 @@ class MelConfig:
         self.basis = _dev(basis)
 
 
-def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> MelConfig:
+def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None, waves=None) -> MelConfig:
     fmax = sr / 2.0 if fmax is None else fmax
-    return _cached(("mel", float(sr), n_fft, n_mels, float(fmin), float(fmax), fused_waves()),
-                   lambda: MelConfig(sr, n_fft, n_mels, fmin, fmax))
+    waves = fused_waves() if waves is None else waves
+    return _cached(("mel", float(sr), n_fft, n_mels, float(fmin), float(fmax), waves),
+                   lambda: MelConfig(sr, n_fft, n_mels, fmin, fmax, waves))
 
 
 def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
@@ -209,11 +210,102 @@ def logmel_dct(mel: torch.Tensor, n_mfcc: Optional[int] = 13, dct_type: int = 2,
     return (logmel if keep_mel else mel), mf
 
 
+# LDS left beside the fused kernel's fixed map for the clip-resident mel matrix (see csrc/stft_mel.hip, Lds<16>)
+_MFCC_LDS_SPARE_FLOATS = (160 * 1024 - 141664) // 4 - 18
+
+
+def mfcc_fused_fits(n_mels: int, n_frames: int, n_mfcc: int = 13) -> bool:
+    return n_mels * (16 * ((n_frames + 15) // 16)) + n_mfcc * (n_mels + 1) <= _MFCC_LDS_SPARE_FLOATS
+
+
+class _MfccCall:
+    """Prepared argument list of syg_stft2048_mfcc_f32 for one (shape, parameters) combination: a steady-state
+    call then costs two allocations and one ctypes call (the kernel runs ~0.2 ms; rebuilding keys, tables and
+    22 ctypes arguments per call costs the host about as much)."""
+
+    def __init__(self, B, L, ld, device, sr, hop, center, window, n_mels, n_mfcc, fmin, fmax, lifter, amin, top_db,
+                 ref, dct_type, norm, keep_mel):
+        if amin <= 0:
+            raise ValueError("amin must be strictly positive")
+        if top_db is not None and top_db < 0:
+            raise ValueError("top_db must be non-negative")
+        Tn = num_frames(L, 2048, hop, center)
+        if Tn <= 0:
+            raise ValueError("signal too short for one frame")
+        self.cfg = mel_config(sr, 2048, n_mels, fmin, fmax, waves=16)
+        K = int(n_mfcc)
+        self.dct = _cached(("dct", K, n_mels, dct_type, norm), lambda: _dev(T.dct_matrix(K, n_mels, dct_type, norm)))
+        lw = T.lifter_weights(K, float(lifter))
+        self.lif = _dev(lw) if lw is not None else None
+        if (isinstance(ref, str) and ref == "max") or ref is np.max:
+            ref_is_max, ref_value = 1, 1.0
+        else:
+            ref_is_max, ref_value = 0, float(ref)
+        self.win = window_dev(window, 2048, 2048)
+        self.tw = twiddle_dev(2048)
+        self.shape = (B, L, ld)
+        self.device = device
+        self.mel_shape = (B, n_mels, Tn) if keep_mel else None
+        self.out_shape = (B, K, Tn)
+        self.fn = lib().syg_stft2048_mfcc_f32
+        self.head = (B, L, ld, hop, int(center), Tn, _ptr(self.win), _ptr(self.tw), _ptr(self.cfg.wpacked),
+                     self.cfg.plan.ctypes.data_as(C.c_void_p), n_mels, _ptr(self.dct), K, _ptr(self.lif), float(amin),
+                     float(top_db) if top_db is not None else -1.0, ref_is_max, ref_value)
+
+    def __call__(self, y):
+        mel = torch.empty(self.mel_shape, dtype=torch.float32, device=self.device) if self.mel_shape else None
+        mf = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+        rc = self.fn(y.data_ptr(), *self.head, mel.data_ptr() if mel is not None else None, mf.data_ptr(),
+                     _stream_ptr())
+        if rc:
+            check(rc, "syg_stft2048_mfcc_f32")
+        return mf, mel
+
+
+_mfcc_calls: dict = {}
+
+
+def stft2048_mfcc(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann", n_mels: int = 128,
+                  n_mfcc: int = 13, fmin: float = 0.0, fmax=None, lifter: float = 0.0, amin: float = 1e-10,
+                  top_db: Optional[float] = 80.0, ref="max", dct_type: int = 2, norm="ortho", keep_mel: bool = False):
+    """One launch: [B, L] clips -> MFCC [B, n_mfcc, T]; the mel matrix of a clip never leaves LDS.
+
+    Returns (mfcc, mel_power | None).  Raises SygnalsHipError when the clip's mel matrix does not fit
+    (mfcc_fused_fits) -- mfcc_batch() falls back to the two-launch form by itself.
+    """
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        require_gpu()
+        raise ValueError("y must be a float32 [B, L] device tensor")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    wkey = window if isinstance(window, str) else _window_key(window, 2048, 2048)
+    rkey = "max" if (ref is np.max or ref == "max") else float(ref)
+    key = (y.device.index, y.shape[0], y.shape[1], _ld(y), float(sr), hop, bool(center), wkey, n_mels, n_mfcc,
+           float(fmin), fmax, float(lifter), amin, top_db, rkey, dct_type, norm, keep_mel)
+    call = _mfcc_calls.get(key)
+    if call is None:
+        require_gpu()
+        call = _MfccCall(y.shape[0], y.shape[1], _ld(y), y.device, sr, hop, center, window, n_mels, n_mfcc, fmin,
+                         fmax, lifter, amin, top_db, ref, dct_type, norm, keep_mel)
+        if len(_mfcc_calls) > 64:
+            _mfcc_calls.clear()
+        _mfcc_calls[key] = call
+    return call(y)
+
+
 def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_mels: int = 128, n_mfcc: int = 13,
-               center: bool = True, window="hann", fmin: float = 0.0, fmax=None, lifter: float = 0.0):
-    """Config C2: [B, L] clips -> MFCC [B, n_mfcc, T] (manager path a1..a5), all on device."""
+               center: bool = True, window="hann", fmin: float = 0.0, fmax=None, lifter: float = 0.0, fused=None):
+    """Config C2: [B, L] clips -> MFCC [B, n_mfcc, T] (manager path a1..a5), all on device.
+
+    fused=None picks the one-launch clip-resident form when the clip's mel matrix fits in LDS and there are
+    enough clips to fill the chip (a workgroup owns whole clips); True / False force either form.
+    """
     if n_fft != 2048:
         raise SygnalsHipError("mfcc_batch: only n_fft=2048 has a fused path; use features.extract_features_batch")
+    if fused is None:
+        fused = mfcc_fused_fits(n_mels, num_frames(y.shape[1], 2048, hop, center), n_mfcc) and y.shape[0] >= 128
+    if fused:
+        return stft2048_mfcc(y, sr, hop, center, window, n_mels, n_mfcc, fmin, fmax, lifter)[0]
     mel, _, _ = stft2048_mel(y, sr, hop, center, window, 2048, n_mels, fmin, fmax)
     _, mf = logmel_dct(mel, n_mfcc, lifter=lifter)
     return mf

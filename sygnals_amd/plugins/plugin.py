@@ -67,6 +67,7 @@ class SygnalsAmdPlugin(_Base):
     def teardown(self):
         from .. import ops
         ops._dev_cache.clear()
+        ops._mfcc_calls.clear()
 
     # ---- registration hooks (call order fixed by loader.py:266-274) -----------------------
     def register_filters(self, registry):

@@ -180,7 +180,53 @@ def test_large_batch_consistency(ops):
     big = np.tile(Y, (64, 1))
     out = ops.mfcc_batch(ops.to_device_f32(big), 48000, n_mels=40).cpu().numpy()
     assert out.shape == (1024, 13, 94)
-    small = ops.mfcc_batch(ops.to_device_f32(Y), 48000, n_mels=40).cpu().numpy()
+    # (the 1024-clip batch takes the one-launch form by itself; run the small batch through the same form)
+    small = ops.mfcc_batch(ops.to_device_f32(Y), 48000, n_mels=40, fused=True).cpu().numpy()
     assert np.array_equal(out.reshape(64, 16, 13, 94), np.broadcast_to(small, (64, 16, 13, 94)))
+    two = ops.mfcc_batch(ops.to_device_f32(big), 48000, n_mels=40, fused=False).cpu().numpy()
+    assert np.array_equal(two.reshape(64, 16, 13, 94), np.broadcast_to(two[:16], (64, 16, 13, 94)))
+    assert_parity(out, two, TOL, "one-launch vs two-launch form at the full batch")
     ref = O.mfcc_batch(Y[:4], 48000, n_mels=40)
     assert_parity(small[:4], ref, TOL, "sample of the large batch")
+
+
+@pytest.mark.parametrize("n_mels,n_mfcc,lifter", [(40, 13, 0.0), (24, 24, 22.0), (44, 16, 0.0)])
+def test_mfcc_one_launch_matches_oracle(ops, clips, n_mels, n_mfcc, lifter):
+    """syg_stft2048_mfcc_f32 (clip-resident mel matrix) against the oracle and against the two-launch form."""
+    y = ops.to_device_f32(clips)
+    mf, mel = ops.stft2048_mfcc(y, 48000, n_mels=n_mels, n_mfcc=n_mfcc, lifter=lifter, keep_mel=True)
+    ref = np.stack([O.mfcc_manager(c.astype(np.float64), 48000, n_mels=n_mels, n_mfcc=n_mfcc, lifter=lifter)
+                    for c in clips])
+    assert mf.shape == ref.shape
+    assert_parity(mf.cpu().numpy(), ref, TOL, f"one-launch MFCC n_mels={n_mels}")
+    two = ops.mfcc_batch(y, 48000, n_mels=n_mels, n_mfcc=n_mfcc, lifter=lifter, fused=False)
+    assert_parity(mf.cpu().numpy(), two.cpu().numpy(), TOL, "one-launch vs two-launch")
+    mel2, _, _ = ops.stft2048_mel(y, 48000, n_mels=n_mels)
+    assert torch.equal(mel, mel2), "the stored mel power must be the two-launch kernel's, bit for bit"
+
+
+def test_mfcc_one_launch_ragged_and_degenerate(ops):
+    """Clips whose frame count is not a multiple of 16, more clips than workgroups, all-zero clip, fixed ref."""
+    rng = np.random.default_rng(11)
+    Y = rng.normal(0, 0.1, (300, 5000)).astype(np.float32)
+    Y[7] = 0.0
+    y = ops.to_device_f32(Y)
+    mf, _ = ops.stft2048_mfcc(y, 16000, hop=160, n_mels=40)
+    two = ops.mfcc_batch(y, 16000, hop=160, n_mels=40, fused=False)
+    assert mf.shape == two.shape == (300, 13, 32)
+    assert_parity(mf.cpu().numpy(), two.cpu().numpy(), TOL, "ragged one-launch vs two-launch")
+    ref = np.stack([O.mfcc_manager(c.astype(np.float64), 16000, 2048, 160, True, "hann", 40, 13) for c in Y[:9]])
+    assert_parity(mf[:9].cpu().numpy(), ref, TOL, "ragged one-launch vs oracle")
+    mf1, _ = ops.stft2048_mfcc(y[:5], 16000, hop=160, n_mels=40, ref=1.0, top_db=None)
+    mel, _, _ = ops.stft2048_mel(y[:5], 16000, hop=160, n_mels=40)
+    _, two1 = ops.logmel_dct(mel, 13, ref=1.0, top_db=None)
+    assert_parity(mf1.cpu().numpy(), two1.cpu().numpy(), TOL, "fixed reference, no clamp")
+
+
+def test_mfcc_one_launch_rejects_oversized_clip(ops):
+    y = ops.to_device_f32(np.zeros((2, 160000), np.float32))
+    assert not ops.mfcc_fused_fits(128, 313)
+    with pytest.raises(Exception, match="does not fit"):
+        ops.stft2048_mfcc(y, 16000, n_mels=128)
+    out = ops.mfcc_batch(y, 16000, n_mels=128)          # falls back to the two-launch form
+    assert out.shape == (2, 13, 313)
