@@ -77,8 +77,10 @@ def cpu_baseline(target_seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # a step is ~0.2 ms and the GPU needs ~150 steps (30 ms) from idle to reach its steady clock
+    # (tools/warm_curve.py), hence the long default warm-up; the whole default run is still ~0.2 s of GPU time
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clips", type=int, default=B_PER_GPU, help="clips per GPU (default: the C2 batch)")
     a = ap.parse_args()
@@ -148,15 +150,15 @@ def main():
     roof = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = max(10, min(a.steps, 50))
-        durs = []
+        reps = max(10, min(a.steps, 100))
+        # back-to-back launches between two events on the launch stream (steady clock: the timed steps above
+        # have just run); the average includes the ~2 us dispatch gap, as rocprofv3's per-dispatch average does not
+        e0.record()
         for _ in range(reps):
-            e0.record()
             ops.stft2048_mfcc(y, SR, HOP, True, "hann", N_MELS, N_MFCC)
-            e1.record()
-            e1.synchronize()
-            durs.append(e0.elapsed_time(e1) * 1e-3)
-        kdur = float(np.mean(durs))
+        e1.record()
+        e1.synchronize()
+        kdur = e0.elapsed_time(e1) * 1e-3 / reps
         # algorithmic bytes of the path this launch carries: every sample read once, MFCCs written once
         kbytes = B * ALGO_BYTES_PER_CLIP           # SURVEY 8d per-clip figure x clips per launch
         achieved = kbytes / kdur / 1e9
@@ -164,7 +166,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("stft2048_mel_bytes_per_launch")
+                traffic = json.load(open(tp)).get("dominant_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
