@@ -149,30 +149,37 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
 #pragma unroll
   for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], tw1l[(c - 1) * 64 + lane]);
 #endif
-  // ---- exchange 1 in two half-rounds through a 512-complex buffer: round h moves the 32 COLUMNS
-  // b = 32h..32h+31 (those 32 lanes store their 16 values, y[c][b] at c*32 + ((b & 31) ^ 4(c & 7))); every
-  // lane then reads the 8 operands y[lane>>2][4a + b'], a = 8h..8h+7, that live in this half -- the reads
-  // are not divergent and land in fixed registers
+  // ---- exchange 1 in two half-rounds through a 512-complex buffer.  Round h moves the 8 ROWS c = 8h..8h+7:
+  // all 64 lanes store (row r = c & 7 at r*64 + (b ^ 4r)) -- an LDS store costs its 6 cycles whatever the EXEC
+  // mask, so half-wave stores would pay twice.  A pass-2 lane (c = lane>>2, b' = lane&3) needs the 16 operands
+  // y[c][4a + b'] of ONE row, which only one of the rounds holds: in round h the lane pair (L, L + 32) shares
+  // the reading of row (L>>2) + 8h -- L takes a = 0..7, L + 32 takes a = 8..15 -- and v_permlane32_swap then
+  // hands each lane the half it is missing (L's round-1 operands <-> (L+32)'s round-0 operands): full-wave
+  // stores AND full-wave loads for 16 extra VALU instructions.
   TICK(1, v[1].x);
   float2 t[16];
   {
-    const int wcol = lane & 31;
-    const int rx = 4 * (cl & 7);
-    const int rbase = cl * 32 + bp;
 #if SYG_ABL == 2 || SYG_ABL == 4
 #pragma unroll
     for (int a = 0; a < 16; ++a) t[a] = v[a];
 #else
+    const int r7 = cl & 7;
+    const int rbase = r7 * 64 + bp + 8 * (cl & 8) / 2;      // + 32 for the upper half-wave (a = 8..15)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if ((lane >> 5) == h) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) sc[c * 32 + (wcol ^ (4 * (c & 7)))] = v[c];
-      }
+      for (int r = 0; r < 8; ++r) sc[r * 64 + (lane ^ (4 * r))] = v[8 * h + r];
       wave_lds_sync();
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[8 * h + i] = sc[rbase + ((4 * i) ^ rx)];
+      for (int i = 0; i < 8; ++i) t[8 * h + i] = sc[rbase + 4 * (i ^ r7)];
       wave_lds_sync();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[i].x), __float_as_uint(t[8 + i].x), false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[i].y), __float_as_uint(t[8 + i].y), false, false);
+      t[i] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+      t[8 + i] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
     }
 #endif
   }
@@ -182,10 +189,13 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   dft16(t);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
-    const float4* t4 = reinterpret_cast<const float4*>(tw2l + bp * TW2_STRIDE);
+    // (read through the LDS address space as one native 4-vector: a generic float4 is split into two 8-byte
+    // halves and re-fused into ds_read2_b64, which costs twice the LDS cycles of ds_read_b128)
+    typedef __attribute__((address_space(3))) const v4f* lds_v4;
+    lds_v4 t4 = (lds_v4)(tw2l + bp * TW2_STRIDE);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const float4 tt = t4[m];
+      const v4f tt = t4[m];
       if (m > 0) t[2 * m] = cmul(t[2 * m], make_float2(tt.x, tt.y));
       t[2 * m + 1] = cmul(t[2 * m + 1], make_float2(tt.z, tt.w));
     }
