@@ -208,6 +208,24 @@ int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg
                   void* work, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Time-domain frame features, one value per frame:
+ *   rows 0..6: mean |x|, population std, skewness (scipy.stats.skew bias=False), excess kurtosis
+ *              (scipy.stats.kurtosis fisher, bias=False), max |x|, crest factor, Shannon entropy of
+ *              np.histogram(frame, num_bins) -- sygnals/core/features/time_domain.py:23-227 applied per frame
+ *              of the zero-padded signal by manager.py:264-286
+ *   row 7:     RMS energy  -- core/audio/features.py:73-131 (librosa.feature.rms, zero padding)
+ *   row 8:     zero-crossing rate -- core/audio/features.py:26-71 (librosa.feature.zero_crossing_rate,
+ *              edge padding, threshold 1e-10)
+ *   y [B, L] float32 (row stride ldy); T as syg_stft2048_mel_f32's framing rule with n_fft = frame_length;
+ *   mask: bit r selects row r (unselected rows are left untouched);  out [B, SYG_NFSTAT, T] float32.
+ * syg_rms_from_spec_f32: librosa.feature.rms(S=...) for rows of magnitudes S [rows, F] -> out [rows].
+ * ------------------------------------------------------------------------------- */
+#define SYG_NFSTAT 9
+int syg_frame_stats_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int frame_length, int hop,
+                        int center, int64_t T, int num_bins, int mask, float* out, void* stream);
+int syg_rms_from_spec_f32(const float* S, int64_t rows, int F, int frame_length, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Constant-Q transform building blocks: librosa.cqt as called by compute_cqt,
  * sygnals/core/dsp.py:276-284 (recursive per-octave algorithm; the host composes the octaves).
  *   syg_decimate2_f32   y[b, n] = scale * sum_j taps[j] * x[b, 2n + (ntaps-1)/2 - j], n < ceil(L/2)

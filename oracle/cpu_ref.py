@@ -13,10 +13,12 @@ PARITY STATUS
   pinned   : design_butterworth_sos, apply_sos_filter/*_pass_filter, compute_fft,
              compute_ifft, apply_window, compute_psd_welch, spectral_centroid,
              spectral_bandwidth, spectral_flatness, spectral_rolloff,
-             dominant_frequency  -- checked against tests/golden/ref_*.npz, which
-             were produced by executing the reference's own functions.
+             dominant_frequency, and the seven time-domain frame functions
+             (mean/std/skewness/kurtosis/peak/crest/entropy)  -- checked against
+             tests/golden/ref_*.npz, which were produced by executing the
+             reference's own functions.
   UNPINNED : stft, mel_filterbank, power_to_db, melspectrogram, mfcc,
-             spectral_contrast, frames_to_time, cqt  ("parity unpinned": no
+             spectral_contrast, frames_to_time, cqt, rms_energy, zero_crossing_rate  ("parity unpinned": no
              runnable librosa, no numeric golden values in the reference's
              tests).  Anchors: librosa's documented examples (mel_frequencies,
              hz_to_mel, mel_to_hz, fft_frequencies), closed-form KATs, and
@@ -580,11 +582,155 @@ def welch_explicit(x, fs=1.0, window="hann", nperseg=256, noverlap=None, nfft=No
 
 
 # --------------------------------------------------------------------------
+# f-1  time-domain frame features (core/features/time_domain.py:23-227, driven per frame by
+#      manager.py:264-286) and RMS / zero-crossing rate (core/audio/features.py:26-131 -> librosa)
+# --------------------------------------------------------------------------
+TIME_FEATURES = ("mean_amplitude", "std_dev_amplitude", "skewness", "kurtosis", "peak_amplitude",
+                 "crest_factor", "signal_entropy")
+
+
+def mean_amplitude(frame) -> np.float64:                      # time_domain.py:23-44
+    frame = np.asarray(frame, dtype=np.float64)
+    return np.float64(0.0) if frame.size == 0 else np.mean(np.abs(frame))
+
+
+def std_dev_amplitude(frame) -> np.float64:                   # time_domain.py:46-67 (population std)
+    frame = np.asarray(frame, dtype=np.float64)
+    return np.float64(0.0) if frame.size == 0 else np.std(frame)
+
+
+def _central_moments(frame):
+    m = frame.mean()
+    d = frame - m
+    return (d ** 2).mean(), (d ** 3).mean(), (d ** 4).mean()
+
+
+def skewness(frame) -> np.float64:
+    """time_domain.py:69-97: scipy.stats.skew(bias=False) = sqrt(n(n-1))/(n-2) * m3/m2^1.5; 0 for n < 2 or
+    var < eps.  (scipy returns nan for n < 3 with bias=False: n = 2 gives 0/0 -> the reference propagates it;
+    restated here as the same formula.)"""
+    frame = np.asarray(frame, dtype=np.float64)
+    n = frame.size
+    if n < 2 or np.var(frame) < EPS64:
+        return np.float64(0.0)
+    m2, m3, _ = _central_moments(frame)
+    g1 = m3 / m2 ** 1.5
+    if n < 3:
+        return np.float64(g1)          # scipy applies the bias correction only when n > 2
+    return np.float64(np.sqrt(n * (n - 1.0)) / (n - 2.0) * g1)
+
+
+def kurtosis_val(frame) -> np.float64:
+    """time_domain.py:99-130: scipy.stats.kurtosis(fisher=True, bias=False) =
+    (n-1)/((n-2)(n-3)) * ((n+1) m4/m2^2 - 3(n-1)); 0 for n < 4 or var < eps."""
+    frame = np.asarray(frame, dtype=np.float64)
+    n = frame.size
+    if n < 4 or np.var(frame) < EPS64:
+        return np.float64(0.0)
+    m2, _, m4 = _central_moments(frame)
+    return np.float64((n - 1.0) / ((n - 2.0) * (n - 3.0)) * ((n + 1.0) * m4 / m2 ** 2 - 3.0 * (n - 1.0)))
+
+
+def peak_amplitude(frame) -> np.float64:                      # time_domain.py:132-153
+    frame = np.asarray(frame, dtype=np.float64)
+    return np.float64(0.0) if frame.size == 0 else np.max(np.abs(frame))
+
+
+def crest_factor(frame) -> np.float64:                        # time_domain.py:155-186
+    frame = np.asarray(frame, dtype=np.float64)
+    if frame.size == 0:
+        return np.float64(0.0)
+    rms = np.sqrt(np.mean(frame ** 2))
+    return np.float64(0.0) if rms < EPS64 else np.float64(peak_amplitude(frame) / rms)
+
+
+def histogram_counts(frame, num_bins):
+    """np.histogram(frame, bins=num_bins) as NumPy computes it for uniform bins: index from the scaled
+    offset, then corrected against the linspace edges; the last bin is closed on the right."""
+    first, last = frame.min(), frame.max()
+    if first == last:
+        first, last = first - 0.5, last + 0.5
+    edges = np.linspace(first, last, num_bins + 1)
+    norm = num_bins / (last - first)
+    idx = ((frame - first) * norm).astype(np.intp)
+    idx[idx == num_bins] -= 1
+    idx[frame < edges[idx]] -= 1
+    inc = (frame >= edges[idx + 1]) & (idx != num_bins - 1)
+    idx[inc] += 1
+    return np.bincount(idx, minlength=num_bins)
+
+
+def signal_entropy(frame, num_bins: int = 10) -> np.float64:  # time_domain.py:188-227
+    frame = np.asarray(frame, dtype=np.float64)
+    if frame.size < 2 or num_bins < 1 or np.all(frame == frame[0]):
+        return np.float64(0.0)
+    counts = histogram_counts(frame, num_bins)
+    pk = counts[counts > 0] / frame.size
+    pk = pk / pk.sum()                                        # scipy.stats.entropy normalises
+    return np.float64(-(pk * np.log(pk)).sum())
+
+
+_TIME_FUNCS = {"mean_amplitude": mean_amplitude, "std_dev_amplitude": std_dev_amplitude, "skewness": skewness,
+               "kurtosis": kurtosis_val, "peak_amplitude": peak_amplitude, "crest_factor": crest_factor,
+               "signal_entropy": signal_entropy}
+
+
+def time_features_frames(y, frame_length=2048, hop_length=512, center=True, num_bins=10):
+    """manager.py:264-286: zero-pad frame_length//2 when centred, frame, apply each function per frame."""
+    y = np.asarray(y, dtype=np.float64)
+    fr = frame_signal(y, frame_length, hop_length, center)   # [T, frame_length]
+    out = {}
+    for name, fn in _TIME_FUNCS.items():
+        if name == "signal_entropy":
+            out[name] = np.array([fn(f, num_bins) for f in fr], dtype=np.float64)
+        else:
+            out[name] = np.array([fn(f) for f in fr], dtype=np.float64)
+    return out
+
+
+def rms_energy(y=None, S=None, frame_length=2048, hop_length=512, center=True):
+    """audio/features.py:73-131 -> librosa.feature.rms (UNPINNED, restated): from y: zero-pad frame_length//2,
+    frame, sqrt(mean(x^2)); from a magnitude spectrogram S: sqrt(2 sum(|S|^2 with DC (and Nyquist for even
+    frame_length) halved) / frame_length^2)."""
+    if S is not None:
+        x = np.abs(np.asarray(S, dtype=np.float64)) ** 2
+        x[0] *= 0.5
+        if frame_length % 2 == 0:
+            x[-1] *= 0.5
+        return np.sqrt(2.0 * x.sum(axis=0) / frame_length ** 2)
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("Input audio data 'y' must be a 1D array.")
+    fr = frame_signal(y, frame_length, hop_length, center)   # [T, frame_length]
+    return np.sqrt(np.mean(fr ** 2, axis=1))
+
+
+def zero_crossing_rate(y, frame_length=2048, hop_length=512, center=True, threshold=1e-10):
+    """audio/features.py:26-71 -> librosa.feature.zero_crossing_rate (UNPINNED, restated): EDGE-pad
+    frame_length//2, frame, zero the samples with |x| <= threshold, count sign-bit changes between neighbours
+    inside the frame (the first sample of a frame never counts: pad=False), divide by frame_length."""
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("Input audio data must be a 1D array.")
+    if center:
+        y = np.pad(y, frame_length // 2, mode="edge")
+    T = 1 + (len(y) - frame_length) // hop_length if len(y) >= frame_length else 0
+    out = np.zeros(max(T, 0), dtype=np.float64)
+    for t in range(T):
+        f = y[t * hop_length: t * hop_length + frame_length].copy()
+        f[np.abs(f) <= threshold] = 0.0
+        sb = np.signbit(f)
+        out[t] = np.count_nonzero(sb[1:] != sb[:-1]) / frame_length
+    return out
+
+
+# --------------------------------------------------------------------------
 # a16 extract_features orchestration (manager.py:78-445), dict_of_arrays form
 # --------------------------------------------------------------------------
 SPECTRUM_FEATURES = ("spectral_centroid", "spectral_bandwidth", "spectral_flatness",
                      "spectral_rolloff", "dominant_frequency")
-KNOWN_FEATURES = set(SPECTRUM_FEATURES) | {"spectral_contrast", "mfcc"}
+KNOWN_FEATURES = set(SPECTRUM_FEATURES) | {"spectral_contrast", "mfcc"} | set(TIME_FEATURES) | {
+    "rms_energy", "zero_crossing_rate"}
 
 
 def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=True,
@@ -608,9 +754,19 @@ def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=
     S_mag = np.abs(stft(y, frame_length, hop_length, frame_length, window, center))
     freqs = fft_frequencies(sr, frame_length)
     stats = None
+    tstats = None
     for name in features:
         p = feature_params.get(name, {})
-        if name in SPECTRUM_FEATURES:
+        if name in TIME_FEATURES:
+            if tstats is None:
+                tstats = time_features_frames(y, frame_length, hop_length, center,
+                                              feature_params.get("signal_entropy", {}).get("num_bins", 10))
+            res[name] = tstats[name]
+        elif name == "rms_energy":
+            res[name] = rms_energy(y, frame_length=frame_length, hop_length=hop_length, center=center)
+        elif name == "zero_crossing_rate":
+            res[name] = zero_crossing_rate(y, frame_length, hop_length, center)
+        elif name in SPECTRUM_FEATURES:
             if per_frame_loop:
                 fn = {"spectral_centroid": spectral_centroid, "spectral_bandwidth": spectral_bandwidth,
                       "spectral_flatness": spectral_flatness, "spectral_rolloff": spectral_rolloff,

@@ -25,10 +25,12 @@ _SPECTRUM_BASED = ("spectral_centroid", "spectral_bandwidth", "spectral_flatness
                    "dominant_frequency")
 _SPECTROGRAM_BASED = ("spectral_contrast",)
 _MELSPEC_BASED = ("mfcc",)
-# names the reference knows (manager.py:38-69); those not listed above are not offloaded yet
-_REFERENCE_ONLY = ("mean_amplitude", "std_dev_amplitude", "skewness", "kurtosis", "peak_amplitude", "crest_factor",
-                   "signal_entropy", "zero_crossing_rate", "rms_energy", "hnr", "jitter", "shimmer")
-_DEVICE_FEATURES = set(_SPECTRUM_BASED) | set(_SPECTROGRAM_BASED) | set(_MELSPEC_BASED)
+# time-domain frame features (time_domain.py) + RMS / ZCR (audio/features.py): one device launch for all of them
+_FRAME_BASED = ("mean_amplitude", "std_dev_amplitude", "skewness", "kurtosis", "peak_amplitude", "crest_factor",
+                "signal_entropy", "zero_crossing_rate", "rms_energy")
+# names the reference knows (manager.py:38-69) that are not offloaded (pitch-based placeholders)
+_REFERENCE_ONLY = ("hnr", "jitter", "shimmer")
+_DEVICE_FEATURES = set(_SPECTRUM_BASED) | set(_SPECTROGRAM_BASED) | set(_MELSPEC_BASED) | set(_FRAME_BASED)
 _ALL_KNOWN_FEATURES = _DEVICE_FEATURES | set(_REFERENCE_ONLY)
 
 
@@ -100,9 +102,19 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     if want_contrast:
         cplan = T.contrast_plan(freqs, sr, cp.get("n_bands", 6), cp.get("fmin", 200.0), cp.get("quantile", 0.02))
 
+    tstats = None
+    want_time = [f for f in features if f in _FRAME_BASED]
+    if want_time:
+        from .time_domain import time_features_frames
+        nb = int(feature_params.get("signal_entropy", {}).get("num_bins", 10))
+        tstats = time_features_frames(yd, frame_length, hop_length, center, nb, want_time)
+    need_stft = bool(want_stats or want_contrast or want_mfcc)
+
     mel = stats = cpv = None
     try:
-        if frame_length == 2048 and power == 2.0 and n_mels <= 16 * ops.fused_waves():
+        if not need_stft:
+            pass
+        elif frame_length == 2048 and power == 2.0 and n_mels <= 16 * ops.fused_waves():
             mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
                                                fmin, fmax, want_stats, roll, bw_p, cplan)
         else:
@@ -131,7 +143,9 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     for name in features:
         if name in res:
             continue
-        if name in _SPECTRUM_BASED:
+        if name in _FRAME_BASED:
+            res[name] = host(tstats[name])
+        elif name in _SPECTRUM_BASED:
             if name == "spectral_centroid":
                 res[name] = host(stats[:, 0])
             elif name == "spectral_bandwidth":

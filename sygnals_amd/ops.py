@@ -400,6 +400,41 @@ def spectral_stats(mag: torch.Tensor, freqs: torch.Tensor, roll_percent: float =
     return out
 
 
+FS_ROWS = ("mean_amplitude", "std_dev_amplitude", "skewness", "kurtosis", "peak_amplitude", "crest_factor",
+           "signal_entropy", "rms_energy", "zero_crossing_rate")      # row r <-> mask bit r of syg_frame_stats_f32
+
+
+def frame_stats(y: torch.Tensor, frame_length: int = 2048, hop: int = 512, center: bool = True, num_bins: int = 10,
+                mask: int = 0x1FF) -> torch.Tensor:
+    """Time-domain frame features of clips y [B, L]: [B, 9, T] float32, rows as FS_ROWS (only the rows
+    selected by `mask` are written)."""
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    B, L = y.shape
+    Tn = num_frames(L, frame_length, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    out = torch.zeros((B, 9, Tn), dtype=torch.float32, device=y.device)
+    rc = lib().syg_frame_stats_f32(_ptr(y), B, L, _ld(y), int(frame_length), int(hop), int(center), Tn, int(num_bins),
+                                   int(mask), _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_frame_stats_f32")
+    return out
+
+
+def rms_from_spec(S: torch.Tensor, frame_length: int) -> torch.Tensor:
+    """librosa.feature.rms(S=...) for frame-major magnitudes S [N, F] -> [N]."""
+    require_gpu()
+    S = S.contiguous()
+    N, F = S.shape
+    out = torch.empty((N,), dtype=torch.float32, device=S.device)
+    rc = lib().syg_rms_from_spec_f32(_ptr(S), N, F, int(frame_length), _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_rms_from_spec_f32")
+    return out
+
+
 def contrast_pv(mag: torch.Tensor, cplan: np.ndarray) -> torch.Tensor:
     """Peak / valley tail means [2, R, N] of frame-major magnitudes mag [N, F]."""
     require_gpu()

@@ -83,9 +83,14 @@ class SygnalsAmdPlugin(_Base):
             registry.add_transform(fn.__name__, fn)
 
     def register_feature_extractors(self, registry):
-        from ..core.features import cepstral, frequency_domain as fd, manager
+        from ..core.audio import features as af
+        from ..core.features import cepstral, frequency_domain as fd, manager, time_domain as td
         for name, fn in fd.FREQUENCY_DOMAIN_FEATURES.items():
             registry.add_feature(name, fn)
+        for name, fn in td.TIME_DOMAIN_FEATURES.items():
+            registry.add_feature(name, fn)
+        registry.add_feature("zero_crossing_rate", af.zero_crossing_rate)
+        registry.add_feature("rms_energy", af.rms_energy)
         registry.add_feature("spectral_contrast", fd.spectral_contrast)
         registry.add_feature("mfcc", cepstral.mfcc)
         registry.add_feature("extract_features", manager.extract_features)

@@ -8,6 +8,7 @@ What is executed: the SciPy/NumPy-backed functions of
   sygnals/core/filters.py                      (loads as-is)
   sygnals/core/dsp.py                          (compute_fft/ifft, apply_window, compute_psd_welch)
   sygnals/core/features/frequency_domain.py    (the five per-frame functions)
+  sygnals/core/features/time_domain.py         (the seven per-frame functions; loads as-is)
 loaded BY FILE PATH (``sygnals/core/__init__.py`` pulls pandasql/soundfile,
 which are not installed).  dsp.py and frequency_domain.py have a top-level
 ``import librosa``; librosa is not installed, so an EMPTY placeholder module is
@@ -134,6 +135,35 @@ def main():
     g["empty"] = np.array([fd.spectral_centroid(e, e), fd.spectral_bandwidth(e, e), fd.spectral_flatness(e),
                            fd.spectral_rolloff(e, e), fd.dominant_frequency(e, e)])
     np.savez_compressed(os.path.join(OUT, "ref_freq.npz"), **g)
+
+    # ---- time_domain.py -------------------------------------------------
+    td = load("ref_time", "features/time_domain.py")
+    g = {}
+    N = 512
+    frames = rng.normal(0, 0.3, (20, N))
+    frames[1] = 0.0                                   # all-zero frame
+    frames[2] = 0.25                                  # constant
+    frames[3] = np.sin(2 * np.pi * 5 * np.arange(N) / N)
+    frames[4] = np.sign(frames[3])                    # square wave
+    frames[5] = np.abs(frames[5]) ** 3                # strongly skewed
+    frames[6] = frames[6] + 2.0                       # large offset
+    frames[7] = 0.0; frames[7, 17] = 1.0              # impulse
+    frames[8] = np.round(frames[8] * 4) / 4           # few distinct values (histogram edges hit exactly)
+    frames[9] = np.linspace(-1.0, 1.0, N)             # uniform ramp: samples on histogram bin edges
+    frames[10] *= 1e-7                                # tiny but non-zero
+    frames = frames.astype(np.float32).astype(np.float64)   # fp32-representable: the device sees the same values
+    g["frames"] = frames
+    names = ["mean_amplitude", "std_dev_amplitude", "skewness", "kurtosis", "peak_amplitude", "crest_factor",
+             "signal_entropy"]
+    for nm in names:
+        g[nm] = np.array([td.TIME_DOMAIN_FEATURES[nm](f) for f in frames])
+    g["signal_entropy_b4"] = np.array([td.signal_entropy(f, num_bins=4) for f in frames])
+    g["signal_entropy_b32"] = np.array([td.signal_entropy(f, num_bins=32) for f in frames])
+    short = [np.array([], dtype=np.float64), np.array([0.5]), np.array([0.5, -0.25]), np.array([0.1, 0.2, 0.4])]
+    for i, f in enumerate(short):
+        g[f"short{i}"] = f
+        g[f"short{i}_out"] = np.array([td.TIME_DOMAIN_FEATURES[nm](f) for nm in names])
+    np.savez_compressed(os.path.join(OUT, "ref_time.npz"), **g)
     print("golden vectors written to", OUT)
 
 

@@ -1,0 +1,89 @@
+"""GPU parity of the time-domain frame features against the oracle and the reference's golden vectors.
+Calls go through the C ABI (sygnals_amd.ops -> libsygnals_hip.so: syg_frame_stats_f32, syg_rms_from_spec_f32)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import cpu_ref as O
+from tests.gpu_util import assert_parity
+
+TOL = 1e-5
+G = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = ["mean_amplitude", "std_dev_amplitude", "skewness", "kurtosis", "peak_amplitude", "crest_factor",
+         "signal_entropy"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sygnals_amd import ops
+    ops.require_gpu()
+    return ops
+
+
+def test_frames_match_reference_golden(ops):
+    """Every frame of the reference's golden set as one 512-sample clip (center=False -> exactly one frame)."""
+    g = np.load(os.path.join(G, "ref_time.npz"))
+    fr = g["frames"]
+    st = ops.frame_stats(ops.to_device_f32(fr), 512, 512, False).cpu().numpy().astype(np.float64)
+    assert st.shape == (fr.shape[0], 9, 1)
+    for r, nm in enumerate(NAMES):
+        assert_parity(st[:, r, 0], g[nm], TOL, nm)
+    for nb in (4, 32):
+        s2 = ops.frame_stats(ops.to_device_f32(fr), 512, 512, False, num_bins=nb, mask=64).cpu().numpy()
+        assert_parity(s2[:, 6, 0].astype(np.float64), g[f"signal_entropy_b{nb}"], TOL, f"entropy bins={nb}")
+
+
+@pytest.mark.parametrize("L,flen,hop,center", [(48000, 2048, 512, True), (5000, 1024, 256, True),
+                                               (4999, 400, 160, False), (700, 2048, 512, True), (3000, 63, 17, True)])
+def test_framed_clips_match_oracle(ops, L, flen, hop, center):
+    Y = O.synth_clips(3, L, 16000, seed=L + flen)
+    Y[1] += 0.2                                   # an offset clip: mean != 0 in every frame
+    st = ops.frame_stats(ops.to_device_f32(Y), flen, hop, center).cpu().numpy().astype(np.float64)
+    for b in range(Y.shape[0]):
+        y = Y[b].astype(np.float64)
+        ref = O.time_features_frames(y, flen, hop, center)
+        for r, nm in enumerate(NAMES):
+            assert_parity(st[b, r], ref[nm], TOL, f"{nm} clip {b}")
+        assert_parity(st[b, 7], O.rms_energy(y, frame_length=flen, hop_length=hop, center=center), TOL, "rms")
+        z = O.zero_crossing_rate(y, flen, hop, center)
+        assert np.array_equal(np.round(st[b, 8] * flen), np.round(z * flen)), "zero-crossing counts must be identical"
+
+
+def test_mask_selects_rows_and_single_frame_mirror(ops):
+    from sygnals_amd.core.features import time_domain as td
+    from sygnals_amd.core.audio import features as af
+    y = O.synth_clips(1, 8000, 16000, seed=3)[0].astype(np.float64)
+    st = ops.frame_stats(ops.to_device_f32(y[None, :]), 1024, 256, True, mask=(1 << 2) | (1 << 7)).cpu().numpy()
+    assert np.all(st[0, [0, 1, 3, 4, 5, 6, 8]] == 0.0) and np.any(st[0, 2] != 0.0) and np.all(st[0, 7] > 0.0)
+    f = y[1000:1512]
+    for nm, fn in td.TIME_DOMAIN_FEATURES.items():
+        assert abs(fn(f) - O._TIME_FUNCS[nm](f)) <= TOL * max(1.0, abs(O._TIME_FUNCS[nm](f))), nm
+    e = np.array([], dtype=np.float64)
+    assert all(fn(e) == 0.0 for fn in td.TIME_DOMAIN_FEATURES.values())
+    assert td.skewness(np.array([1.0])) == 0.0 and td.kurtosis_val(np.array([1.0, 2.0, 4.0])) == 0.0
+    assert td.signal_entropy(np.ones(64)) == 0.0 and td.crest_factor(np.zeros(64)) == 0.0
+    assert_parity(af.rms_energy(y, frame_length=1024, hop_length=256), O.rms_energy(y, frame_length=1024, hop_length=256),
+                  TOL, "rms mirror")
+    assert_parity(af.zero_crossing_rate(y, 1024, 256), O.zero_crossing_rate(y, 1024, 256), TOL, "zcr mirror")
+    S = np.abs(O.stft(y, 1024, 256, window="hann"))
+    assert_parity(af.rms_energy(S=S, frame_length=1024), O.rms_energy(S=S, frame_length=1024), TOL, "rms from S")
+    with pytest.raises(ValueError):
+        af.rms_energy()
+    with pytest.raises(ValueError):
+        af.zero_crossing_rate(np.zeros((2, 8)))
+
+
+def test_manager_extracts_time_and_spectral_rows_together(ops):
+    from sygnals_amd.core.features.manager import extract_features
+    y = O.synth_clips(1, 16000, 16000, seed=9)[0].astype(np.float64)
+    feats = ["rms_energy", "zero_crossing_rate", "skewness", "signal_entropy", "spectral_centroid", "mfcc"]
+    out = extract_features(y, 16000, feats, output_format="dict_of_arrays", feature_params={"mfcc": {"n_mels": 40}})
+    ref = O.extract_features(y, 16000, feats, feature_params={"mfcc": {"n_mels": 40}})
+    assert set(out) == set(ref)
+    for k in ref:
+        assert out[k].dtype == np.float64 and out[k].shape == ref[k].shape
+        assert_parity(out[k], ref[k], TOL, k)

@@ -146,3 +146,40 @@ def test_vectorised_stats_match_per_frame(gq):
     assert_allclose(st["spectral_flatness"], gq["flatness"], rtol=1e-12, atol=1e-15)
     assert_array_equal(st["spectral_rolloff"], gq["rolloff85"])
     assert_array_equal(st["dominant_frequency"], gq["dominant"])
+
+
+# ---------------------------------------------------------------- time-domain frame features
+def _time_golden():
+    return np.load(os.path.join(G, "ref_time.npz"))
+
+
+@pytest.mark.parametrize("name", ["mean_amplitude", "std_dev_amplitude", "skewness", "kurtosis", "peak_amplitude",
+                                  "crest_factor", "signal_entropy"])
+def test_time_domain_functions_match_reference(name):
+    g = _time_golden()
+    out = np.array([O._TIME_FUNCS[name](f) for f in g["frames"]])
+    np.testing.assert_allclose(out, g[name], rtol=1e-12, atol=1e-13)
+
+
+def test_time_domain_entropy_bins_and_short_frames():
+    g = _time_golden()
+    for nb in (4, 32):
+        out = np.array([O.signal_entropy(f, nb) for f in g["frames"]])
+        np.testing.assert_allclose(out, g[f"signal_entropy_b{nb}"], rtol=1e-12, atol=1e-13)
+    for i in range(4):
+        f = g[f"short{i}"]
+        out = np.array([O._TIME_FUNCS[nm](f) for nm in O.TIME_FEATURES])
+        np.testing.assert_allclose(out, g[f"short{i}_out"], rtol=1e-12, atol=1e-13)
+
+
+def test_time_domain_restatement_agrees_with_scipy_stats():
+    """The explicit moment / histogram formulas against the SciPy / NumPy routines the reference calls."""
+    import scipy.stats
+    rng = np.random.default_rng(5)
+    for n in (5, 64, 2048):
+        f = rng.gamma(2.0, 0.1, n) - 0.1
+        assert abs(O.skewness(f) - scipy.stats.skew(f, bias=False)) < 1e-12
+        assert abs(O.kurtosis_val(f) - scipy.stats.kurtosis(f, fisher=True, bias=False)) < 1e-11
+        c, _ = np.histogram(f, bins=10)
+        assert np.array_equal(O.histogram_counts(f, 10), c)
+        assert abs(O.signal_entropy(f) - scipy.stats.entropy(c[c > 0] / n)) < 1e-13

@@ -216,3 +216,29 @@ def test_cqt_plan_schedule():
     with pytest.raises(ValueError, match="multiple of 2"):
         O.cqt_plan(48000, hop_length=48)
     assert abs(O.note_c1_hz() - 32.70319566257483) < 1e-12
+
+
+# ---------------------------------------------------------------- RMS / ZCR restatement (librosa: unpinned)
+def test_rms_known_answers():
+    sr, n = 16000, 8192
+    y = 0.5 * np.sin(2 * np.pi * 1000 * np.arange(n) / sr)
+    r = O.rms_energy(y, frame_length=2048, hop_length=512, center=True)
+    assert r.shape == (1 + n // 512,)
+    assert np.allclose(r[4:-4], 0.5 / np.sqrt(2), rtol=1e-3)             # interior frames: A/sqrt(2)
+    assert r[0] < r[4]                                                    # zero padding lowers the edge frames
+    # spectrogram form: Parseval for a rectangular window equals the time-domain RMS of the frame
+    fr = O.frame_signal(y, 2048, 512, False)                               # [T, 2048]
+    S = np.abs(np.fft.rfft(fr, axis=1)).T                                 # [F, T] as librosa
+    assert np.allclose(O.rms_energy(S=S, frame_length=2048), np.sqrt(np.mean(fr ** 2, axis=1)), rtol=1e-12)
+
+
+def test_zcr_known_answers():
+    sr, n = 16000, 8192
+    y = np.sin(2 * np.pi * 500 * np.arange(n) / sr + 0.1)                 # 1000 crossings per second
+    z = O.zero_crossing_rate(y, 2048, 512, True)
+    assert z.shape == (1 + n // 512,)
+    assert np.allclose(z[4:-4], 2 * 500 / sr, atol=1.5 / 2048)
+    assert np.all(O.zero_crossing_rate(np.full(4096, 0.3), 1024, 256, True) == 0.0)     # edge padding: no crossing
+    assert np.all(O.zero_crossing_rate(np.full(4096, 1e-11) * np.resize([1, -1], 4096), 1024, 256) == 0.0)  # under threshold
+    alt = np.resize([1.0, -1.0], 1024)
+    assert O.zero_crossing_rate(alt, 1024, 1024, False)[0] == 1023 / 1024  # first sample never counts
