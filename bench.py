@@ -101,7 +101,7 @@ def main():
     import torch.distributed as dist
     from oracle import cpu_ref as O           # synthetic-input recipe only
     from sygnals_amd import ops
-    from sygnals_amd.distributed import gather_to_root
+    from sygnals_amd.distributed import RootGather
 
     # rehearsal on a 1-GPU box: SYG_BENCH_SAME_GPU=1 puts every rank on cuda:0 and exchanges through gloo
     # (RCCL refuses two ranks on one device); the real multi-GPU run uses one GPU per rank over RCCL
@@ -120,13 +120,22 @@ def main():
     y = ops.to_device_f32(np.tile(base, (B // 64 + 1, 1))[:B])
     n_total = B * world
 
+    # N > 1: every step's MFCC block is gathered to rank 0 (the only exchange of the path).  The gather
+    # of step k is asynchronous and overlaps the kernel of step k+1; all gathers are finished inside the timed
+    # region.
+    T_frames = 1 + L // HOP
+    gat = RootGather(n_total, (B, N_MFCC, T_frames), torch.float32, "cpu" if same_gpu else torch.device("cuda", dev_index))
+
     def step():
         out = ops.mfcc_batch(y, SR, N_FFT, HOP, N_MELS, N_MFCC)
         if world > 1:
-            out = gather_to_root(out.cpu() if same_gpu else out, n_total, 0)
+            gat.finish()                               # (the previous step's gather; a stream-side wait)
+            gat.start(out.cpu() if same_gpu else out)
         return out
 
     def sync():
+        if world > 1:
+            gat.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -70,3 +70,54 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def _pipeline_worker(rank, world, port, n_total, steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sygnals_amd.distributed import RootGather, shard_range
+    lo, hi = shard_range(n_total, rank, world)
+    gat = RootGather(n_total, (hi - lo, 3, 5), torch.float32, "cpu", dst=0)
+    got = []
+    for k in range(steps):                      # bench.py's loop shape: compute k, finish k-1, start k
+        block = (torch.arange(lo, hi, dtype=torch.float32)[:, None, None] * 1000 + k) * torch.ones(1, 3, 5)
+        prev = gat.finish()
+        if prev is not None:
+            got.append(prev.clone())
+        gat.start(block)
+    last = gat.finish()
+    if last is not None:
+        got.append(last.clone())
+    q.put((rank, [g.numpy() for g in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [6, 7])
+def test_two_rank_pipelined_gather(n_total):
+    """RootGather: one asynchronous gather in flight, double-buffered receive side, even and uneven shards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    steps = 5
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, n_total, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] == []                                        # only the root assembles results
+    assert len(res[0]) == steps
+    for k, g in enumerate(res[0]):
+        want = (np.arange(n_total, dtype=np.float32)[:, None, None] * 1000 + k) * np.ones((1, 3, 5), np.float32)
+        assert g.shape == want.shape and np.array_equal(g, want), f"step {k}"
+
+
+def test_root_gather_single_process_passthrough():
+    from sygnals_amd.distributed import RootGather
+    gat = RootGather(4, (4, 2), torch.float32, "cpu")
+    x = torch.arange(8, dtype=torch.float32).reshape(4, 2)
+    gat.start(x)
+    assert gat.finish() is x and gat.finish() is None
