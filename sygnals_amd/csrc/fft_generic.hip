@@ -274,7 +274,14 @@ int set_lds(const void* fn, size_t bytes, const char* what) {
   return SYG_OK;
 }
 
-constexpr int WELCH_NBLK = 64;
+// Partial-sum workgroups per stream: enough of them to fill the chip whatever the batch (a single one-hour stream
+// -- config C5 -- gets 1024, a batch of 1024 clips 16 each); block j sums the segments j, j + nblk, ...
+__host__ int welch_nblk(int64_t B) {
+  int64_t n = 4096 / B;
+  if (n < 16) n = 16;
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
 
 }  // namespace
 }  // namespace syg
@@ -344,7 +351,7 @@ extern "C" int syg_mel_dense_f32(const float* P, int64_t B, int64_t T, int F, co
 
 extern "C" int64_t syg_welch_work_bytes(int64_t B, int nfft) {
   if (B < 1 || nfft < 2) return -1;
-  return B * (int64_t)WELCH_NBLK * (nfft / 2 + 1) * (int64_t)sizeof(float);
+  return B * (int64_t)welch_nblk(B) * (nfft / 2 + 1) * (int64_t)sizeof(float);
 }
 
 extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg, int step, int nfft,
@@ -363,11 +370,13 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
   int rc = set_lds((const void*)welch_partial_kernel, lds, "welch");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(welch_partial_kernel, dim3(WELCH_NBLK, (unsigned)B), dim3(WELCH_NT), lds, st, x, L, ldx, nperseg,
+  int nblk = welch_nblk(B);
+  if ((int64_t)nblk > nseg) nblk = (int)nseg;
+  hipLaunchKernelGGL(welch_partial_kernel, dim3(nblk, (unsigned)B), dim3(WELCH_NT), lds, st, x, L, ldx, nperseg,
                      step, nfft, nseg, window, (const float2*)twiddle, detrend, (float*)work);
   SYG_CHECK_LAUNCH("welch_partial");
   hipLaunchKernelGGL(welch_final_kernel, dim3((F + 255) / 256, (unsigned)B), dim3(256), 0, st, (const float*)work,
-                     WELCH_NBLK, F, nseg, scale, 0, psd_out);
+                     nblk, F, nseg, scale, 0, psd_out);
   SYG_CHECK_LAUNCH("welch_final");
   return SYG_OK;
 }
