@@ -34,27 +34,24 @@ struct SosParams {
   double apow[MAXD * MAXD];  // A^CS, row-major D x D (padded to MAXD)
 };
 
-// ---- pass 0: odd extension, zero tail up to nch*CS
-__global__ void ext_kernel(const float* __restrict__ x, int64_t L, int64_t ldx, int pad, int64_t lext, int64_t lpad,
-                           float* __restrict__ e) {
-  const int64_t b = blockIdx.y;
-  const float* xb = x + b * ldx;
-  float* eb = e + b * lpad;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < lpad; i += (int64_t)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    if (i < pad) v = 2.f * xb[0] - xb[pad - i];
-    else if (i < pad + L) v = xb[i - pad];
-    else if (i < lext) v = 2.f * xb[L - 1] - xb[L - 2 - (i - pad - L)];
-    eb[i] = v;
-  }
+// Sample i of the odd-extended, zero-tailed signal (scipy's padtype='odd'): read straight from the clip, so the
+// forward sweep needs no extended copy in HBM.
+__device__ __forceinline__ float ext_at(const float* __restrict__ xb, int64_t L, int pad, int64_t lext, int64_t i) {
+  if (i < pad) return 2.f * xb[0] - xb[pad - i];
+  if (i < pad + L) return xb[i - pad];
+  if (i < lext) return 2.f * xb[L - 1] - xb[L - 2 - (i - pad - L)];
+  return 0.f;
 }
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 
 // ---- pass A / C
 // MODE 0: zero-state pass, writes end states.  MODE 1: true pass, output reversed into `dst`
 // (dst[lext-1-i]).  MODE 2: true pass, output reversed and trimmed into y[b, n], n = lext-1-pad-i.
-template <int S, int MODE>
-__global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in, int64_t lpad, int nch, int64_t lext,
-                                                   SosParams P, const double* __restrict__ init,
+// SRCX: the input is the clip itself, odd-extended on the fly (forward sweep; `in` = x, row stride `ldin`);
+// otherwise a [B, lpad] work buffer (backward sweep).
+template <int S, int MODE, bool SRCX>
+__global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in, int64_t ldin, int64_t lpad, int nch,
+                                                   int64_t lext, SosParams P, const double* __restrict__ init,
                                                    double* __restrict__ zs, float* __restrict__ dst, int64_t lddst,
                                                    int pad, int64_t L) {
   __shared__ float tile[TS * TSTRIDE];
@@ -62,7 +59,7 @@ __global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in,
   const int64_t b = blockIdx.y;
   const int c0 = blockIdx.x * 64;
   const int c = c0 + lane;
-  const float* inb = in + b * lpad;
+  const float* inb = in + b * ldin;
   double z0[S], z1[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) { z0[s] = 0.0; z1[s] = 0.0; }
@@ -77,7 +74,18 @@ __global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in,
     for (int r = 0; r < 8; ++r) {
       const int ch = r * 8 + (lane >> 3), part = lane & 7;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + ch < nch) v = *reinterpret_cast<const float4*>(inb + (int64_t)(c0 + ch) * CS + j0 + 4 * part);
+      if (c0 + ch < nch) {
+        const int64_t i0 = (int64_t)(c0 + ch) * CS + j0 + 4 * part;
+        if (!SRCX) {
+          v = *reinterpret_cast<const float4*>(inb + i0);
+        } else if (i0 >= pad && i0 + 3 < pad + L) {
+          const f4u u4 = *reinterpret_cast<const f4u*>(inb + (i0 - pad));
+          v = make_float4(u4.x, u4.y, u4.z, u4.w);
+        } else {
+          v = make_float4(ext_at(inb, L, pad, lext, i0), ext_at(inb, L, pad, lext, i0 + 1),
+                          ext_at(inb, L, pad, lext, i0 + 2), ext_at(inb, L, pad, lext, i0 + 3));
+        }
+      }
       tile[(4 * part + 0) * TSTRIDE + ch] = v.x;
       tile[(4 * part + 1) * TSTRIDE + ch] = v.y;
       tile[(4 * part + 2) * TSTRIDE + ch] = v.z;
@@ -122,11 +130,32 @@ __global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in,
   }
 }
 
-// ---- pass B: 16 lanes per clip; lane r carries state component r
-template <int S>
-__global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in, int64_t lpad, int nch, int64_t B,
+// ---- pass B: 16 lanes per clip (one DPP row); lane r carries state component r.  The state vector is broadcast
+// inside the row with DPP row_newbcast (two 32-bit moves per double) instead of ds_bpermute, and the zero-state
+// end states of the next chunks are loaded four steps ahead of the serial chain.
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+  const uint64_t u = (uint64_t)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, 0x150 + J, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), 0x150 + J, 0xF, 0xF, false);
+  return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+template <int D, int J>
+struct RowDot {
+  static __device__ __forceinline__ double run(const double (&arow)[D], double s, double acc) {
+    acc = fma(arow[J], row_bcast<J>(s), acc);
+    return RowDot<D, J + 1>::run(arow, s, acc);
+  }
+};
+template <int D>
+struct RowDot<D, D> {
+  static __device__ __forceinline__ double run(const double (&)[D], double, double acc) { return acc; }
+};
+
+template <int S, bool SRCX>
+__global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in, int64_t ldin, int nch, int64_t B,
                                                    SosParams P, const double* __restrict__ zs,
-                                                   double* __restrict__ init) {
+                                                   double* __restrict__ init, int pad, int64_t L, int64_t lext) {
   constexpr int D = 2 * S;
   const int r = threadIdx.x & 15;
   const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -145,15 +174,28 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in,
 #pragma unroll
   for (int rr = 0; rr < D; ++rr)
     if (r == rr) zi = P.zi[rr];
-  double s = zi * (double)in[bb * lpad];
-  for (int c = 0; c < nch; ++c) {
-    const int64_t off = ((int64_t)bb * nch + c) * D + (r < D ? r : 0);
-    if (live) init[off] = s;
-    const double z = live ? zs[off] : 0.0;
-    double acc = z;
+  const float first = SRCX ? ext_at(in + bb * ldin, L, pad, lext, 0) : in[bb * ldin];
+  double s = zi * (double)first;
+  const int rc = (r < D) ? r : 0;
+  const double* zp = zs + (int64_t)bb * nch * D + rc;
+  double* ip = init + (int64_t)bb * nch * D + rc;
+  constexpr int AHEAD = 4;
+  double zq[AHEAD];
 #pragma unroll
-    for (int j = 0; j < D; ++j) acc = fma(arow[j], __shfl(s, j, 16), acc);
-    s = acc;
+  for (int k = 0; k < AHEAD; ++k) zq[k] = (live && k < nch) ? zp[(int64_t)k * D] : 0.0;
+  for (int c0 = 0; c0 < nch; c0 += AHEAD) {
+    double zn[AHEAD];
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) zn[k] = (live && c0 + AHEAD + k < nch) ? zp[(int64_t)(c0 + AHEAD + k) * D] : 0.0;
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) {
+      if (c0 + k < nch) {
+        if (live) ip[(int64_t)(c0 + k) * D] = s;
+        s = RowDot<D, 0>::run(arow, s, zq[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) zq[k] = zn[k];
   }
 }
 
@@ -174,28 +216,24 @@ int launch_all(const float* x, int64_t B, int64_t L, int64_t ldx, const SosParam
   const int64_t lext = L + 2 * (int64_t)pad;
   const int nch = (int)((lext + CS - 1) / CS);
   const int64_t lpad = (int64_t)nch * CS;
-  float* E = (float*)work;
-  float* G = E + B * lpad;
+  float* G = (float*)work;                      // forward output, reversed: [B, lpad]
   double* zs = (double*)(G + B * lpad);
   double* init = zs + B * (int64_t)nch * (2 * S);
-  dim3 gext((unsigned)((lpad + 255) / 256 > 1024 ? 1024 : (lpad + 255) / 256), (unsigned)B);
-  hipLaunchKernelGGL(ext_kernel, gext, dim3(256), 0, st, x, L, ldx, pad, lext, lpad, E);
-  SYG_CHECK_LAUNCH("sosfiltfilt ext");
   dim3 gch((unsigned)((nch + 63) / 64), (unsigned)B), gsc((unsigned)((B + 15) / 16));
-  // forward sweep
-  hipLaunchKernelGGL((chunk_kernel<S, 0>), gch, dim3(64), 0, st, (const float*)E, lpad, nch, lext, P,
+  // forward sweep: reads the clip (odd extension on the fly), writes G
+  hipLaunchKernelGGL((chunk_kernel<S, 0, true>), gch, dim3(64), 0, st, x, ldx, lpad, nch, lext, P,
                      (const double*)nullptr, zs, (float*)nullptr, (int64_t)0, pad, L);
-  hipLaunchKernelGGL((scan_kernel<S>), gsc, dim3(256), 0, st, (const float*)E, lpad, nch, B, P, (const double*)zs,
-                     init);
-  hipLaunchKernelGGL((chunk_kernel<S, 1>), gch, dim3(64), 0, st, (const float*)E, lpad, nch, lext, P,
+  hipLaunchKernelGGL((scan_kernel<S, true>), gsc, dim3(256), 0, st, x, ldx, nch, B, P, (const double*)zs, init, pad, L,
+                     lext);
+  hipLaunchKernelGGL((chunk_kernel<S, 1, true>), gch, dim3(64), 0, st, x, ldx, lpad, nch, lext, P,
                      (const double*)init, (double*)nullptr, G, lpad, pad, L);
   SYG_CHECK_LAUNCH("sosfiltfilt forward");
-  // backward sweep (G holds the forward output reversed; its tail [lext, lpad) was zeroed by ext on E only)
-  hipLaunchKernelGGL((chunk_kernel<S, 0>), gch, dim3(64), 0, st, (const float*)G, lpad, nch, lext, P,
+  // backward sweep: G[.., lext..lpad) is never written by the forward pass and must read as zero
+  hipLaunchKernelGGL((chunk_kernel<S, 0, false>), gch, dim3(64), 0, st, (const float*)G, lpad, lpad, nch, lext, P,
                      (const double*)nullptr, zs, (float*)nullptr, (int64_t)0, pad, L);
-  hipLaunchKernelGGL((scan_kernel<S>), gsc, dim3(256), 0, st, (const float*)G, lpad, nch, B, P, (const double*)zs,
-                     init);
-  hipLaunchKernelGGL((chunk_kernel<S, 2>), gch, dim3(64), 0, st, (const float*)G, lpad, nch, lext, P,
+  hipLaunchKernelGGL((scan_kernel<S, false>), gsc, dim3(256), 0, st, (const float*)G, lpad, nch, B, P,
+                     (const double*)zs, init, pad, L, lext);
+  hipLaunchKernelGGL((chunk_kernel<S, 2, false>), gch, dim3(64), 0, st, (const float*)G, lpad, lpad, nch, lext, P,
                      (const double*)init, (double*)nullptr, y, ldy, pad, L);
   SYG_CHECK_LAUNCH("sosfiltfilt backward");
   return SYG_OK;
@@ -210,7 +248,7 @@ extern "C" int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, 
   if (B < 1 || L < 1 || padlen < 0 || n_sections < 1 || n_sections > MAXS) return -1;
   const int64_t lext = L + 2 * (int64_t)padlen;
   const int64_t nch = (lext + CS - 1) / CS;
-  return 2 * B * nch * CS * (int64_t)sizeof(float) + 2 * B * nch * 2 * n_sections * (int64_t)sizeof(double);
+  return B * nch * CS * (int64_t)sizeof(float) + 2 * B * nch * 2 * n_sections * (int64_t)sizeof(double);
 }
 
 extern "C" int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const double* sos_host,
