@@ -68,29 +68,39 @@ __global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in,
 #pragma unroll
     for (int s = 0; s < S; ++s) { z0[s] = ip[2 * s]; z1[s] = ip[2 * s + 1]; }
   }
-  for (int j0 = 0; j0 < CS; j0 += TS) {
-    // cooperative coalesced load: 8 lanes x float4 cover one chunk's 32 samples
+  // cooperative coalesced load of one 64-chunk x 32-sample tile: 8 lanes x float4 cover one chunk's 32 samples.
+  // The loads of tile k+1 are issued before the recurrence over tile k starts, so their latency hides behind it.
+  auto load_tile = [&](int j0, float4 (&v)[8]) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int ch = r * 8 + (lane >> 3), part = lane & 7;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c0 + ch < nch) {
         const int64_t i0 = (int64_t)(c0 + ch) * CS + j0 + 4 * part;
         if (!SRCX) {
-          v = *reinterpret_cast<const float4*>(inb + i0);
+          v[r] = *reinterpret_cast<const float4*>(inb + i0);
         } else if (i0 >= pad && i0 + 3 < pad + L) {
           const f4u u4 = *reinterpret_cast<const f4u*>(inb + (i0 - pad));
-          v = make_float4(u4.x, u4.y, u4.z, u4.w);
+          v[r] = make_float4(u4.x, u4.y, u4.z, u4.w);
         } else {
-          v = make_float4(ext_at(inb, L, pad, lext, i0), ext_at(inb, L, pad, lext, i0 + 1),
-                          ext_at(inb, L, pad, lext, i0 + 2), ext_at(inb, L, pad, lext, i0 + 3));
+          v[r] = make_float4(ext_at(inb, L, pad, lext, i0), ext_at(inb, L, pad, lext, i0 + 1),
+                             ext_at(inb, L, pad, lext, i0 + 2), ext_at(inb, L, pad, lext, i0 + 3));
         }
       }
-      tile[(4 * part + 0) * TSTRIDE + ch] = v.x;
-      tile[(4 * part + 1) * TSTRIDE + ch] = v.y;
-      tile[(4 * part + 2) * TSTRIDE + ch] = v.z;
-      tile[(4 * part + 3) * TSTRIDE + ch] = v.w;
     }
+  };
+  float4 nxt[8];
+  load_tile(0, nxt);
+  for (int j0 = 0; j0 < CS; j0 += TS) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int ch = r * 8 + (lane >> 3), part = lane & 7;
+      tile[(4 * part + 0) * TSTRIDE + ch] = nxt[r].x;
+      tile[(4 * part + 1) * TSTRIDE + ch] = nxt[r].y;
+      tile[(4 * part + 2) * TSTRIDE + ch] = nxt[r].z;
+      tile[(4 * part + 3) * TSTRIDE + ch] = nxt[r].w;
+    }
+    if (j0 + TS < CS) load_tile(j0 + TS, nxt);
     __syncthreads();
 #pragma unroll 4
     for (int j = 0; j < TS; ++j) {
