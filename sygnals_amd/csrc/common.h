@@ -72,6 +72,84 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     bfly4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3], v[q], v[q + 4], v[q + 8], v[q + 12]);
 }
 
+// In-register forward 8-point DFT, natural order in and out (radix-2 x radix-4).
+__device__ __forceinline__ void dft8(float2 (&a)[8]) {
+  constexpr float R = 0.70710678118654752440f;
+  float2 e0, e1, e2, e3, o0, o1, o2, o3;
+  bfly4(a[0], a[2], a[4], a[6], e0, e1, e2, e3);
+  bfly4(a[1], a[3], a[5], a[7], o0, o1, o2, o3);
+  const float2 t1 = make_float2(R * (o1.x + o1.y), R * (o1.y - o1.x));      // W_8^1 o1
+  const float2 t2 = mul_mi(o2);                                             // W_8^2 o2
+  const float2 t3 = make_float2(R * (o3.y - o3.x), -R * (o3.x + o3.y));     // W_8^3 o3
+  a[0] = cadd(e0, o0); a[4] = csub(e0, o0);
+  a[1] = cadd(e1, t1); a[5] = csub(e1, t1);
+  a[2] = cadd(e2, t2); a[6] = csub(e2, t2);
+  a[3] = cadd(e3, t3); a[7] = csub(e3, t3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stockham autosort FFT of N = 2^m complex points in LDS (ping-pong buffers x, y; N >= 2), shared by the generic
+// FFT / STFT / Welch kernels (a workgroup of `nt` threads) and the CQT (one wave, nt = 64 -- its callers keep
+// all waves of a workgroup on the same trip counts, so the barriers line up).  tw[k] = W_N^k.
+//   * radix-8 passes (8 points per thread in registers) with a radix-4 / radix-2 tail: 4 passes for N = 2048
+//     instead of 6 radix-4/2 ones;
+//   * index arithmetic by shifts (the stride is a power of two);
+//   * the intermediate buffers are XOR-swizzled (i ^ ((i >> 4) & 15)): the stride-8 stores of the early passes
+//     would otherwise hit two LDS banks with every lane; input and result stay in natural order.
+// Returns the buffer that holds the result.
+__device__ __forceinline__ int fft_swz(int i, bool on) { return on ? (i ^ ((i >> 4) & 15)) : i; }
+
+__device__ __forceinline__ float2* block_fft(float2* x, float2* y, int N, const float2* __restrict__ tw, int tid,
+                                             int nt) {
+  int lN = 0;
+  while ((1 << lN) < N) ++lN;
+  const int n8 = lN / 3, tail = lN - 3 * n8;          // radix-8 passes, then a radix-4 (tail 2) or radix-2 (tail 1)
+  const int npass = n8 + (tail ? 1 : 0);
+  int ls = 0, pass = 0;                                // stride s = 1 << ls; sub-length n = N >> ls
+  for (int k = 0; k < n8; ++k, ++pass) {
+    const bool sin = pass > 0, sout = pass < npass - 1;
+    const int s = 1 << ls, q8 = N >> (ls + 3);
+    for (int i = tid; i < (N >> 3); i += nt) {
+      const int p = i >> ls, q = i & (s - 1);
+      float2 a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = x[fft_swz(q + ((p + j * q8) << ls), sin)];
+      dft8(a);
+      const int e = p << ls;                           // W_n^p = W_N^(p s)
+      const int ob = q + ((8 * p) << ls);
+      y[fft_swz(ob, sout)] = a[0];
+#pragma unroll
+      for (int m = 1; m < 8; ++m) y[fft_swz(ob + (m << ls), sout)] = cmul(a[m], tw[m * e]);
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+    ls += 3;
+  }
+  if (tail == 2) {
+    const bool sin = pass > 0;                         // last pass: natural output
+    const int s = 1 << ls;                             // n = 4: p = 0, all twiddles are 1
+    for (int i = tid; i < (N >> 2); i += nt) {
+      float2 o0, o1, o2, o3;
+      bfly4(x[fft_swz(i, sin)], x[fft_swz(i + s, sin)], x[fft_swz(i + 2 * s, sin)], x[fft_swz(i + 3 * s, sin)], o0, o1,
+            o2, o3);
+      y[i] = o0; y[i + s] = o1; y[i + 2 * s] = o2; y[i + 3 * s] = o3;
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+  } else if (tail == 1) {
+    const bool sin = pass > 0;
+    const int s = 1 << ls;                             // n = 2
+    for (int i = tid; i < (N >> 1); i += nt) {
+      const float2 a = x[fft_swz(i, sin)], b = x[fft_swz(i + s, sin)];
+      y[i] = cadd(a, b);
+      y[i + s] = csub(a, b);
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+  }
+  return x;
+}
+
 // Lanes of one wave exchange data through LDS without a workgroup barrier (the LDS executes a wave's
 // DS instructions in order).  To the COMPILER that is a data race: it may assume a lane that did not store
 // re-reads unchanged memory.  This wavefront-scope release/acquire pair emits no instruction but makes every

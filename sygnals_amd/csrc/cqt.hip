@@ -28,38 +28,6 @@ __global__ void decimate2_kernel(const float* __restrict__ x, int64_t L, int64_t
   }
 }
 
-// Stockham radix-4/2 FFT of N complex points by one wave (64 lanes) inside a multi-wave workgroup: every
-// wave runs the same trip counts, so the workgroup barriers line up.
-__device__ float2* wave_block_fft(float2* x, float2* y, int N, const float2* __restrict__ tw, int lane) {
-  int n = N, s = 1;
-  while (n >= 4) {
-    const int q4 = n >> 2;
-    for (int i = lane; i < (N >> 2); i += 64) {
-      const int p = i / s, q = i - p * s;
-      float2 o0, o1, o2, o3;
-      bfly4(x[q + s * p], x[q + s * (p + q4)], x[q + s * (p + 2 * q4)], x[q + s * (p + 3 * q4)], o0, o1, o2, o3);
-      const int e = p * s;
-      y[q + s * (4 * p)] = o0;
-      y[q + s * (4 * p + 1)] = cmul(o1, tw[e]);
-      y[q + s * (4 * p + 2)] = cmul(o2, tw[2 * e]);
-      y[q + s * (4 * p + 3)] = cmul(o3, tw[3 * e]);
-    }
-    __syncthreads();
-    float2* t = x; x = y; y = t;
-    n >>= 2; s <<= 2;
-  }
-  if (n == 2) {
-    for (int i = lane; i < (N >> 1); i += 64) {
-      const float2 a = x[i], b = x[i + s];
-      y[i] = cadd(a, b);
-      y[i + s] = csub(a, b);
-    }
-    __syncthreads();
-    float2* t = x; x = y; y = t;
-  }
-  return x;
-}
-
 __global__ __launch_bounds__(FPW * 64) void cqt_octave_kernel(
     const float* __restrict__ ysig, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
     const float2* __restrict__ tw, const float2* __restrict__ basis, int n_filt, float2* __restrict__ out,
@@ -82,7 +50,7 @@ __global__ __launch_bounds__(FPW * 64) void cqt_octave_kernel(
     xa[m] = make_float2(a, c);
   }
   __syncthreads();
-  float2* Z = wave_block_fft(xa, xb, M, tw + n_fft, lane);
+  float2* Z = block_fft(xa, xb, M, tw + n_fft, lane, 64);   // one wave per frame; all waves run the same trip counts
   for (int k = lane; k <= M; k += 64) {
     const float2 zk = Z[k & (M - 1)], zm = Z[(M - k) & (M - 1)];
     const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);

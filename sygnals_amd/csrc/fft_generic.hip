@@ -1,4 +1,4 @@
-// Generic power-of-two FFT in LDS (Stockham autosort, radix 4 with a radix-2 tail) and the
+// Generic power-of-two FFT in LDS (Stockham autosort, radix 8 with a radix-4/2 tail: block_fft in common.h) and the
 // kernels built on it: batched c2c FFT/IFFT, framed STFT for any power-of-two n_fft, Welch PSD.
 //
 // Reference behaviour reproduced:
@@ -14,39 +14,7 @@ namespace {
 
 constexpr int MAX_N = 8192;
 
-// Forward complex FFT of N points held in LDS buffer `x` (scratch `y`), N a power of two >= 2.
-// tw[k] = W_N^k.  Returns the buffer that holds the result (natural order).
-__device__ float2* block_fft(float2* x, float2* y, int N, const float2* __restrict__ tw, int tid, int nt) {
-  int n = N, s = 1;
-  while (n >= 4) {
-    const int q4 = n >> 2;
-    for (int i = tid; i < (N >> 2); i += nt) {
-      const int p = i / s, q = i - p * s;
-      const float2 a = x[q + s * p], b = x[q + s * (p + q4)], c = x[q + s * (p + 2 * q4)],
-                   d = x[q + s * (p + 3 * q4)];
-      float2 o0, o1, o2, o3;
-      bfly4(a, b, c, d, o0, o1, o2, o3);
-      const int e = p * s;  // W_n^p = W_N^(p*s)
-      y[q + s * (4 * p)] = o0;
-      y[q + s * (4 * p + 1)] = cmul(o1, tw[e]);
-      y[q + s * (4 * p + 2)] = cmul(o2, tw[2 * e]);
-      y[q + s * (4 * p + 3)] = cmul(o3, tw[3 * e]);
-    }
-    __syncthreads();
-    float2* t = x; x = y; y = t;
-    n >>= 2; s <<= 2;
-  }
-  if (n == 2) {
-    for (int i = tid; i < (N >> 1); i += nt) {
-      const float2 a = x[i], b = x[i + s];   // p = 0, q = i, s = N/2
-      y[i] = cadd(a, b);
-      y[i + s] = csub(a, b);
-    }
-    __syncthreads();
-    float2* t = x; x = y; y = t;
-  }
-  return x;
-}
+// (block_fft: common.h)
 
 // Real-input split: Z = FFT_M(z), z[m] = x[2m] + i x[2m+1]; returns X[k], k in [0, M].
 // tw2[k] = W_{2M}^k.
@@ -155,10 +123,21 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
   for (int j = 0; j < WELCH_MAXACC; ++j) acc[j] = 0.f;
   for (int64_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
     const float* seg = xr + sg * (int64_t)step;
+    // one pass over the segment: the samples stay in registers while the mean is reduced, then they are detrended,
+    // windowed and packed (z[m] = x[2m] + i x[2m+1]) into LDS
+    constexpr int PER = (MAX_N / 2 + WELCH_NT - 1) / WELCH_NT;       // packed points per thread (16 at n = 8192)
+    float2 raw[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int m = tid + j * WELCH_NT;
+      const int i0 = 2 * m, i1 = 2 * m + 1;
+      raw[j].x = (m < M && i0 < nperseg) ? seg[i0] : 0.f;
+      raw[j].y = (m < M && i1 < nperseg) ? seg[i1] : 0.f;
+      s += raw[j].x + raw[j].y;
+    }
     float mean = 0.f;
     if (detrend) {
-      float s = 0.f;
-      for (int i = tid; i < nperseg; i += WELCH_NT) s += seg[i];
       s = wave_sum(s);
       if (lane == 0) red[w] = s;
       __syncthreads();
@@ -167,11 +146,15 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
       for (int i = 0; i < WELCH_NT / 64; ++i) s += red[i];
       mean = s / (float)nperseg;
     }
-    for (int m = tid; m < M; m += WELCH_NT) {
-      const int i0 = 2 * m, i1 = 2 * m + 1;
-      const float a = (i0 < nperseg) ? (seg[i0] - mean) * win[i0] : 0.f;
-      const float c = (i1 < nperseg) ? (seg[i1] - mean) * win[i1] : 0.f;
-      xa[m] = make_float2(a, c);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int m = tid + j * WELCH_NT;
+      if (m < M) {
+        const int i0 = 2 * m, i1 = 2 * m + 1;
+        const float a = (i0 < nperseg) ? (raw[j].x - mean) * win[i0] : 0.f;
+        const float c = (i1 < nperseg) ? (raw[j].y - mean) * win[i1] : 0.f;
+        xa[m] = make_float2(a, c);
+      }
     }
     __syncthreads();
     float2* Z = block_fft(xa, xb, M, tw + nfft, tid, WELCH_NT);
@@ -193,13 +176,25 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
   }
 }
 
-__global__ void welch_final_kernel(const float* __restrict__ partial, int nblk, int F, int64_t nseg, double scale,
-                                   int odd_nfft, float* __restrict__ psd) {
+// Combine the per-workgroup partial sums in float64, fixed order: 64 bins x 16 strided sub-sums per workgroup
+// (thread (k, g) adds partials g, g + 16, ...), then the 16 sub-sums of a bin are added in order through LDS.
+constexpr int WF_G = 16;
+__global__ __launch_bounds__(64 * WF_G) void welch_final_kernel(const float* __restrict__ partial, int nblk, int F,
+                                                                 int64_t nseg, double scale, int odd_nfft,
+                                                                 float* __restrict__ psd) {
+  __shared__ double sub[WF_G][64];
   const int64_t b = blockIdx.y;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= F) return;
+  const int kx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kx;
   double s = 0.0;
-  for (int j = 0; j < nblk; ++j) s += (double)partial[((int64_t)b * nblk + j) * F + k];
+  if (k < F)
+    for (int j = g; j < nblk; j += WF_G) s += (double)partial[((int64_t)b * nblk + j) * F + k];
+  sub[g][kx] = s;
+  __syncthreads();
+  if (g != 0 || k >= F) return;
+  s = 0.0;
+#pragma unroll
+  for (int i = 0; i < WF_G; ++i) s += sub[i][kx];
   s = s * scale / (double)nseg;
   if (k > 0 && (odd_nfft || k < F - 1)) s *= 2.0;  // one-sided: double all but DC (and Nyquist)
   psd[b * (int64_t)F + k] = (float)s;
@@ -375,7 +370,7 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
   hipLaunchKernelGGL(welch_partial_kernel, dim3(nblk, (unsigned)B), dim3(WELCH_NT), lds, st, x, L, ldx, nperseg,
                      step, nfft, nseg, window, (const float2*)twiddle, detrend, (float*)work);
   SYG_CHECK_LAUNCH("welch_partial");
-  hipLaunchKernelGGL(welch_final_kernel, dim3((F + 255) / 256, (unsigned)B), dim3(256), 0, st, (const float*)work,
+  hipLaunchKernelGGL(welch_final_kernel, dim3((F + 63) / 64, (unsigned)B), dim3(64 * WF_G), 0, st, (const float*)work,
                      nblk, F, nseg, scale, 0, psd_out);
   SYG_CHECK_LAUNCH("welch_final");
   return SYG_OK;
