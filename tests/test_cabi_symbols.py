@@ -52,6 +52,9 @@ def test_argument_errors_are_reported_without_device_work():
     assert rc == -1 and b"greater than padlen, which is 27" in h.syg_last_error()
     assert h.syg_sosfiltfilt_work_bytes(1024, 48000, 27, 4) > 0
     assert h.syg_sosfiltfilt_work_bytes(1, 100, 9, 9) == -1
-    assert h.syg_welch_work_bytes(8, 4096) == 8 * 64 * 2049 * 4
+    # partial-sum workgroups per stream: clamp(4096 / B, 16, 1024)
+    assert h.syg_welch_work_bytes(8, 4096) == 8 * 512 * 2049 * 4
+    assert h.syg_welch_work_bytes(1, 4096) == 1 * 1024 * 2049 * 4
+    assert h.syg_welch_work_bytes(1024, 256) == 1024 * 16 * 129 * 4
     with pytest.raises(_lib.SygnalsHipError, match="padlen"):
         _lib.check(-1, "x")
