@@ -232,14 +232,16 @@ int syg_rms_from_spec_f32(const float* S, int64_t rows, int F, int frame_length,
  *                       (zero outside the signal) -- the decimation between octaves
  *   syg_cqt_octave_f32  rectangular-window centred STFT frame (n_fft = 2^k <= 4096, hop) of y [B, L],
  *                       times the frequency-domain basis [n_filt, n_fft/2+1] complex64 ->
- *                       out[b * out_bstride + (row0 + f) * T + t] complex64; twiddle as for
+ *                       out[b * out_bstride + (row0 + f) * T + t] complex64; hull_host (host int32
+ *                       [2 * n_filt], may be NULL = dense): first non-zero bin and run length of every
+ *                       basis row (librosa sparsifies the basis; only the run is multiplied); twiddle as for
  *                       syg_stft_pow2_c2c_f32 ([n_fft + n_fft/2] complex)
  * ------------------------------------------------------------------------------- */
 int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const float* taps, int ntaps, float scale,
                       float* y, int64_t ldy, void* stream);
 int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
-                       const float* twiddle, const float* basis, int n_filt, float* out, int64_t out_bstride,
-                       int row0, void* stream);
+                       const float* twiddle, const float* basis, int n_filt, const int32_t* hull_host,
+                       float* out, int64_t out_bstride, int row0, void* stream);
 
 #ifdef __cplusplus
 }

@@ -28,11 +28,23 @@ __global__ void decimate2_kernel(const float* __restrict__ x, int64_t L, int64_t
   }
 }
 
+// Non-zero column range of every filter's frequency-domain row: librosa sparsifies the basis (entries below
+// the 1 % magnitude quantile are set to zero), so each constant-Q filter keeps a run of a few dozen bins.
+struct FiltHull {
+  int k0[MAXFILT];
+  int len[MAXFILT];
+};
+
 __global__ __launch_bounds__(FPW * 64) void cqt_octave_kernel(
     const float* __restrict__ ysig, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
-    const float2* __restrict__ tw, const float2* __restrict__ basis, int n_filt, float2* __restrict__ out,
-    int64_t out_bstride, int row0) {
+    const float2* __restrict__ tw, const float2* __restrict__ basis, int n_filt, FiltHull hull,
+    float2* __restrict__ out, int64_t out_bstride, int row0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int hl[2 * MAXFILT];
+  if (threadIdx.x < MAXFILT) {
+    hl[threadIdx.x] = hull.k0[threadIdx.x];
+    hl[MAXFILT + threadIdx.x] = hull.len[threadIdx.x];
+  }
   const int M = n_fft >> 1, F = M + 1;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float2* xa = reinterpret_cast<float2*>(lds) + (size_t)w * (2 * M + F);
@@ -59,25 +71,30 @@ __global__ __launch_bounds__(FPW * 64) void cqt_octave_kernel(
     X[k] = make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
   }
   __syncthreads();
-  // n_filt complex dot products, lanes stride over bins, then a wave reduction
-  float2 acc[MAXFILT];
+  // n_filt sparse complex dot products: each 16-lane row of the wave takes one filter at a time (filter f -> row
+  // f & 3 of pass f >> 2) and walks only the filter's non-zero bin run; the row sum is four DPP steps.
+  const int row = lane >> 4, l16 = lane & 15;
+  for (int f0 = 0; f0 < n_filt; f0 += 4) {
+    const int f = f0 + row;
+    const int k0 = (f < n_filt) ? hl[f] : 0;
+    const int len = (f < n_filt) ? hl[MAXFILT + f] : 0;
+    int maxlen = 0;
 #pragma unroll
-  for (int f = 0; f < MAXFILT; ++f) acc[f] = make_float2(0.f, 0.f);
-  for (int k = lane; k < F; k += 64) {
-    const float2 xk = X[k];
-#pragma unroll
-    for (int f = 0; f < MAXFILT; ++f)
-      if (f < n_filt) {
-        const float2 p = cmul(basis[f * F + k], xk);
-        acc[f] = cadd(acc[f], p);
-      }
-  }
-#pragma unroll
-  for (int f = 0; f < MAXFILT; ++f)
-    if (f < n_filt) {
-      const float re = wave_sum(acc[f].x), im = wave_sum(acc[f].y);
-      if (lane == 0 && live) out[b * out_bstride + (int64_t)(row0 + f) * T + t] = make_float2(re, im);
+    for (int r = 0; r < 4; ++r) {
+      const int lr = __builtin_amdgcn_readlane(len, 16 * r);
+      maxlen = lr > maxlen ? lr : maxlen;
     }
+    float2 acc = make_float2(0.f, 0.f);
+    const float2* bf = basis + (int64_t)(f < n_filt ? f : 0) * F + k0;
+    for (int j = l16; j < maxlen; j += 16)
+      if (j < len) acc = cadd(acc, cmul(bf[j], X[k0 + j]));
+    float re = acc.x, im = acc.y;
+    re += dpp_f<DPP_QP_1032>(re); im += dpp_f<DPP_QP_1032>(im);
+    re += dpp_f<DPP_QP_2301>(re); im += dpp_f<DPP_QP_2301>(im);
+    re += dpp_f<DPP_ROW_HALF_MIRROR>(re); im += dpp_f<DPP_ROW_HALF_MIRROR>(im);
+    re += dpp_f<DPP_ROW_MIRROR>(re); im += dpp_f<DPP_ROW_MIRROR>(im);
+    if (l16 == 0 && f < n_filt && live) out[b * out_bstride + (int64_t)(row0 + f) * T + t] = make_float2(re, im);
+  }
 }
 
 bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
@@ -103,8 +120,8 @@ extern "C" int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t l
 }
 
 extern "C" int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
-                                  const float* twiddle, const float* basis, int n_filt, float* out,
-                                  int64_t out_bstride, int row0, void* stream) {
+                                  const float* twiddle, const float* basis, int n_filt, const int32_t* hull_host,
+                                  float* out, int64_t out_bstride, int row0, void* stream) {
   SYG_REQUIRE(y && twiddle && basis && out, "cqt_octave: null pointer argument");
   SYG_REQUIRE(is_pow2(n_fft) && n_fft >= 8 && n_fft <= 4096, "cqt_octave: n_fft must be a power of two in [8, 4096]");
   SYG_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && ldy >= L && hop >= 1, "cqt_octave: bad B/L/ldy/hop");
@@ -121,9 +138,21 @@ extern "C" int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t 
   }
   const int64_t gx = (T + FPW - 1) / FPW;
   SYG_REQUIRE(gx < (int64_t)0x7fffffff, "cqt_octave: grid too large");
+  // hull_host: [2 * n_filt] = first non-zero bin and run length of every basis row (NULL: rows are dense)
+  FiltHull hull;
+  for (int f = 0; f < MAXFILT; ++f) {
+    hull.k0[f] = 0;
+    hull.len[f] = (f < n_filt) ? M + 1 : 0;
+    if (hull_host && f < n_filt) {
+      hull.k0[f] = hull_host[f];
+      hull.len[f] = hull_host[n_filt + f];
+      SYG_REQUIRE(hull.k0[f] >= 0 && hull.len[f] >= 0 && hull.k0[f] + hull.len[f] <= M + 1,
+                  "cqt_octave: non-zero run of filter %d out of range (k0=%d len=%d)", f, hull.k0[f], hull.len[f]);
+    }
+  }
   hipLaunchKernelGGL(cqt_octave_kernel, dim3((unsigned)gx, (unsigned)B), dim3(FPW * 64), lds, (hipStream_t)stream, y, L,
-                     ldy, n_fft, hop, T, (const float2*)twiddle, (const float2*)basis, n_filt, (float2*)out, out_bstride,
-                     row0);
+                     ldy, n_fft, hop, T, (const float2*)twiddle, (const float2*)basis, n_filt, hull, (float2*)out,
+                     out_bstride, row0);
   SYG_CHECK_LAUNCH("cqt_octave");
   return SYG_OK;
 }

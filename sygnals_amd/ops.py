@@ -625,7 +625,12 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
         p = CqtPlan(sr, hop_length, fmin, n_bins, bins_per_octave, tuning, filter_scale, sparsity)
         for o in p.octaves:
             b = o["basis"]
-            o["basis_dev"] = _dev(np.stack([b.real, b.imag], axis=-1).astype(np.float32))
+            b32 = np.stack([b.real, b.imag], axis=-1).astype(np.float32)
+            o["basis_dev"] = _dev(b32)
+            nz = (b32[..., 0] != 0) | (b32[..., 1] != 0)          # librosa's sparsified basis: a short run per row
+            k0 = np.array([int(np.argmax(r)) if r.any() else 0 for r in nz], dtype=np.int32)
+            k1 = np.array([int(len(r) - np.argmax(r[::-1])) if r.any() else 0 for r in nz], dtype=np.int32)
+            o["hull"] = np.ascontiguousarray(np.concatenate([k0, k1 - k0]).astype(np.int32))
         p.taps_dev = _dev(decimation_taps().astype(np.float32))
         return p
     plan = _cached(key, build)
@@ -651,7 +656,8 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
     for o in plan.octaves:
         if o["n"] > 0:
             rc = lib().syg_cqt_octave_f32(_ptr(cur), B, cur.shape[1], _ld(cur), o["n_fft"], o["hop"], Tn,
-                                          _ptr(twiddle_rfft_dev(o["n_fft"])), _ptr(o["basis_dev"]), o["n"], _ptr(out),
+                                          _ptr(twiddle_rfft_dev(o["n_fft"])), _ptr(o["basis_dev"]), o["n"],
+                                          o["hull"].ctypes.data_as(C.c_void_p), _ptr(out),
                                           plan.n_bins * Tn, o["row0"], C.c_void_p(_stream_ptr()))
             check(rc, "syg_cqt_octave_f32")
         if o["decimate_after"]:
