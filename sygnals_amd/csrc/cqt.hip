@@ -12,19 +12,55 @@ namespace {
 constexpr int FPW = 8;            // frames per workgroup
 constexpr int MAXFILT = 24;       // filters per octave (bins_per_octave <= 24 handled in registers)
 
-__global__ void decimate2_kernel(const float* __restrict__ x, int64_t L, int64_t ldx, const float* __restrict__ taps,
-                                 int ntaps, float scale, float* __restrict__ y, int64_t Lout, int64_t ldy) {
+// FIR decimation by 2:  y[n] = scale * sum_j h[j] x[2n + half - j],  half = (ntaps - 1) / 2.
+// A workgroup produces DEC_NBO consecutive outputs: the input run it needs is staged once in LDS, split into its
+// even and odd samples (E[m] = x[2m], O[m] = x[2m+1]: the stride-2 reads of the filter become contiguous,
+// conflict-free LDS reads; samples outside [0, L) are staged as zeros), the taps sit in LDS too, and every thread
+// accumulates DEC_OUTS outputs per tap read.  Taps are applied in index order (same sum order as a direct loop).
+constexpr int DEC_NT = 256, DEC_OUTS = 4, DEC_NBO = DEC_NT * DEC_OUTS;
+
+__global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restrict__ x, int64_t L, int64_t ldx,
+                                                           const float* __restrict__ taps, int ntaps, float scale,
+                                                           float* __restrict__ y, int64_t Lout, int64_t ldy) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int half = (ntaps - 1) / 2;
+  const int nstage = DEC_NBO + half + 2;             // staged pairs (even, odd)
+  float* hs = lds;                                   // [ntaps]
+  float* E = hs + ((ntaps + 3) & ~3);
+  float* O = E + nstage;
   const int64_t b = blockIdx.y;
   const float* xb = x + b * ldx;
-  const int half = (ntaps - 1) / 2;
-  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < Lout; n += (int64_t)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    const int64_t c = 2 * n + half;
-    for (int j = 0; j < ntaps; ++j) {
-      const int64_t i = c - j;
-      if (i >= 0 && i < L) acc = fmaf(taps[j], xb[i], acc);
+  const int tid = threadIdx.x;
+  for (int j = tid; j < ntaps; j += DEC_NT) hs[j] = taps[j];
+  for (int64_t n0 = (int64_t)blockIdx.x * DEC_NBO; n0 < Lout; n0 += (int64_t)gridDim.x * DEC_NBO) {
+    // lowest input index used: 2 n0 + half - (ntaps - 1) = 2 n0 - half; mbase = floor(that / 2)
+    const int64_t ilo = 2 * n0 - half;
+    const int64_t mbase = (ilo >= 0) ? ilo / 2 : -((-ilo + 1) / 2);
+    __syncthreads();                                  // the previous round's reads are done
+    for (int u = tid; u < nstage; u += DEC_NT) {
+      const int64_t i0 = 2 * (mbase + u);
+      E[u] = (i0 >= 0 && i0 < L) ? xb[i0] : 0.f;
+      O[u] = (i0 + 1 >= 0 && i0 + 1 < L) ? xb[i0 + 1] : 0.f;
     }
-    y[b * ldy + n] = acc * scale;
+    __syncthreads();
+    float acc[DEC_OUTS];
+#pragma unroll
+    for (int o = 0; o < DEC_OUTS; ++o) acc[o] = 0.f;
+    // input index of tap j for output n: i = 2n + half - j = 2 (n + q) + r with (q, r) from c = half - j
+    for (int j = 0; j < ntaps; ++j) {
+      const int c = half - j;
+      const int q = (c >= 0) ? c / 2 : -((-c + 1) / 2);     // floor(c / 2)
+      const int r = c - 2 * q;                               // 0 or 1
+      const float* src = (r ? O : E) + (int)(n0 - mbase) + q + tid;
+      const float h = hs[j];
+#pragma unroll
+      for (int o = 0; o < DEC_OUTS; ++o) acc[o] = fmaf(h, src[o * DEC_NT], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < DEC_OUTS; ++o) {
+      const int64_t n = n0 + tid + o * DEC_NT;
+      if (n < Lout) y[b * ldy + n] = acc[o] * scale;
+    }
   }
 }
 
@@ -111,10 +147,12 @@ extern "C" int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t l
   SYG_REQUIRE(ntaps >= 1 && (ntaps & 1) == 1 && ntaps <= 1025, "decimate2: ntaps must be odd and <= 1025");
   const int64_t Lout = (L + 1) / 2;
   SYG_REQUIRE(ldy >= Lout, "decimate2: ldy too small");
-  int64_t blocks = (Lout + 255) / 256;
+  int64_t blocks = (Lout + DEC_NBO - 1) / DEC_NBO;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(decimate2_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, L, ldx,
-                     taps, ntaps, scale, y, Lout, ldy);
+  const int half = (ntaps - 1) / 2;
+  const size_t lds = (size_t)(((ntaps + 3) & ~3) + 2 * (DEC_NBO + half + 2)) * sizeof(float);
+  hipLaunchKernelGGL(decimate2_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(DEC_NT), lds, (hipStream_t)stream, x, L,
+                     ldx, taps, ntaps, scale, y, Lout, ldy);
   SYG_CHECK_LAUNCH("decimate2");
   return SYG_OK;
 }
