@@ -101,6 +101,7 @@ int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int 
  * transform buffers (e.g. n_mels=40: T <= 128 frames); callers then use the two-launch form
  * syg_stft2048_mel_f32 + syg_logmel_dct_f32.
  * ------------------------------------------------------------------------------- */
+int syg_stft2048_mfcc_fits(int n_mels, int64_t T, int n_mfcc);   /* 1: the shape fits the one-launch form */
 int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
                           int64_t T, const float* window, const float* twiddle, const float* wpacked,
                           const int32_t* plan_host, int n_mels, const float* dct, int n_mfcc,

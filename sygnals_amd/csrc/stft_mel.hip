@@ -1116,6 +1116,14 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
 #undef SYG_LAUNCH
 }
 
+// 1 when the clip-resident form has room for the clip's mel matrix + DCT rows + lifter behind the fixed LDS map
+extern "C" int syg_stft2048_mfcc_fits(int n_mels, int64_t T, int n_mfcc) {
+  if (n_mels < 1 || n_mels > 16 * MAXW || T < 1 || n_mfcc < 1 || n_mfcc > n_mels) return 0;
+  const int64_t tp = ((T + MAXW - 1) / MAXW) * MAXW;
+  const int64_t bytes = (int64_t)lds_bytes<16>() + ((int64_t)n_mels * tp + 16 + (int64_t)n_mfcc * (n_mels + 1)) * 4;
+  return bytes <= (int64_t)LDS_LIMIT ? 1 : 0;
+}
+
 extern "C" int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
                                      int64_t T, const float* window, const float* twiddle, const float* wpacked,
                                      const int32_t* plan_host, int n_mels, const float* dct, int n_mfcc,

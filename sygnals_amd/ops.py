@@ -210,12 +210,10 @@ def logmel_dct(mel: torch.Tensor, n_mfcc: Optional[int] = 13, dct_type: int = 2,
     return (logmel if keep_mel else mel), mf
 
 
-# LDS left beside the fused kernel's fixed map for the clip-resident mel matrix (see csrc/stft_mel.hip, Lds<16>)
-_MFCC_LDS_SPARE_FLOATS = (160 * 1024 - 141664) // 4 - 18
-
-
 def mfcc_fused_fits(n_mels: int, n_frames: int, n_mfcc: int = 13) -> bool:
-    return n_mels * (16 * ((n_frames + 15) // 16)) + n_mfcc * (n_mels + 1) <= _MFCC_LDS_SPARE_FLOATS
+    """True when the clip's mel matrix + DCT rows fit the LDS left beside the fused kernel's buffers (the library
+    owns the formula: syg_stft2048_mfcc_fits)."""
+    return bool(lib().syg_stft2048_mfcc_fits(int(n_mels), int(n_frames), int(n_mfcc)))
 
 
 class _MfccCall:
