@@ -733,6 +733,16 @@ KNOWN_FEATURES = set(SPECTRUM_FEATURES) | {"spectral_contrast", "mfcc"} | set(TI
     "rms_energy", "zero_crossing_rate"}
 
 
+def _nan_pad(a, T):
+    """manager.py:378-386: a feature array shorter than the frame count is padded with NaN, a longer one cut."""
+    a = np.asarray(a, dtype=np.float64)
+    if len(a) >= T:
+        return a[:T]
+    out = np.full(T, np.nan, dtype=np.float64)
+    out[: len(a)] = a
+    return out
+
+
 def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=True,
                      window="hann", feature_params=None, per_frame_loop=False):
     """Oracle for the spectrum / spectrogram / mel feature groups (dict_of_arrays).
@@ -761,11 +771,11 @@ def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=
             if tstats is None:
                 tstats = time_features_frames(y, frame_length, hop_length, center,
                                               feature_params.get("signal_entropy", {}).get("num_bins", 10))
-            res[name] = tstats[name]
+            res[name] = _nan_pad(tstats[name], T)
         elif name == "rms_energy":
-            res[name] = rms_energy(y, frame_length=frame_length, hop_length=hop_length, center=center)
+            res[name] = _nan_pad(rms_energy(y, frame_length=frame_length, hop_length=hop_length, center=center), T)
         elif name == "zero_crossing_rate":
-            res[name] = zero_crossing_rate(y, frame_length, hop_length, center)
+            res[name] = _nan_pad(zero_crossing_rate(y, frame_length, hop_length, center), T)
         elif name in SPECTRUM_FEATURES:
             if per_frame_loop:
                 fn = {"spectral_centroid": spectral_centroid, "spectral_bandwidth": spectral_bandwidth,

@@ -108,6 +108,14 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
         from .time_domain import time_features_frames
         nb = int(feature_params.get("signal_entropy", {}).get("num_bins", 10))
         tstats = time_features_frames(yd, frame_length, hop_length, center, nb, want_time)
+        # the reference frames the signal padded by frame_length // 2 on both sides (manager.py:268-271, librosa's
+        # rms / zcr likewise): with an ODD frame_length that is one sample short of the last frame whenever hop
+        # divides len(y), and the missing value is NaN-padded (manager.py:378-386).  Same observable result here.
+        if center:
+            t_ref = 1 + (L + 2 * (frame_length // 2) - frame_length) // hop_length
+            if t_ref < Tn:
+                for v in tstats.values():
+                    v[:, t_ref:] = float("nan")
     need_stft = bool(want_stats or want_contrast or want_mfcc)
 
     mel = stats = cpv = None

@@ -87,3 +87,17 @@ def test_manager_extracts_time_and_spectral_rows_together(ops):
     for k in ref:
         assert out[k].dtype == np.float64 and out[k].shape == ref[k].shape
         assert_parity(out[k], ref[k], TOL, k)
+
+
+def test_odd_frame_length_last_frame_is_nan_padded_like_the_reference(ops):
+    """frame_length odd and hop | len(y): the reference's padded framing is one sample short of the last frame and
+    NaN-pads it (manager.py:268-271, 378-386)."""
+    from sygnals_amd.core.features.manager import extract_features
+    y = O.synth_clips(1, 4096, 16000, seed=2)[0].astype(np.float64)
+    feats = ["mean_amplitude", "rms_energy", "zero_crossing_rate", "kurtosis"]
+    out = extract_features(y, 16000, feats, frame_length=1023, hop_length=256, output_format="dict_of_arrays")
+    ref = O.extract_features(y, 16000, feats, frame_length=1023, hop_length=256)
+    assert len(out["time"]) == 17
+    for k in feats:
+        assert np.isnan(ref[k][-1]) and np.isnan(out[k][-1]) and not np.isnan(out[k][:-1]).any()
+        assert_parity(out[k][:-1], ref[k][:-1], TOL, k)

@@ -60,8 +60,10 @@ for it in range(N):
     ct = bool(rng.integers(0, 2)); nb = int(rng.integers(1, 40))
     st = ops.frame_stats(ops.to_device_f32(yt[None, :]), fl, hp, ct, nb).cpu().numpy()[0].astype(np.float64)
     ref = O.time_features_frames(yt.astype(np.float64), fl, hp, ct, nb)
+    tr = len(ref["mean_amplitude"])          # odd frame_length: the reference may form one frame fewer (NaN-padded)
+    assert tr in (st.shape[1], st.shape[1] - 1)
     for r, nm in enumerate(O.TIME_FEATURES):
-        check(nm, rel(st[r], ref[nm]), 1e-5, (fl, hp, Lt, ct, nb))
+        check(nm, rel(st[r, :tr], ref[nm]), 1e-5, (fl, hp, Lt, ct, nb))
     z = O.zero_crossing_rate(yt.astype(np.float64), fl, hp, ct)
-    assert np.array_equal(np.round(st[8] * fl), np.round(z * fl)), ("zcr", fl, hp, Lt, ct)
+    assert np.array_equal(np.round(st[8, :len(z)] * fl), np.round(z * fl)), ("zcr", fl, hp, Lt, ct)
 print("fuzz ok:", {k: f"{v:.1e}" for k, v in worst.items()})
