@@ -1,24 +1,31 @@
-// Fused STFT(2048) -> power -> mel kernel for gfx950 (MI355X).
+// Fused STFT(2048) -> power -> mel (-> dB -> DCT) kernel for gfx950 (MI355X).
 //
-// One persistent workgroup of W waves (W = 8: two workgroups per CU; W = 16: one) walks a contiguous
-// chunk of tiles; a tile is W consecutive frames of one clip, one frame per wave.
-//   phase 1  each wave: coalesced float2 loads of its (overlapped) frame straight from HBM/L2, analysis
-//            window, a 1024-point complex FFT held 16 points per lane (radix 16 x 16 x 4).  The two
-//            exchanges go through a 4.1 KiB per-wave LDS scratch in two half-rounds each (XOR / planar
-//            swizzles: every ds_write_b64 / ds_read_b64 is bank-conflict free), which is what lets 16
-//            waves (4 per SIMD) stay resident on a CU.  Real-FFT split on mirror pairs, |X|^2 stored as
-//            one skewed 1025-bin row in LDS.
-//   phase 2  the W power rows are the B operand of v_mfma_f32_16x16x4_f32: the mel filterbank is stored
-//            block-sparse (per 16-mel tile only its non-zero bin range), split over the waves and streamed
-//            four k-steps per 16-byte load; partial 16 x W tiles are combined in a fixed order
-//            (deterministic) and stored as mel[b, m, t].
-//   phase 2b (MODE 1) per-frame spectral statistics and contrast tail means from the same LDS rows.
-// Nothing but the input samples and the mel / stats outputs touches HBM.
+// One persistent workgroup of W waves (W = 16: one per CU; W = 8: two) walks a contiguous chunk of tiles; a tile
+// is W consecutive frames of one clip, one frame per wave.  Per tile (two barriers):
+//   FFT      the tile's contiguous sample run was copied into LDS by LDS-DMA (buffer_load ... lds; the buffer
+//            descriptor's range check supplies center=True's zero padding) while the previous tile was being
+//            processed; each wave takes its (overlapped) frame from there, applies the analysis window (LDS copy)
+//            and runs a 1024-point complex FFT held 16 points per lane (radix 16 x 16 x 4).  The two exchanges go
+//            through a 4.1 KiB per-wave scratch that aliases the wave's own power row, in two half-rounds each:
+//            full-wave ds_write_b64 / ds_read_b64, conflict-free under the per-instruction LDS banking, the lane
+//            pair (L, L + 32) completing each other's rows with v_permlane32_swap.  Real-FFT split on mirror
+//            pairs, |X|^2 stored as one skewed 1025-bin row.
+//   barrier A
+//   project  the W power rows are the B operand of v_mfma_f32_16x16x4_f32: the mel filterbank is stored
+//            block-sparse (per 16-mel tile only its non-zero bin range), split over the waves, four k-steps per
+//            16-byte load (pre-loaded behind barrier A); then the next frame is fetched LDS -> registers.
+//   barrier B
+//   reduce   the DMA of the tile after next is started; partial 16 x W tiles are combined in a fixed order
+//            (deterministic) into mel[b, m, t] (MODE 0/1) or the clip's LDS mel matrix (MODE 3).
+//   MODE 1   per-frame spectral statistics and contrast tail means from the same LDS rows (+ one barrier).
+//   MODE 3   at a clip's last tile: power_to_db + DCT-II from the LDS mel matrix inside the next tile's projection
+//            phase -- only MFCCs are written.   MODE 2: complex STFT output instead of the projection.
+// Nothing but the input samples and the outputs touches HBM.
 //
 // Reference behaviour reproduced: librosa.stft (center zero padding, periodic window, rfft) -> np.abs ->
-// **2 -> melspectrogram, as called from sygnals/core/features/manager.py:184-187, 198, 219-222; per-frame
-// statistics follow sygnals/core/features/frequency_domain.py:24-386.
-// Index maps are validated by tools/wave_fft_model_v3.py.
+// **2 -> melspectrogram -> power_to_db(ref=np.max) -> mfcc, as called from sygnals/core/features/manager.py:184-187,
+// 198, 219-223 and cepstral.py:106-115; per-frame statistics follow sygnals/core/features/frequency_domain.py:24-386.
+// Index maps and LDS bank behaviour are validated by tools/wave_fft_model_v4.py.
 #include "common.h"
 #include <string.h>
 
