@@ -218,3 +218,27 @@ def test_cqt_plan_matches_oracle(sr, hop, n_bins):
         CqtPlan(8000)
     with pytest.raises(ValueError, match="multiple of 2"):
         CqtPlan(48000, hop_length=48)
+
+
+def test_wave_fft_index_model_is_exact_and_conflict_free():
+    """tools/wave_fft_model_v4.py is the lane/register model the kernel's exchange maps were derived from: it must
+    reproduce numpy's rfft and keep every exchange access conflict-free under the per-instruction LDS banking."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("wfm", os.path.join(ROOT, "tools", "wave_fft_model_v4.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=2048)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(2048) / 2048)
+    X = m.model(x, win)
+    assert not np.isnan(X).any() and np.abs(X - np.fft.rfft(x * win)).max() < 1e-10
+    lane = np.arange(64)
+    cl, bp, hi = lane >> 2, lane & 3, lane >> 5
+    G16 = [list(range(i, i + 16)) for i in range(0, 64, 16)]
+    G32 = [list(range(32)), list(range(32, 64))]
+    assert all(m.conf(8 * m.x1(c, lane), 8, G16, 128) == 1 for c in range(16))
+    for h in (0, 1):
+        row = (cl & 7) + 8 * h
+        assert all(m.conf(8 * m.x1(row, 4 * (8 * hi + i) + bp), 8, G32, 256) == 1 for i in range(8))
+    assert all(m.conf(8 * m.x2(cl, cp, bp), 8, G16, 128) == 1 for cp in range(16))
