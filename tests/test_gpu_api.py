@@ -288,3 +288,64 @@ def test_c4_share_full_size_batch_consistency():
             assert np.mean(small[k][3] == ref[k]) > 0.99
         else:
             assert peak_rel(small[k][3], ref[k]) <= tol, k
+
+
+def test_c5_full_size_stream_welch_and_cqt():
+    """Config C5 on one GPU: a 1-hour 48 kHz stream (172.8 M samples), Welch nperseg 4096 / 50 % and the 84-bin CQT.
+    The oracle covers a 2-minute excerpt; at full size: exact power scaling (x2 -> PSD x4), and the CQT of the
+    stream delayed by a whole number of hops equals the shifted CQT away from the edges."""
+    from sygnals_amd import ops
+    from sygnals_amd.core import dsp as D
+    sr, L = 48000, 48000 * 3600
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(L, device="cuda", generator=g, dtype=torch.float32) * 0.05
+    for c0 in range(0, L, 1 << 24):                    # tone phases in float64: float32 loses the sample index past 2^24
+        t = torch.arange(c0, min(c0 + (1 << 24), L), device="cuda", dtype=torch.float64)
+        x[c0:c0 + t.numel()] += (0.3 * torch.sin(2 * np.pi * 440.0 / sr * t)
+                                 + 0.2 * torch.sin(2 * np.pi * 3000.5 / sr * t)).float()
+    del t
+    x = x.reshape(1, L)
+    f, P = D.welch_batch(x, fs=sr, nperseg=4096)
+    P = P.cpu().numpy()[0].astype(np.float64)
+    assert P.shape == (2049,) and np.isfinite(P).all()
+    assert abs(f[np.argmax(P)] - 440.0) < sr / 4096
+    _, P2 = D.welch_batch(x * 2.0, fs=sr, nperseg=4096)
+    assert np.array_equal(P2.cpu().numpy()[0], (4.0 * P).astype(np.float32))          # exact in floating point
+    ex = x[:, : sr * 120]
+    _, Pe = D.welch_batch(ex, fs=sr, nperseg=4096)
+    fo, Po = O.compute_psd_welch(ex.cpu().numpy()[0].astype(np.float64), sr, "hann", 4096)
+    assert peak_rel(Pe.cpu().numpy()[0], Po) <= TOL
+    # Parseval: the one-sided density integrates to the signal power
+    power = float((x.double() ** 2).mean())
+    assert abs(P.sum() * (sr / 4096) - power) <= 2e-3 * power
+    # CQT: frames of the delayed stream are the shifted frames (interior)
+    C = ops.cqt(x, sr)
+    assert tuple(C.shape) == (1, 84, 1 + L // 512, 2)
+    k = 1024
+    Cs = ops.cqt(x[:, 512 * k:], sr)
+    a = C[0, :, k + 200: k + 5200].cpu().numpy().astype(np.float64)
+    b = Cs[0, :, 200:5200].cpu().numpy().astype(np.float64)
+    assert np.abs(a - b).max() <= TOL * np.abs(a).max()
+    exc = x[0, : sr * 4].cpu().numpy().astype(np.float64)
+    ref = O.cqt(exc, sr)
+    got = C[0, :, :300].cpu().numpy()
+    got = got[..., 0] + 1j * got[..., 1]
+    assert peak_rel(got[:, :250], ref[:, :250]) <= 1e-3      # the excerpt's end differs only through filter tails
+
+
+def test_c3_full_size_filter_then_mfcc():
+    """Config C3: the 1024-clip batch through the order-4 Butterworth band-pass filtfilt, then STFT -> MFCC.
+    Size-independent property: batch consistency; the oracle (SciPy sosfiltfilt + float64 MFCC chain) checks a sample."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.filters import apply_sos_filter_batch
+    Y = O.synth_clips(16, 48000, 48000, seed=31)
+    sos = O.design_butterworth_sos((300.0, 3400.0), 48000, 4, "bandpass")
+    big = ops.to_device_f32(np.tile(Y, (64, 1)))
+    out = ops.mfcc_batch(apply_sos_filter_batch(sos, big), 48000, n_mels=40).cpu().numpy()
+    small = ops.mfcc_batch(apply_sos_filter_batch(sos, ops.to_device_f32(Y)), 48000, n_mels=40, fused=True).cpu().numpy()
+    assert out.shape == (1024, 13, 94)
+    assert np.array_equal(out.reshape(64, 16, 13, 94), np.broadcast_to(small, (64, 16, 13, 94)))
+    for i in (0, 9):
+        yf = O.apply_sos_filter(sos, Y[i].astype(np.float64))
+        ref = O.mfcc_manager(yf, 48000, n_mels=40)
+        assert peak_rel(small[i], ref) <= 2e-5, i      # two fp32 stages in series (filter output rounded to fp32)
