@@ -8,14 +8,26 @@
 // The recurrence is serial in time, so time is cut into chunks of CS samples and the cascade is
 // treated as one linear system of dimension D = 2*n_sections:
 //   pass A  every chunk runs from a zero state          -> its zero-state end state
-//   pass B  a short serial scan per clip, s <- A^CS s + zs (A^CS formed on the host in float64)
+//   pass B  a short serial scan per clip, s <- A^CS s + zs (A^n formed on the host in float64)
 //           gives every chunk its true initial state
 //   pass C  every chunk re-runs from the true state and writes its output (reversed, so the
 //           backward sweep reads forward again)
 // Recurrences run in float64 (the pole radius of the headline band-pass is 0.987; float32 state
-// alone costs half the 1e-5 parity budget); signals are stored float32.  A wave owns 64 consecutive
-// chunks of one clip and moves 64x32-sample tiles through LDS so that global accesses stay
-// coalesced while each lane walks its own chunk.
+// alone costs half the 1e-5 parity budget); signals are stored float32.
+//
+// Data movement (it, not the fp64 arithmetic, bounds these passes).  Each sweep works on an ALIGNED GRID: grid
+// position g = sequence index + skip, with skip chosen per sweep so that every 4-sample group of the grid is
+// a 16-byte aligned float4 -- and every 8-lane, 32-sample segment a whole 128-byte line -- both where it is read and
+// where it is written (skip in 0..31):
+//   forward sweep   reads the clip itself (odd extension computed on the fly): skip_f = -pad mod 32 aligns x;
+//                   writes its output reversed into the work buffer G at grid K - g (K fixed by skip_b);
+//   backward sweep  reads G in place order: skip_b = -(lext + skip_f) mod 32 makes the forward stores aligned.
+// The skip leading positions of chunk 0 are not samples: its lane leaves the state untouched there.  Chunk 0 is
+// therefore short, so its pass A starts from the true initial state zi * first sample (known up front) and what
+// it reports is already the true state at the start of chunk 1 -- the scan takes it as is.  A wave owns 64 consecutive chunks of one clip and moves 64 x 32-sample
+// tiles through LDS (lane-major rows of 36 floats: 128-bit, conflict-free LDS accesses on both sides) so that
+// global accesses stay coalesced while each lane walks its own chunk; the next tile's loads are issued before the
+// recurrence over the current one.  One wave per workgroup: ordering inside the wave replaces barriers.
 #include "common.h"
 #include <string.h>
 
@@ -26,7 +38,7 @@ constexpr int CS = 256;      // samples per chunk
 constexpr int TS = 32;       // samples per LDS tile row group
 constexpr int MAXS = 8;      // sections
 constexpr int MAXD = 2 * MAXS;
-constexpr int TSTRIDE = 65;  // LDS tile row stride (floats)
+constexpr int LSTR = 36;     // LDS tile row stride (floats): one row = the 32 samples of one chunk (+4 pad)
 
 struct SosParams {
   double b0[MAXS], b1[MAXS], b2[MAXS], a1[MAXS], a2[MAXS];
@@ -37,6 +49,7 @@ struct SosParams {
 // Sample i of the odd-extended, zero-tailed signal (scipy's padtype='odd'): read straight from the clip, so the
 // forward sweep needs no extended copy in HBM.
 __device__ __forceinline__ float ext_at(const float* __restrict__ xb, int64_t L, int pad, int64_t lext, int64_t i) {
+  if (i < 0) return 0.f;                                  // (grid positions in front of the sequence)
   if (i < pad) return 2.f * xb[0] - xb[pad - i];
   if (i < pad + L) return xb[i - pad];
   if (i < lext) return 2.f * xb[L - 1] - xb[L - 2 - (i - pad - L)];
@@ -45,16 +58,16 @@ __device__ __forceinline__ float ext_at(const float* __restrict__ xb, int64_t L,
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 
 // ---- pass A / C
-// MODE 0: zero-state pass, writes end states.  MODE 1: true pass, output reversed into `dst`
-// (dst[lext-1-i]).  MODE 2: true pass, output reversed and trimmed into y[b, n], n = lext-1-pad-i.
+// MODE 0: zero-state pass, writes end states.  MODE 1: true pass of the forward sweep, output reversed into the
+// work buffer (grid K - g).  MODE 2: true pass of the backward sweep, output reversed and trimmed into y[b, n].
 // SRCX: the input is the clip itself, odd-extended on the fly (forward sweep; `in` = x, row stride `ldin`);
-// otherwise a [B, lpad] work buffer (backward sweep).
+// otherwise the [B, lpad] work buffer (backward sweep).  Grid position g <-> sequence index i = g - skip.
 template <int S, int MODE, bool SRCX>
-__global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in, int64_t ldin, int64_t lpad, int nch,
-                                                   int64_t lext, SosParams P, const double* __restrict__ init,
+__global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in, int64_t ldin, int nch, int64_t lext,
+                                                   int skip, SosParams P, const double* __restrict__ init,
                                                    double* __restrict__ zs, float* __restrict__ dst, int64_t lddst,
-                                                   int pad, int64_t L) {
-  __shared__ float tile[TS * TSTRIDE];
+                                                   int64_t K, int pad, int64_t L) {
+  __shared__ __attribute__((aligned(16))) float tile[64 * LSTR];
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.y;
   const int c0 = blockIdx.x * 64;
@@ -68,70 +81,114 @@ __global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in,
 #pragma unroll
     for (int s = 0; s < S; ++s) { z0[s] = ip[2 * s]; z1[s] = ip[2 * s + 1]; }
   }
-  // cooperative coalesced load of one 64-chunk x 32-sample tile: 8 lanes x float4 cover one chunk's 32 samples.
-  // The loads of tile k+1 are issued before the recurrence over tile k starts, so their latency hides behind it.
+  if (MODE == 0 && c == 0) {
+    // chunk 0 runs from the true initial state zi * (sequence sample 0): see the header
+    const double first = (double)(SRCX ? ext_at(inb, L, pad, lext, 0) : inb[skip]);
+#pragma unroll
+    for (int s = 0; s < S; ++s) { z0[s] = P.zi[2 * s] * first; z1[s] = P.zi[2 * s + 1] * first; }
+  }
+  // cooperative load of one 64-chunk x 32-sample tile: 8 lanes x float4 cover one chunk's 32 samples
   auto load_tile = [&](int j0, float4 (&v)[8]) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int ch = r * 8 + (lane >> 3), part = lane & 7;
       v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c0 + ch < nch) {
-        const int64_t i0 = (int64_t)(c0 + ch) * CS + j0 + 4 * part;
+        const int64_t g0 = (int64_t)(c0 + ch) * CS + j0 + 4 * part;
         if (!SRCX) {
-          v[r] = *reinterpret_cast<const float4*>(inb + i0);
-        } else if (i0 >= pad && i0 + 3 < pad + L) {
-          const f4u u4 = *reinterpret_cast<const f4u*>(inb + (i0 - pad));
-          v[r] = make_float4(u4.x, u4.y, u4.z, u4.w);
+          v[r] = *reinterpret_cast<const float4*>(inb + g0);                 // work buffer: aligned by construction
         } else {
-          v[r] = make_float4(ext_at(inb, L, pad, lext, i0), ext_at(inb, L, pad, lext, i0 + 1),
-                             ext_at(inb, L, pad, lext, i0 + 2), ext_at(inb, L, pad, lext, i0 + 3));
-        }
-      }
-    }
-  };
-  float4 nxt[8];
-  load_tile(0, nxt);
-  for (int j0 = 0; j0 < CS; j0 += TS) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int ch = r * 8 + (lane >> 3), part = lane & 7;
-      tile[(4 * part + 0) * TSTRIDE + ch] = nxt[r].x;
-      tile[(4 * part + 1) * TSTRIDE + ch] = nxt[r].y;
-      tile[(4 * part + 2) * TSTRIDE + ch] = nxt[r].z;
-      tile[(4 * part + 3) * TSTRIDE + ch] = nxt[r].w;
-    }
-    if (j0 + TS < CS) load_tile(j0 + TS, nxt);
-    __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < TS; ++j) {
-      double u = (double)tile[j * TSTRIDE + lane];
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const double yv = fma(P.b0[s], u, z0[s]);
-        z0[s] = fma(P.b1[s], u, fma(-P.a1[s], yv, z1[s]));
-        z1[s] = fma(P.b2[s], u, -P.a2[s] * yv);
-        u = yv;
-      }
-      if (MODE != 0) tile[j * TSTRIDE + lane] = (float)u;
-    }
-    if (MODE != 0) {
-      __syncthreads();
-      // coalesced (reversed) store: 32 lanes cover one chunk's 32 samples
-#pragma unroll 4
-      for (int r = 0; r < 32; ++r) {
-        const int ch = r * 2 + (lane >> 5), j = lane & 31;
-        if (c0 + ch < nch) {
-          const int64_t i = (int64_t)(c0 + ch) * CS + j0 + j;
-          if (MODE == 1) {
-            if (i < lext) dst[b * lddst + (lext - 1 - i)] = tile[j * TSTRIDE + ch];
+          const int64_t i0 = g0 - skip;                                      // sequence index; x index = i0 - pad
+          if (i0 >= pad && i0 + 3 < pad + L) {
+            v[r] = *reinterpret_cast<const float4*>(inb + (i0 - pad));       // 16-byte aligned: skip = -pad mod 4
           } else {
-            const int64_t n = lext - 1 - pad - i;
-            if (n >= 0 && n < L) dst[b * lddst + n] = tile[j * TSTRIDE + ch];
+            v[r] = make_float4(ext_at(inb, L, pad, lext, i0), ext_at(inb, L, pad, lext, i0 + 1),
+                               ext_at(inb, L, pad, lext, i0 + 2), ext_at(inb, L, pad, lext, i0 + 3));
           }
         }
       }
     }
-    __syncthreads();
+  };
+  auto step = [&](double u) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const double yv = fma(P.b0[s], u, z0[s]);
+      z0[s] = fma(P.b1[s], u, fma(-P.a1[s], yv, z1[s]));
+      z1[s] = fma(P.b2[s], u, -P.a2[s] * yv);
+      u = yv;
+    }
+    return u;
+  };
+  float4 nxt[8], nx2[8];                 // two tiles in flight: the passes are bound by memory latency, not arithmetic
+  load_tile(0, nxt);
+  load_tile(TS, nx2);
+  for (int j0 = 0; j0 < CS; j0 += TS) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int ch = r * 8 + (lane >> 3), part = lane & 7;
+      *reinterpret_cast<float4*>(&tile[ch * LSTR + 4 * part]) = nxt[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) nxt[r] = nx2[r];
+    if (j0 + 2 * TS < CS) load_tile(j0 + 2 * TS, nx2);
+    wave_lds_sync();
+    float* row = &tile[lane * LSTR];
+    int jb = 0;
+    if (j0 == 0 && c0 == 0) {
+      // the wave that holds chunk 0: its first `skip` (< TS) grid positions are not samples -- this one tile is
+      // walked sample by sample with the chunk-0 lane sitting those positions out
+      for (int j = 0; j < TS; ++j) {
+        float o = 0.f;
+        if (c != 0 || j >= skip) o = (float)step((double)row[j]);
+        if (MODE != 0) row[j] = o;
+      }
+      jb = TS;
+    }
+#pragma unroll 2
+    for (int j = jb; j < TS; j += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(row + j);
+      const float o0 = (float)step((double)q.x), o1 = (float)step((double)q.y), o2 = (float)step((double)q.z),
+                  o3 = (float)step((double)q.w);
+      if (MODE != 0) *reinterpret_cast<float4*>(row + j) = make_float4(o0, o1, o2, o3);
+    }
+    if (MODE != 0) {
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int ch = r * 8 + (lane >> 3), part = lane & 7;
+        if (c0 + ch < nch) {
+          const float4 v = *reinterpret_cast<const float4*>(&tile[ch * LSTR + 4 * part]);
+          const int64_t g0 = (int64_t)(c0 + ch) * CS + j0 + 4 * part;
+          const int64_t i0 = g0 - skip;                       // sequence index of v.x
+          if (MODE == 1) {
+            // reversed into the work buffer: sample g -> grid K - g; (K - g0 - 3) is a multiple of 4
+            float* d = dst + b * lddst + (K - g0 - 3);
+            if (i0 >= 0 && i0 + 3 < lext) {
+              *reinterpret_cast<float4*>(d) = make_float4(v.w, v.z, v.y, v.x);
+            } else {
+              if (i0 + 3 >= 0 && i0 + 3 < lext) d[0] = v.w;
+              if (i0 + 2 >= 0 && i0 + 2 < lext) d[1] = v.z;
+              if (i0 + 1 >= 0 && i0 + 1 < lext) d[2] = v.y;
+              if (i0 >= 0 && i0 < lext) d[3] = v.x;
+            }
+          } else {
+            // y[n], n = lext - 1 - pad - i: alignment of the result is the caller's, so dword stores
+            const int64_t n0 = lext - 1 - pad - i0;
+            float* d = dst + b * lddst;
+            if (i0 >= 0 && n0 - 3 >= 0 && n0 < L) {          // interior: one 16-byte store at 4-byte alignment
+              f4u o; o.x = v.w; o.y = v.z; o.z = v.y; o.w = v.x;
+              *reinterpret_cast<f4u*>(d + (n0 - 3)) = o;
+              continue;
+            }
+            if (i0 >= 0 && n0 >= 0 && n0 < L) d[n0] = v.x;
+            if (i0 + 1 >= 0 && n0 - 1 >= 0 && n0 - 1 < L) d[n0 - 1] = v.y;
+            if (i0 + 2 >= 0 && n0 - 2 >= 0 && n0 - 2 < L) d[n0 - 2] = v.z;
+            if (i0 + 3 >= 0 && n0 - 3 >= 0 && n0 - 3 < L) d[n0 - 3] = v.w;
+          }
+        }
+      }
+    }
+    wave_lds_sync();
   }
   if (MODE == 0 && c < nch) {
     double* zp = zs + ((int64_t)b * nch + c) * (2 * S);
@@ -164,7 +221,7 @@ struct RowDot<D, D> {
 
 template <int S, bool SRCX>
 __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in, int64_t ldin, int nch, int64_t B,
-                                                   SosParams P, const double* __restrict__ zs,
+                                                   int skip, SosParams P, const double* __restrict__ zs,
                                                    double* __restrict__ init, int pad, int64_t L, int64_t lext) {
   constexpr int D = 2 * S;
   const int r = threadIdx.x & 15;
@@ -184,7 +241,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in,
 #pragma unroll
   for (int rr = 0; rr < D; ++rr)
     if (r == rr) zi = P.zi[rr];
-  const float first = SRCX ? ext_at(in + bb * ldin, L, pad, lext, 0) : in[bb * ldin];
+  const float first = SRCX ? ext_at(in + bb * ldin, L, pad, lext, 0) : in[bb * ldin + skip];   // sequence sample 0
   double s = zi * (double)first;
   const int rc = (r < D) ? r : 0;
   const double* zp = zs + (int64_t)bb * nch * D + rc;
@@ -201,7 +258,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in,
     for (int k = 0; k < AHEAD; ++k) {
       if (c0 + k < nch) {
         if (live) ip[(int64_t)(c0 + k) * D] = s;
-        s = RowDot<D, 0>::run(arow, s, zq[k]);
+        // chunk 0 (short by `skip`) ran pass A from the true state: its report is the state at chunk 1
+        s = (c0 + k == 0) ? zq[k] : RowDot<D, 0>::run(arow, s, zq[k]);
       }
     }
 #pragma unroll
@@ -220,31 +278,58 @@ void host_step(const double* sos5, int S, double* z, double x) {
   }
 }
 
+// A^n (row-major D x D in a MAXD-strided array) by repeated multiplication; n <= CS
+void mat_pow(const double* A1, int D, int n, double* out) {
+  double R[MAXD * MAXD] = {0}, T[MAXD * MAXD];
+  for (int i = 0; i < D; ++i) R[i * MAXD + i] = 1.0;
+  for (int it = 0; it < n; ++it) {
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) {
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc += A1[i * MAXD + k] * R[k * MAXD + j];
+        T[i * MAXD + j] = acc;
+      }
+    for (int i = 0; i < MAXD * MAXD; ++i) R[i] = T[i];
+  }
+  for (int i = 0; i < MAXD * MAXD; ++i) out[i] = R[i];
+}
+
+int64_t grid_chunks(int64_t lext, int skip) { return (lext + skip + CS - 1) / CS; }
+
 template <int S>
-int launch_all(const float* x, int64_t B, int64_t L, int64_t ldx, const SosParams& P, int pad, float* y, int64_t ldy,
-               void* work, hipStream_t st) {
+int launch_all(const float* x, int64_t B, int64_t L, int64_t ldx, const SosParams& P, int pad, float* y,
+               int64_t ldy, void* work, hipStream_t st) {
   const int64_t lext = L + 2 * (int64_t)pad;
-  const int nch = (int)((lext + CS - 1) / CS);
-  const int64_t lpad = (int64_t)nch * CS;
-  float* G = (float*)work;                      // forward output, reversed: [B, lpad]
+  // 32-sample (128-byte) alignment of every 8-lane segment: x index of grid g = g - skip_f - pad = 0 (mod 32);
+  // forward stores K - g - 31 .. K - g land on aligned 128-byte segments of G
+  const int skip_f = (TS - pad % TS) % TS;
+  const int skip_b = (int)((TS - (lext + skip_f) % TS) % TS);
+  const int64_t K = lext - 1 + skip_f + skip_b;                  // forward grid g  <->  backward grid K - g
+  const int nch_f = (int)grid_chunks(lext, skip_f), nch_b = (int)grid_chunks(lext, skip_b);
+  const int nch_w = (int)grid_chunks(lext, TS - 1);              // what syg_sosfiltfilt_work_bytes sized the buffers for
+  const int64_t lpad = (int64_t)nch_w * CS;
+  float* G = (float*)work;                                       // forward output, reversed: [B, lpad]
   double* zs = (double*)(G + B * lpad);
-  double* init = zs + B * (int64_t)nch * (2 * S);
-  dim3 gch((unsigned)((nch + 63) / 64), (unsigned)B), gsc((unsigned)((B + 15) / 16));
+  double* init = zs + B * (int64_t)nch_w * (2 * S);
+  dim3 gsc((unsigned)((B + 15) / 16));
   // forward sweep: reads the clip (odd extension on the fly), writes G
-  hipLaunchKernelGGL((chunk_kernel<S, 0, true>), gch, dim3(64), 0, st, x, ldx, lpad, nch, lext, P,
-                     (const double*)nullptr, zs, (float*)nullptr, (int64_t)0, pad, L);
-  hipLaunchKernelGGL((scan_kernel<S, true>), gsc, dim3(256), 0, st, x, ldx, nch, B, P, (const double*)zs, init, pad, L,
-                     lext);
-  hipLaunchKernelGGL((chunk_kernel<S, 1, true>), gch, dim3(64), 0, st, x, ldx, lpad, nch, lext, P,
-                     (const double*)init, (double*)nullptr, G, lpad, pad, L);
+  dim3 gf((unsigned)((nch_f + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL((chunk_kernel<S, 0, true>), gf, dim3(64), 0, st, x, ldx, nch_f, lext, skip_f, P,
+                     (const double*)nullptr, zs, (float*)nullptr, (int64_t)0, K, pad, L);
+  hipLaunchKernelGGL((scan_kernel<S, true>), gsc, dim3(256), 0, st, x, ldx, nch_f, B, skip_f, P, (const double*)zs,
+                     init, pad, L, lext);
+  hipLaunchKernelGGL((chunk_kernel<S, 1, true>), gf, dim3(64), 0, st, x, ldx, nch_f, lext, skip_f, P,
+                     (const double*)init, (double*)nullptr, G, lpad, K, pad, L);
   SYG_CHECK_LAUNCH("sosfiltfilt forward");
-  // backward sweep: G[.., lext..lpad) is never written by the forward pass and must read as zero
-  hipLaunchKernelGGL((chunk_kernel<S, 0, false>), gch, dim3(64), 0, st, (const float*)G, lpad, lpad, nch, lext, P,
-                     (const double*)nullptr, zs, (float*)nullptr, (int64_t)0, pad, L);
-  hipLaunchKernelGGL((scan_kernel<S, false>), gsc, dim3(256), 0, st, (const float*)G, lpad, nch, B, P,
+  // backward sweep: grid positions of G outside [skip_b, skip_b + lext) are never written: the leading ones are
+  // skipped by chunk 0, whatever lies behind the sequence cannot reach an output
+  dim3 gb((unsigned)((nch_b + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL((chunk_kernel<S, 0, false>), gb, dim3(64), 0, st, (const float*)G, lpad, nch_b, lext, skip_b, P,
+                     (const double*)nullptr, zs, (float*)nullptr, (int64_t)0, K, pad, L);
+  hipLaunchKernelGGL((scan_kernel<S, false>), gsc, dim3(256), 0, st, (const float*)G, lpad, nch_b, B, skip_b, P,
                      (const double*)zs, init, pad, L, lext);
-  hipLaunchKernelGGL((chunk_kernel<S, 2, false>), gch, dim3(64), 0, st, (const float*)G, lpad, lpad, nch, lext, P,
-                     (const double*)init, (double*)nullptr, y, ldy, pad, L);
+  hipLaunchKernelGGL((chunk_kernel<S, 2, false>), gb, dim3(64), 0, st, (const float*)G, lpad, nch_b, lext, skip_b, P,
+                     (const double*)init, (double*)nullptr, y, ldy, K, pad, L);
   SYG_CHECK_LAUNCH("sosfiltfilt backward");
   return SYG_OK;
 }
@@ -257,7 +342,7 @@ using namespace syg;
 extern "C" int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, int n_sections) {
   if (B < 1 || L < 1 || padlen < 0 || n_sections < 1 || n_sections > MAXS) return -1;
   const int64_t lext = L + 2 * (int64_t)padlen;
-  const int64_t nch = (lext + CS - 1) / CS;
+  const int64_t nch = (lext + (TS - 1) + CS - 1) / CS;   // grid = sequence + up to TS - 1 alignment positions
   return B * nch * CS * (int64_t)sizeof(float) + 2 * B * nch * 2 * n_sections * (int64_t)sizeof(double);
 }
 
@@ -285,25 +370,15 @@ extern "C" int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t
     P.zi[2 * s] = zi_host[2 * s];
     P.zi[2 * s + 1] = zi_host[2 * s + 1];
   }
-  // A: homogeneous one-step map, column j = step(e_j, x = 0); then A^CS by repeated squaring
-  double A[MAXD * MAXD] = {0}, T[MAXD * MAXD];
+  // A: homogeneous one-step map, column j = step(e_j, x = 0); A^CS (and A^(CS - skip) per sweep) on the host
+  double A1[MAXD * MAXD] = {0};
   for (int j = 0; j < D; ++j) {
     double z[MAXD] = {0};
     z[j] = 1.0;
     host_step(sos5, S, z, 0.0);
-    for (int i = 0; i < D; ++i) A[i * MAXD + j] = z[i];
+    for (int i = 0; i < D; ++i) A1[i * MAXD + j] = z[i];
   }
-  for (int sq = 0; (1 << sq) < CS; ++sq) {
-    for (int i = 0; i < D; ++i)
-      for (int j = 0; j < D; ++j) {
-        double acc = 0.0;
-        for (int k = 0; k < D; ++k) acc += A[i * MAXD + k] * A[k * MAXD + j];
-        T[i * MAXD + j] = acc;
-      }
-    for (int i = 0; i < D; ++i)
-      for (int j = 0; j < D; ++j) A[i * MAXD + j] = T[i * MAXD + j];
-  }
-  for (int i = 0; i < MAXD * MAXD; ++i) P.apow[i] = A[i];
+  mat_pow(A1, D, CS, P.apow);
   hipStream_t st = (hipStream_t)stream;
   switch (S) {
     case 1: return launch_all<1>(x, B, L, ldx, P, padlen, y, ldy, work, st);
