@@ -208,16 +208,29 @@ __device__ __forceinline__ double row_bcast(double v) {
   return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
 }
 template <int D, int J>
-struct RowDot {
-  static __device__ __forceinline__ double run(const double (&arow)[D], double s, double acc) {
-    acc = fma(arow[J], row_bcast<J>(s), acc);
-    return RowDot<D, J + 1>::run(arow, s, acc);
+__device__ __forceinline__ void bcast_all(double (&b)[D], double s) {
+  if constexpr (J < D) {
+    b[J] = row_bcast<J>(s);
+    bcast_all<D, J + 1>(b, s);
   }
-};
+}
+
+// row . state with four independent partial sums (the serial scan is latency-bound: one accumulator would chain
+// D dependent fp64 FMAs per step); fixed summation order, so results are reproducible
 template <int D>
-struct RowDot<D, D> {
-  static __device__ __forceinline__ double run(const double (&)[D], double, double acc) { return acc; }
-};
+__device__ __forceinline__ double row_dot(const double (&arow)[D], double s, double z) {
+  double b[D];
+  bcast_all<D, 0>(b, s);
+  double p0 = z, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+  for (int j = 0; j < D; j += 4) {
+    p0 = fma(arow[j], b[j], p0);
+    if (j + 1 < D) p1 = fma(arow[j + 1], b[j + 1], p1);
+    if (j + 2 < D) p2 = fma(arow[j + 2], b[j + 2], p2);
+    if (j + 3 < D) p3 = fma(arow[j + 3], b[j + 3], p3);
+  }
+  return (p0 + p1) + (p2 + p3);
+}
 
 template <int S, bool SRCX>
 __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in, int64_t ldin, int nch, int64_t B,
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in,
   const int rc = (r < D) ? r : 0;
   const double* zp = zs + (int64_t)bb * nch * D + rc;
   double* ip = init + (int64_t)bb * nch * D + rc;
-  constexpr int AHEAD = 4;
+  constexpr int AHEAD = 32;       // chunk states in flight: a step is ~150 cycles, memory latency an order more
   double zq[AHEAD];
 #pragma unroll
   for (int k = 0; k < AHEAD; ++k) zq[k] = (live && k < nch) ? zp[(int64_t)k * D] : 0.0;
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ in,
       if (c0 + k < nch) {
         if (live) ip[(int64_t)(c0 + k) * D] = s;
         // chunk 0 (short by `skip`) ran pass A from the true state: its report is the state at chunk 1
-        s = (c0 + k == 0) ? zq[k] : RowDot<D, 0>::run(arow, s, zq[k]);
+        s = (c0 + k == 0) ? zq[k] : row_dot<D>(arow, s, zq[k]);
       }
     }
 #pragma unroll
