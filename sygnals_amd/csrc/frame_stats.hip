@@ -45,10 +45,16 @@ __device__ __forceinline__ double edge_at(double first, double last, double step
   return m + first;
 }
 
+// STAGED: the workgroup's FS_WAVES consecutive frames overlap (hop < frame_length), so their common sample run
+// [t0 hop - pad, + (FS_WAVES-1) hop + frame_length) is copied once into LDS (zero padded) and both passes of every
+// frame read it from there -- the passes are bound by L2 traffic otherwise (each sample is needed
+// 2 x frame_length / hop times).
+template <bool STAGED>
 __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int flen, int hop, int pad, int64_t T, int num_bins,
     int mask, float* __restrict__ out) {
   __shared__ unsigned hist[FS_WAVES][FS_MAXBINS];
+  extern __shared__ __attribute__((aligned(16))) float stage[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t t = (int64_t)blockIdx.x * FS_WAVES + w;
   const int64_t b = blockIdx.y;
@@ -57,6 +63,25 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
   const int64_t s0 = live ? t * (int64_t)hop - pad : 0;
   const double n = (double)flen;
   const double THR = 1e-10;
+  const int64_t sbase = (int64_t)blockIdx.x * FS_WAVES * hop - pad;      // first staged sample
+  const int span = (FS_WAVES - 1) * hop + flen;
+  if (STAGED) {
+    for (int i = threadIdx.x; i < span; i += FS_WAVES * 64) {
+      const int64_t s = sbase + i;
+      stage[i] = (s >= 0 && s < L) ? yb[s] : 0.f;
+    }
+    __syncthreads();
+  }
+  // sample s of the clip, zero padded / edge padded
+  auto at0 = [&](int64_t s) -> float {
+    if (STAGED) return stage[s - sbase];
+    return (s >= 0 && s < L) ? yb[s] : 0.f;
+  };
+  auto ate = [&](int64_t s) -> float {
+    const int64_t sc = s < 0 ? 0 : (s >= L ? L - 1 : s);
+    if (STAGED && sc >= sbase && sc < sbase + span) return stage[sc - sbase];
+    return yb[sc];
+  };
 
   // ---- pass 1: raw sums, extrema, zero crossings
   double sx = 0.0, sa = 0.0, sq = 0.0, mx = -1.79e308, mn = 1.79e308, pk = 0.0;
@@ -64,12 +89,11 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
   if (live) {
     for (int i = lane; i < flen; i += 64) {
       const int64_t s = s0 + i;
-      const double x = (s >= 0 && s < L) ? (double)yb[s] : 0.0;           // zero padding
+      const double x = (double)at0(s);                                    // zero padding
       sx += x; sa += fabs(x); sq += x * x;
       mx = fmax(mx, x); mn = fmin(mn, x); pk = fmax(pk, fabs(x));
       if ((mask & 256) && i >= 1) {                                       // edge padding for the ZCR
-        const int64_t sc = s < 0 ? 0 : (s >= L ? L - 1 : s), sp = (s - 1) < 0 ? 0 : ((s - 1) >= L ? L - 1 : s - 1);
-        double a = (double)yb[sp], c = (double)yb[sc];
+        double a = (double)ate(s - 1), c = (double)ate(s);
         a = (fabs(a) <= THR) ? 0.0 : a;
         c = (fabs(c) <= THR) ? 0.0 : c;
         zc += ((a < 0.0) != (c < 0.0)) ? 1.0 : 0.0;
@@ -93,7 +117,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
   if (live) {
     for (int i = lane; i < flen; i += 64) {
       const int64_t s = s0 + i;
-      const double x = (s >= 0 && s < L) ? (double)yb[s] : 0.0;
+      const double x = (double)at0(s);
       const double d = x - mean;
       const double d2 = d * d;
       m2 += d2; m3 += d2 * d; m4 += d2 * d2;
@@ -180,8 +204,15 @@ extern "C" int syg_frame_stats_f32(const float* y, int64_t B, int64_t L, int64_t
   SYG_REQUIRE(B <= 65535, "frame_stats: at most 65535 clips per call");
   const int64_t gx = (T + FS_WAVES - 1) / FS_WAVES;
   SYG_REQUIRE(gx < (int64_t)0x7fffffff, "frame_stats: too many frames");
-  hipLaunchKernelGGL(frame_stats_kernel, dim3((unsigned)gx, (unsigned)B), dim3(FS_WAVES * 64), 0, (hipStream_t)stream, y,
-                     L, ldy, frame_length, hop, center ? frame_length / 2 : 0, T, num_bins, mask, out);
+  const size_t span_bytes = ((size_t)(FS_WAVES - 1) * hop + frame_length) * sizeof(float);
+  const int pad = center ? frame_length / 2 : 0;
+  if (hop < frame_length && span_bytes <= 48 * 1024) {
+    hipLaunchKernelGGL(frame_stats_kernel<true>, dim3((unsigned)gx, (unsigned)B), dim3(FS_WAVES * 64), span_bytes,
+                       (hipStream_t)stream, y, L, ldy, frame_length, hop, pad, T, num_bins, mask, out);
+  } else {
+    hipLaunchKernelGGL(frame_stats_kernel<false>, dim3((unsigned)gx, (unsigned)B), dim3(FS_WAVES * 64), 0,
+                       (hipStream_t)stream, y, L, ldy, frame_length, hop, pad, T, num_bins, mask, out);
+  }
   SYG_CHECK_LAUNCH("frame_stats");
   return SYG_OK;
 }
