@@ -105,7 +105,7 @@ __global__ void mel_dense_kernel(const float* __restrict__ P, int64_t T, int F, 
 // Welch: grid (nblk, B); workgroup loops over segments blockIdx.x, += gridDim.x and keeps
 // per-bin partial sums in registers; a second kernel combines the partials in fixed order.
 constexpr int WELCH_NT = 256;
-constexpr int WELCH_MAXACC = (MAX_N / 2 + 1 + WELCH_NT - 1) / WELCH_NT;  // 17
+constexpr int WELCH_MAXPAIR = (MAX_N / 4 + 1 + WELCH_NT - 1) / WELCH_NT;  // mirror pairs (k, M - k) per thread: 9
 
 __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
     const float* __restrict__ x, int64_t L, int64_t ldx, int nperseg, int step, int nfft, int64_t nseg,
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t b = blockIdx.y;
   const float* xr = x + b * ldx;
-  float acc[WELCH_MAXACC];
+  float acc[WELCH_MAXPAIR], accm[WELCH_MAXPAIR];
 #pragma unroll
-  for (int j = 0; j < WELCH_MAXACC; ++j) acc[j] = 0.f;
+  for (int j = 0; j < WELCH_MAXPAIR; ++j) { acc[j] = 0.f; accm[j] = 0.f; }
   for (int64_t sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
     const float* seg = xr + sg * (int64_t)step;
     // one pass over the segment: the samples stay in registers while the mean is reduced, then they are detrended,
@@ -158,21 +158,32 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
     }
     __syncthreads();
     float2* Z = block_fft(xa, xb, M, tw + nfft, tid, WELCH_NT);
+    // periodogram by mirror pairs: bins k and M - k come out of the same two points Z[k], Z[M-k] and one twiddle
+    // W_{2M}^k:  X[k] = (E + w O)/2,  X[M-k] = conj(E - w O)/2,  E = Z[k] + conj(Z[M-k]),  O = -i (Z[k] - conj(Z[M-k]))
 #pragma unroll
-    for (int j = 0; j < WELCH_MAXACC; ++j) {
+    for (int j = 0; j < WELCH_MAXPAIR; ++j) {
       const int k = tid + j * WELCH_NT;
-      if (k <= M) {
-        const float2 X = rfft_bin(Z, M, k, tw);
-        acc[j] += fmaf(X.x, X.x, X.y * X.y);
+      if (k <= (M >> 1)) {
+        const float2 zk = Z[k], zm = Z[(M - k) & (M - 1)];
+        const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);
+        const float2 O = make_float2(zk.y + zm.y, zm.x - zk.x);
+        const float2 wO = cmul(tw[k], O);
+        const float ax = 0.5f * (E.x + wO.x), ay = 0.5f * (E.y + wO.y);
+        const float bx = 0.5f * (E.x - wO.x), by = 0.5f * (E.y - wO.y);
+        acc[j] += fmaf(ax, ax, ay * ay);                      // bin k
+        accm[j] += fmaf(bx, bx, by * by);                     // bin M - k (the same bin when k = M/2)
       }
     }
     __syncthreads();
   }
   float* po = partial + ((int64_t)b * gridDim.x + blockIdx.x) * (int64_t)(M + 1);
 #pragma unroll
-  for (int j = 0; j < WELCH_MAXACC; ++j) {
+  for (int j = 0; j < WELCH_MAXPAIR; ++j) {
     const int k = tid + j * WELCH_NT;
-    if (k <= M) po[k] = acc[j];
+    if (k <= (M >> 1)) {
+      po[k] = acc[j];
+      if (M - k != k) po[M - k] = accm[j];
+    }
   }
 }
 
