@@ -7,7 +7,9 @@ OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 20 --warmup 200 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
+# the trace pass runs the default step counts (200 warm-up + 500 timed + 100 for the roofline block): its per-dispatch
+# average is then dominated by steady-clock launches, like the figure bench.py prints
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc1" -- $CMD > "$OUT/pmc1.log" 2>&1
 echo "pmc1 rc=$?"
