@@ -97,3 +97,39 @@ def save_data(data, output_path, sr=None) -> None:
         wavfile.write(str(p), int(sr or data[1]), np.round(x * 32767.0).astype(np.int16))
     else:
         raise TypeError(f"Unsupported data type for core saving handlers: {type(data)}.")
+
+
+def read_clips(paths, length: Union[int, None] = None, mono: bool = True, pin: bool = False):
+    """Batched ingest for the device path: decode WAV / NPZ / CSV clips into ONE float32 [B, L]
+    host array (zero padded / cut to `length`, default = the longest clip), ready for a single host-to-device copy.
+
+    Multi-channel audio is mixed down like `sygnals features extract` does (mean over channels,
+    cli/features_cmd.py:66-68).  With pin=True the batch is returned as a pinned torch tensor so that
+    `tensor.to(device, non_blocking=True)` overlaps with device work.  Returns (batch, sample_rates).
+    """
+    sigs, srs = [], []
+    for p in paths:
+        r = read_data(p)
+        if isinstance(r, tuple) and np.ndim(r[0]) == 2:
+            if not mono:
+                raise ValueError(f"{p}: multi-channel audio needs mono=True (mix-down)")
+            r = (np.mean(r[0], axis=0), r[1])
+        y, sr = signal_from(r)
+        if y.ndim != 1:
+            raise ValueError(f"{p}: expected a 1-D signal, got shape {y.shape}")
+        sigs.append(y)
+        srs.append(sr)
+    if not sigs:
+        raise ValueError("read_clips: no input files")
+    L = int(length) if length is not None else max(len(s) for s in sigs)
+    if L < 1:
+        raise ValueError("read_clips: length must be >= 1")
+    batch = np.zeros((len(sigs), L), dtype=np.float32)
+    for i, s in enumerate(sigs):
+        n = min(len(s), L)
+        batch[i, :n] = s[:n]
+    if pin:
+        import torch
+        t = torch.from_numpy(batch)
+        return (t.pin_memory() if torch.cuda.is_available() else t), srs
+    return batch, srs

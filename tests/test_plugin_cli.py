@@ -118,3 +118,25 @@ def test_io_roundtrip(tmp_path):
     assert np.array_equal(sig, np.arange(4.0))
     with pytest.raises(ValueError):
         sio.save_data({"a": np.zeros(2)}, tmp_path / "d.csv")
+
+
+def test_read_clips_batches_mixed_inputs(tmp_path):
+    """Batched ingest: WAV (mono + stereo mix-down), NPZ and CSV clips into one padded [B, L] batch."""
+    from sygnals_amd import io as sio
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-0.5, 0.5, 1000)
+    st = rng.uniform(-0.5, 0.5, (2, 700))
+    sio.save_data((a, 16000), tmp_path / "a.wav", sr=16000)
+    from scipy.io import wavfile
+    wavfile.write(str(tmp_path / "st.wav"), 16000, np.round(st.T * 32767).astype(np.int16))
+    np.savez(tmp_path / "n.npz", data=a[:300], sr=8000)
+    sio.save_data(a[:50], tmp_path / "c.csv")
+    batch, srs = sio.read_clips([tmp_path / "a.wav", tmp_path / "st.wav", tmp_path / "n.npz", tmp_path / "c.csv"])
+    assert batch.dtype == np.float32 and batch.shape == (4, 1000) and srs == [16000, 16000, 8000, None]
+    assert np.abs(batch[0] - np.round(a * 32767) / 32768).max() < 1e-6
+    assert np.abs(batch[1, :700] - (np.round(st * 32767) / 32768).mean(axis=0)).max() < 1e-6 and not batch[1, 700:].any()
+    assert np.allclose(batch[2, :300], a[:300], atol=1e-7) and np.allclose(batch[3, :50], a[:50], atol=1e-7)
+    cut, _ = sio.read_clips([tmp_path / "a.wav"], length=10)
+    assert cut.shape == (1, 10)
+    with pytest.raises(ValueError):
+        sio.read_clips([])
