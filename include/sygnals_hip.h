@@ -175,7 +175,8 @@ int syg_contrast_pv_f32(const float* mag, int64_t N, int F, const int32_t* cplan
 
 /* contrast[b, r, t] = power_to_db(peak) - power_to_db(valley) (ref 1, amin, top_db clamp per
  * [R, T] matrix), the last step of librosa.feature.spectral_contrast (frequency_domain.py:200-207).
- *   pv [B, 2, R, T] (peak, valley) -> out [B, R, T]; top_db < 0 disables the clamp. */
+ *   pv [B, 2, R, T] (peak, valley) -> out [B, R, T]; top_db < 0 disables the clamp;
+ *   amin <= 0 selects librosa's linear=True: out = peak - valley. */
 int syg_contrast_db_f32(const float* pv, int64_t B, int R, int64_t T, float amin, float top_db, float* out,
                         void* stream);
 

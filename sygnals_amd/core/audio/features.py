@@ -42,7 +42,7 @@ def rms_energy(y=None, *, S=None, frame_length: int = 2048, hop_length: int = 51
         raise TypeError(f"rms_energy: unsupported librosa arguments on the device backend: {sorted(kwargs)}")
     logger.debug(f"Calculating RMS Energy: frame={frame_length}, hop={hop_length}, center={center}")
     if S is not None:                       # librosa ignores y when S is given
-        Sm = np.abs(np.asarray(S, dtype=np.float64))
+        Sm = np.asarray(S)                   # (the kernel squares the values: |S|^2 needs no abs on the host)
         if Sm.shape[0] != frame_length // 2 + 1:
             raise ValueError(f"Since S.shape[-2] is {Sm.shape[0]}, frame_length is expected to be "
                              f"{2 * Sm.shape[0] - 2} or {2 * Sm.shape[0] - 1}; found {frame_length}")

@@ -101,10 +101,7 @@ def spectral_contrast(S, sr: int, n_bands: int = 6, fmin: float = 200.0, freqs=N
     plan = T.contrast_plan(freqs, sr, n_bands, fmin, quantile)
     mag = ops.to_device_f32(np.ascontiguousarray(S.T))               # frame-major [T, F]
     pv = ops.contrast_pv(mag, plan)                                   # [2, R, T]
-    if linear:
-        a = pv.cpu().numpy().astype(np.float64)
-        return a[0] - a[1]
-    return ops.contrast_db(pv[None])[0].cpu().numpy().astype(np.float64)
+    return ops.contrast_db(pv[None], linear=bool(linear))[0].cpu().numpy().astype(np.float64)
 
 
 FREQUENCY_DOMAIN_FEATURES: Dict[str, Any] = {

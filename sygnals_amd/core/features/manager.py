@@ -167,11 +167,7 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 idx = stats[:, 4].cpu().numpy().astype(np.int64)
                 res[name] = freqs[idx] if to_host else stats[:, 4] * float(sr / frame_length)
         elif name == "spectral_contrast":
-            if cp.get("linear", False):
-                pv_h = cpv.cpu().numpy().astype(np.float64)        # linear=True: plain difference of the means
-                cdb, host_c = pv_h[:, 0] - pv_h[:, 1], (lambda a: a)
-            else:
-                cdb, host_c = ops.contrast_db(cpv), host
+            cdb, host_c = ops.contrast_db(cpv, linear=bool(cp.get("linear", False))), host
             R = cdb.shape[1]
             for i in range(R - 1):
                 res[f"contrast_band_{i}"] = host_c(cdb[:, i])

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void contrast_db_kernel(const float* __restric
   const int64_t b = blockIdx.x, n = (int64_t)R * T;
   const float* pk = pv + (b * 2 + 0) * n;
   const float* vl = pv + (b * 2 + 1) * n;
+  if (amin <= 0.f) {                      // linear=True: plain difference of the means
+    for (int64_t i = tid; i < n; i += 256) out[b * n + i] = pk[i] - vl[i];
+    return;
+  }
   float m0 = 0.f, m1 = 0.f;
   for (int64_t i = tid; i < n; i += 256) { m0 = fmaxf(m0, pk[i]); m1 = fmaxf(m1, vl[i]); }
   m0 = wave_max(m0); m1 = wave_max(m1);
@@ -208,7 +212,7 @@ extern "C" int syg_contrast_db_f32(const float* pv, int64_t B, int R, int64_t T,
                                    float* out, void* stream) {
   SYG_REQUIRE(pv && out, "contrast_db: null pointer argument");
   SYG_REQUIRE(B >= 1 && B < (int64_t)0x7fffffff && R >= 1 && T >= 1, "contrast_db: bad shape");
-  SYG_REQUIRE(amin > 0.f, "contrast_db: amin must be strictly positive");
+  SYG_REQUIRE(amin >= 0.f, "contrast_db: amin must be positive (or 0 for the linear difference)");
   hipLaunchKernelGGL(contrast_db_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, pv, R, T, amin, top_db,
                      out);
   SYG_CHECK_LAUNCH("contrast_db");

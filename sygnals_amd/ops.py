@@ -487,8 +487,11 @@ def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: 
     return out
 
 
-def contrast_db(pv: torch.Tensor, amin: float = 1e-10, top_db: Optional[float] = 80.0) -> torch.Tensor:
-    """pv [B, 2, R, T] (peak, valley means) -> spectral contrast in dB [B, R, T]."""
+def contrast_db(pv: torch.Tensor, amin: float = 1e-10, top_db: Optional[float] = 80.0, linear: bool = False) -> torch.Tensor:
+    """pv [B, 2, R, T] (peak, valley means) -> spectral contrast [B, R, T]: dB difference, or the plain difference
+    of the means with linear=True (librosa's `linear` option)."""
+    if linear:
+        amin = 0.0
     require_gpu()
     pv = pv.contiguous()
     B, two, R, Tn = pv.shape
