@@ -185,6 +185,16 @@ constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, 
 
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// after the four in-row steps every lane of a row holds its row's result; two row broadcasts (lane 15 of the row
+// below into rows 1 and 3, then lane 31 into rows 2 and 3) fold the rows into row 3, read back from lane 63
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_rows_f(float v) {      // lanes of rows outside ROWMASK keep v
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_rows_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xF, false); }
+
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f<DPP_QP_1032>(v);
   v += dpp_f<DPP_QP_2301>(v);
@@ -197,22 +207,27 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f<DPP_QP_2301>(v));
   v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
   v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
-  return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+  v = fmaxf(v, dpp_rows_f<DPP_ROW_BCAST15, 0xA>(v));
+  v = fmaxf(v, dpp_rows_f<DPP_ROW_BCAST31, 0xC>(v));
+  return rl_f(v, 63);
 }
 __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, dpp_f<DPP_QP_1032>(v));
   v = fminf(v, dpp_f<DPP_QP_2301>(v));
   v = fminf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
   v = fminf(v, dpp_f<DPP_ROW_MIRROR>(v));
-  return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+  v = fminf(v, dpp_rows_f<DPP_ROW_BCAST15, 0xA>(v));
+  v = fminf(v, dpp_rows_f<DPP_ROW_BCAST31, 0xC>(v));
+  return rl_f(v, 63);
 }
 __device__ __forceinline__ int wave_min_i(int v) {
   v = min(v, dpp_i<DPP_QP_1032>(v));
   v = min(v, dpp_i<DPP_QP_2301>(v));
   v = min(v, dpp_i<DPP_ROW_HALF_MIRROR>(v));
   v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
-  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+  v = min(v, dpp_rows_i<DPP_ROW_BCAST15, 0xA>(v));
+  v = min(v, dpp_rows_i<DPP_ROW_BCAST31, 0xC>(v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
   v += dpp_i<DPP_QP_1032>(v);
