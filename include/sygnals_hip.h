@@ -245,6 +245,32 @@ int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_
                        const float* twiddle, const float* basis, int n_filt, const int32_t* hull_host,
                        float* out, int64_t out_bstride, int row0, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * FFT-backed 1-D operations; the host composes them with the power-of-two complex FFT above.
+ *   syg_pack_rows_f32       out[r, i] = (x[r, j] - mean_r) * window[i] for i < min(len, n), 0 up to n;
+ *                           j = reverse ? len-1-i : i; mean_r only when detrend != 0 (float64 sum, needs `work` of
+ *                           syg_pack_rows_work_bytes(rows) bytes); cplx != 0 writes complex rows (value, 0).
+ *                           A real row of n floats is at the same time the packed row z[m] = x[2m] + i x[2m+1]
+ *                           of n/2 complex elements consumed by syg_rconv_spectrum_c64.
+ *   syg_rconv_spectrum_c64  za [rows, H], zb [rows_b (1 or rows), H]: length-H complex FFTs of two packed real
+ *                           rows of 2H samples -> out [rows, H] (may alias za): the packed transform of their
+ *                           circular convolution; its inverse length-H FFT, read as 2H floats, is the real
+ *                           result.  scipy.signal.fftconvolve / correlate as called at sygnals/core/dsp.py:333,
+ *                           :388 (correlation = convolution with the reversed second input).
+ *   syg_analytic_mask_c64   in place X[r, k] *= h[k], h = scipy.signal.hilbert's mask (1, 2.., [1], 0..)
+ *                           -- sygnals/core/transforms.py:146, sygnals/core/dsp.py:609
+ *   syg_psd_onesided_f32    out[r, k] = scale * |X[r, k]|^2 * (1 for DC and the even-n Nyquist bin, else 2),
+ *                           k <= n/2, from the full spectrum X [rows, n] -- scipy.signal.periodogram as called
+ *                           at sygnals/core/dsp.py:484-492
+ * ------------------------------------------------------------------------------- */
+int64_t syg_pack_rows_work_bytes(int64_t rows);
+int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window, int detrend,
+                      int reverse, int cplx, float* out, int64_t n, void* work, void* stream);
+int syg_rconv_spectrum_c64(const float* za, const float* zb, int64_t rows, int64_t rows_b, int64_t H, float* out,
+                           void* stream);
+int syg_analytic_mask_c64(float* X, int64_t rows, int64_t n, void* stream);
+int syg_psd_onesided_f32(const float* X, int64_t rows, int64_t n, double scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

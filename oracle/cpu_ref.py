@@ -13,8 +13,10 @@ PARITY STATUS
   pinned   : design_butterworth_sos, apply_sos_filter/*_pass_filter, compute_fft,
              compute_ifft, apply_window, compute_psd_welch, spectral_centroid,
              spectral_bandwidth, spectral_flatness, spectral_rolloff,
-             dominant_frequency, and the seven time-domain frame functions
-             (mean/std/skewness/kurtosis/peak/crest/entropy)  -- checked against
+             dominant_frequency, the seven time-domain frame functions
+             (mean/std/skewness/kurtosis/peak/crest/entropy), apply_convolution,
+             compute_correlation, compute_autocorrelation, compute_psd_periodogram,
+             hilbert_transform, amplitude_envelope(hilbert)  -- checked against
              tests/golden/ref_*.npz, which were produced by executing the
              reference's own functions.
   UNPINNED : stft, mel_filterbank, power_to_db, melspectrogram, mfcc,
@@ -579,6 +581,107 @@ def welch_explicit(x, fs=1.0, window="hann", nperseg=256, noverlap=None, nfft=No
     else:
         P[:, 1:-1] *= 2
     return np.fft.rfftfreq(nfft, 1 / fs), P.mean(axis=0)
+
+
+# --------------------------------------------------------------------------
+# f-3  FFT-backed 1-D operations: convolution / correlation (dsp.py:294-433 -> scipy.signal.fftconvolve,
+#      scipy.signal.correlate), periodogram (dsp.py:438-498 -> scipy.signal.periodogram), analytic signal
+#      (transforms.py:119-151, dsp.py:565-636 -> scipy.signal.hilbert).  Restated from the definitions in float64
+#      and pinned on tests/golden/ref_dsp2.npz (outputs of the reference functions).
+# --------------------------------------------------------------------------
+def conv_slice(n, m, mode):
+    """Start and length of scipy's `mode` result inside the full linear convolution of n and m samples
+    ('same' is centred with respect to the FIRST input, scipy.signal._signaltools._centered)."""
+    if mode == "full":
+        return 0, n + m - 1
+    if mode == "same":
+        return (m - 1) // 2, n
+    if mode == "valid":
+        return min(n, m) - 1, max(n, m) - min(n, m) + 1
+    raise ValueError("acceptable mode flags are 'valid', 'same', or 'full'")
+
+
+def apply_convolution(data, kernel, mode="same"):             # dsp.py:294-337
+    data = np.asarray(data, dtype=np.float64)
+    kernel = np.asarray(kernel, dtype=np.float64)
+    if data.ndim != 1 or kernel.ndim != 1:
+        raise ValueError("Input data and kernel must be 1D arrays.")
+    if data.size == 0 or kernel.size == 0:
+        return np.array([], dtype=np.float64)
+    full = np.convolve(data, kernel, mode="full")              # direct sum: the definition fftconvolve evaluates
+    start, count = conv_slice(data.shape[0], kernel.shape[0], mode)
+    return full[start:start + count]
+
+
+def compute_correlation(x, y, mode="full", method="auto"):    # dsp.py:342-394
+    """scipy.signal.correlate(x, y) = convolve(x, y[::-1]) for real input, whatever `method`."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if x.ndim != 1 or y.ndim != 1:
+        raise ValueError("Input sequences for correlation must be 1D arrays.")
+    return apply_convolution(x, y[::-1], mode)
+
+
+def compute_autocorrelation(x, mode="full", method="auto"):   # dsp.py:396-433
+    return compute_correlation(x, x, mode, method)
+
+
+def compute_psd_periodogram(x, fs=1.0, window="hann", nfft=None, detrend="constant", scaling="density"):
+    """dsp.py:438-498: scipy.signal.periodogram = one Welch segment spanning the (possibly truncated) signal."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    if x.size == 0:
+        return np.empty(0), np.empty(0)
+    if nfft is None:
+        nfft = x.shape[0]
+    if nfft < x.shape[0]:
+        x = x[:nfft]
+    nperseg = x.shape[0]
+    w = scipy.signal.get_window(window, nperseg) if isinstance(window, (str, tuple)) else np.asarray(window, float)
+    seg = x
+    if detrend == "constant":
+        seg = seg - seg.mean()
+    elif detrend == "linear":
+        seg = scipy.signal.detrend(seg, type="linear")
+    X = np.fft.rfft(seg * w, n=nfft)
+    scale = 1.0 / (fs * (w * w).sum()) if scaling == "density" else 1.0 / w.sum() ** 2
+    P = (np.abs(X) ** 2) * scale
+    if nfft % 2:
+        P[1:] *= 2
+    else:
+        P[1:-1] *= 2
+    return np.fft.rfftfreq(nfft, 1 / fs), P
+
+
+def hilbert_transform(data):                                  # transforms.py:119-151
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    n = data.shape[0]
+    if n == 0:
+        raise ValueError("N must be positive.")
+    h = np.zeros(n)
+    if n % 2 == 0:
+        h[0] = h[n // 2] = 1.0
+        h[1:n // 2] = 2.0
+    else:
+        h[0] = 1.0
+        h[1:(n + 1) // 2] = 2.0
+    return np.fft.ifft(np.fft.fft(data) * h)
+
+
+def amplitude_envelope(y, method="hilbert", frame_length=None, hop_length=None):   # dsp.py:565-636
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    if method == "hilbert":
+        return np.abs(hilbert_transform(y))
+    if method == "rms":
+        if frame_length is None or hop_length is None:
+            raise ValueError("frame_length and hop_length are required for 'rms' envelope method.")
+        return rms_energy(y, frame_length=frame_length, hop_length=hop_length, center=True)
+    raise ValueError(f"Unsupported envelope method: {method}. Choose 'hilbert' or 'rms'.")
 
 
 # --------------------------------------------------------------------------

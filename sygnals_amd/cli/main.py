@@ -3,7 +3,7 @@
 `features extract` keeps the option surface of sygnals/cli/features_cmd.py:30-113
 (-o/--output, repeatable -f/--feature incl. 'all', --frame-length 2048, --hop-length 512;
 .csv -> DataFrame, .npz -> dict of arrays; ValueError -> click.UsageError).  The `dsp` and
-`filter` groups follow the surface documented in the reference's README.md:483-533, 704-841 --
+`filter` groups follow the surface documented in the reference's README.md:483-533, 704-900 --
 in the reference snapshot those groups are commented out (sygnals/cli/main.py:29-33, 115-119), so
 they are provided here rather than kept.  Run stand-alone as `python -m sygnals_amd.cli.main ...`
 or attach the groups to the reference CLI through the plugin (register_cli_commands).
@@ -151,6 +151,96 @@ def dsp_welch(input_file, output, fs, window, nperseg, noverlap, nfft, detrend, 
     else:
         sio.save_data(pd.DataFrame({"Frequency": f, "PSD": p}), output)
     click.echo(f"Welch PSD saved to '{Path(output).name}'.")
+
+
+@dsp_cmd.command("psd-periodogram")
+@click.argument("input_file", type=click.Path(exists=True, dir_okay=False))
+@click.option("-o", "--output", required=True, type=click.Path())
+@click.option("--fs", type=float, required=True)
+@click.option("--window", default="hann", show_default=True)
+@click.option("--nfft", type=int, default=None)
+@click.option("--detrend", type=click.Choice(["none", "constant", "linear"]), default="constant", show_default=True)
+@click.option("--scaling", type=click.Choice(["density", "spectrum"]), default="density", show_default=True)
+def dsp_periodogram(input_file, output, fs, window, nfft, detrend, scaling):
+    """Estimate Power Spectral Density using Periodogram."""
+    from ..core.dsp import compute_psd_periodogram
+    try:
+        x, _ = _load_signal(input_file, fs)
+        f, p = compute_psd_periodogram(x, fs=fs, window=window, nfft=nfft,
+                                       detrend=False if detrend == "none" else detrend, scaling=scaling)
+    except ValueError as e:
+        raise click.UsageError(str(e))
+    if Path(output).suffix.lower() == ".npz":
+        sio.save_data({"frequencies": f, "psd": p}, output)
+    else:
+        sio.save_data(pd.DataFrame({"Frequency": f, "PSD": p}), output)
+    click.echo(f"Periodogram PSD saved to '{Path(output).name}'.")
+
+
+def _save_series(y, sr, output):
+    if Path(output).suffix.lower() == ".wav":
+        if sr is None:
+            raise click.UsageError("Writing audio needs a sampling rate; the input file carries none.")
+        sio.save_data((y, int(sr)), output)
+    else:
+        sio.save_data(y, output)
+
+
+@dsp_cmd.command("convolution")
+@click.argument("input_file_1", type=click.Path(exists=True, dir_okay=False))
+@click.argument("input_file_2", type=click.Path(exists=True, dir_okay=False))
+@click.option("-o", "--output", required=True, type=click.Path())
+@click.option("--mode", type=click.Choice(["full", "valid", "same"]), default="same", show_default=True)
+def dsp_convolution(input_file_1, input_file_2, output, mode):
+    """Apply convolution to a 1D signal using a 1D kernel."""
+    from ..core.dsp import apply_convolution
+    x, sr = _load_signal(input_file_1, None)
+    k, _ = _load_signal(input_file_2, None)
+    try:
+        y = apply_convolution(x, k, mode=mode)
+    except ValueError as e:
+        raise click.UsageError(str(e))
+    _save_series(y, sr if mode == "same" else None, output)
+    click.echo(f"Convolution ({mode}) saved to '{Path(output).name}'.")
+
+
+@dsp_cmd.command("correlation")
+@click.argument("input_file_1", type=click.Path(exists=True, dir_okay=False))
+@click.argument("input_file_2", type=click.Path(exists=True, dir_okay=False), required=False)
+@click.option("-o", "--output", required=True, type=click.Path())
+@click.option("--mode", type=click.Choice(["full", "valid", "same"]), default="full", show_default=True)
+@click.option("--method", type=click.Choice(["auto", "direct", "fft"]), default="auto", show_default=True)
+def dsp_correlation(input_file_1, input_file_2, output, mode, method):
+    """Compute cross-correlation (two inputs) or autocorrelation (one input)."""
+    from ..core.dsp import compute_autocorrelation, compute_correlation
+    x, _ = _load_signal(input_file_1, None)
+    try:
+        if input_file_2 is None:
+            y = compute_autocorrelation(x, mode=mode, method=method)
+        else:
+            y = compute_correlation(x, _load_signal(input_file_2, None)[0], mode=mode, method=method)
+    except ValueError as e:
+        raise click.UsageError(str(e))
+    _save_series(y, None, output)
+    click.echo(f"{'Auto' if input_file_2 is None else 'Cross-'}correlation saved to '{Path(output).name}'.")
+
+
+@dsp_cmd.command("hilbert")
+@click.argument("input_file", type=click.Path(exists=True, dir_okay=False))
+@click.option("-o", "--output", required=True, type=click.Path())
+def dsp_hilbert(input_file, output):
+    """Compute the Analytic Signal using the Hilbert Transform (output is complex)."""
+    from ..core.transforms import hilbert_transform
+    x, _ = _load_signal(input_file, None)
+    try:
+        a = hilbert_transform(x)
+    except ValueError as e:
+        raise click.UsageError(str(e))
+    if Path(output).suffix.lower() == ".npz":
+        sio.save_data({"analytic_signal": a, "envelope": np.abs(a)}, output)
+    else:
+        sio.save_data(pd.DataFrame({"Real": a.real, "Imag": a.imag, "Envelope": np.abs(a)}), output)
+    click.echo(f"Analytic signal saved to '{Path(output).name}'.")
 
 
 @dsp_cmd.command("stft")

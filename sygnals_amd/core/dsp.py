@@ -1,8 +1,9 @@
 """Device-backed mirror of sygnals/core/dsp.py (FFT/IFFT, STFT, Welch, windowing).
 
 Same signatures, dtypes (float64 / complex128 out) and error behaviour as the reference:
-compute_fft :40-112, compute_ifft :114-162, compute_stft :167-229, compute_psd_welch :495-560,
-apply_window :641-691.  Arithmetic runs in fp32 on the device (parity gate 1e-5, peak-relative).
+compute_fft :40-112, compute_ifft :114-162, compute_stft :167-229, apply_convolution :294-337,
+compute_correlation :342-394, compute_autocorrelation :396-433, compute_psd_periodogram :438-498,
+compute_psd_welch :495-560, amplitude_envelope :565-636, apply_window :641-691.  Arithmetic runs in fp32 on the device (parity gate 1e-5, peak-relative).
 """
 from __future__ import annotations
 
@@ -166,3 +167,129 @@ def welch_batch(x, fs=1.0, window="hann", nperseg=None, noverlap=None, nfft=None
     scale = 1.0 / (fs * (w * w).sum()) if scaling == "density" else 1.0 / w.sum() ** 2
     p = ops.welch(x, nperseg, int(noverlap), int(nfft), w, detrend == "constant", scale)
     return np.fft.rfftfreq(int(nfft), 1 / fs).astype(np.float64), p
+
+
+# ------------------------------------------------------------------ convolution / correlation (dsp.py:294-433)
+_MODES = ("full", "valid", "same")
+
+
+def _conv_slice(n: int, m: int, mode: str) -> Tuple[int, int]:
+    """(start, count) of scipy's 'full' / 'same' (centred on the first input) / 'valid' result inside the full
+    linear convolution of n and m samples."""
+    if mode == "full":
+        return 0, n + m - 1
+    if mode == "same":
+        return (m - 1) // 2, n
+    return min(n, m) - 1, max(n, m) - min(n, m) + 1
+
+
+def convolve_batch(x, kernel, mode: str = "same", correlate: bool = False):
+    """Rows of the device tensor x [B, n] convolved (correlate=True: cross-correlated) with kernel [m] or [B, m]
+    -> device tensor [B, count]; the batched form of apply_convolution / compute_correlation."""
+    if mode not in _MODES:
+        raise ValueError("acceptable mode flags are 'valid', 'same', or 'full'")
+    k = kernel if kernel.dim() == 2 else kernel[None, :]
+    n, m = x.shape[1], k.shape[1]
+    if n == 0 or m == 0:
+        raise ValueError("convolve_batch: empty input")
+    start, count = _conv_slice(n, m, mode)
+    return ops.rfft_conv(x, k, reverse_k=correlate)[:, start:start + count]
+
+
+def apply_convolution(data, kernel, mode: str = "same") -> np.ndarray:
+    data, kernel = np.asarray(data), np.asarray(kernel)
+    if data.ndim != 1 or kernel.ndim != 1:
+        raise ValueError("Input data and kernel must be 1D arrays.")
+    if data.size == 0 or kernel.size == 0:
+        if mode not in _MODES:
+            raise ValueError("acceptable mode flags are 'valid', 'same', or 'full'")
+        return np.array([], dtype=np.float64)                  # scipy.signal.fftconvolve's empty-input rule
+    out = convolve_batch(ops.to_device_f32(data[None, :]), ops.to_device_f32(kernel[None, :]), mode)
+    return out[0].cpu().numpy().astype(np.float64)
+
+
+def compute_correlation(x, y, mode: str = "full", method: str = "auto") -> np.ndarray:
+    """scipy.signal.correlate(x, y): every `method` gives the same numbers up to rounding; the device always
+    uses the FFT form (x convolved with the reversed y)."""
+    x, y = np.asarray(x), np.asarray(y)
+    if x.ndim != 1 or y.ndim != 1:
+        raise ValueError("Input sequences for correlation must be 1D arrays.")
+    if method not in ("auto", "direct", "fft"):
+        raise ValueError("Acceptable method flags are 'auto', 'direct', or 'fft'.")
+    if mode not in _MODES:
+        raise ValueError("Acceptable mode flags are 'valid', 'same', or 'full'.")
+    if x.size == 0 or y.size == 0:
+        return np.array([], dtype=np.float64)
+    out = convolve_batch(ops.to_device_f32(x[None, :]), ops.to_device_f32(y[None, :]), mode, correlate=True)
+    return out[0].cpu().numpy().astype(np.float64)
+
+
+def compute_autocorrelation(x, mode: str = "full", method: str = "auto") -> np.ndarray:
+    return compute_correlation(x, x, mode=mode, method=method)
+
+
+# ------------------------------------------------------------------ periodogram (dsp.py:438-498)
+def periodogram_batch(x, fs=1.0, window="hann", nfft=None, detrend="constant", scaling="density"):
+    """[B, L] device tensor -> (freqs float64 [F], Pxx device tensor [B, F]); scipy.signal.periodogram rules."""
+    L = x.shape[1]
+    if L == 0:
+        raise ValueError("periodogram_batch: empty input")
+    if nfft is None:
+        nfft = L
+    nfft = int(nfft)
+    if nfft < 1:
+        raise ValueError("nfft must be a positive integer")
+    nperseg = min(L, nfft)                                    # nfft < L truncates x to nfft samples
+    if scaling not in ("density", "spectrum"):
+        raise ValueError(f"Unknown scaling: {scaling!r}")
+    if detrend not in ("constant", False, None, "none"):
+        raise SygnalsHipError("periodogram: only detrend='constant' or False run on the device")
+    if isinstance(window, (str, tuple)):
+        w = get_window(window, nperseg)
+    else:
+        w = np.asarray(window, dtype=np.float64)
+        if w.ndim != 1:
+            raise ValueError("window must be 1-D")
+        if w.shape[0] != nperseg:
+            raise ValueError("window must have length of nperseg")
+    scale = 1.0 / (fs * (w * w).sum()) if scaling == "density" else 1.0 / w.sum() ** 2
+    p = ops.periodogram(x, nfft, w, detrend == "constant", scale)
+    return np.fft.rfftfreq(nfft, 1 / fs).astype(np.float64), p
+
+
+def compute_psd_periodogram(x, fs: float = 1.0, window="hann", nfft: Optional[int] = None,
+                            detrend: Union[str, bool] = "constant", scaling: str = "density"
+                            ) -> Tuple[np.ndarray, np.ndarray]:
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    if x.size == 0:
+        return np.empty(0, dtype=np.float64), np.empty(0, dtype=np.float64)
+    f, p = periodogram_batch(ops.to_device_f32(x[None, :]), fs, window, nfft, detrend, scaling)
+    return f, p[0].cpu().numpy().astype(np.float64)
+
+
+# ------------------------------------------------------------------ envelope (dsp.py:565-636)
+def analytic_batch(x):
+    """Rows of the device tensor x [B, n] -> analytic signal, complex [B, n, 2] (scipy.signal.hilbert)."""
+    if x.shape[1] == 0:
+        raise ValueError("analytic_batch: empty input")
+    return ops.analytic_signal(x)
+
+
+def amplitude_envelope(y, method: str = "hilbert", frame_length: Optional[int] = None,
+                       hop_length: Optional[int] = None) -> np.ndarray:
+    y = np.asarray(y)
+    if y.ndim != 1:
+        raise ValueError("Input data must be a 1D array.")
+    if method == "hilbert":
+        if y.size == 0:
+            raise ValueError("N must be positive.")
+        env = ops.cabs_pow(analytic_batch(ops.to_device_f32(y[None, :])), 1)
+        return env[0].cpu().numpy().astype(np.float64)
+    if method == "rms":
+        if frame_length is None or hop_length is None:
+            raise ValueError("frame_length and hop_length are required for 'rms' envelope method.")
+        from .audio.features import rms_energy
+        return rms_energy(y, frame_length=frame_length, hop_length=hop_length, center=True)
+    raise ValueError(f"Unsupported envelope method: {method}. Choose 'hilbert' or 'rms'.")

@@ -600,6 +600,72 @@ def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     return cmul(c[:, :n].contiguous(), w_out)
 
 
+# ------------------------------------------------------------------ FFT-backed 1-D operations
+def pack_rows(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None, detrend: bool = False,
+              reverse: bool = False, cplx: bool = False) -> torch.Tensor:
+    """Rows of x [rows, len] -> [rows, n] real (or [rows, n, 2] complex) rows: mean removed (detrend), windowed,
+    optionally time-reversed, zero-padded / truncated to n."""
+    require_gpu()
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError("x must be a float32 [rows, len] device tensor")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, ln = x.shape
+    out = torch.empty((rows, n, 2) if cplx else (rows, n), dtype=torch.float32, device=x.device)
+    work = None
+    if detrend:
+        work = torch.empty(lib().syg_pack_rows_work_bytes(rows) // 8, dtype=torch.float64, device=x.device)
+    rc = lib().syg_pack_rows_f32(_ptr(x), rows, ln, _ld(x), _ptr(window), int(bool(detrend)), int(bool(reverse)),
+                                 int(bool(cplx)), _ptr(out), n, _ptr(work), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_pack_rows_f32")
+    return out
+
+
+def conv_fft_len(n_out: int) -> int:
+    """Power-of-two transform length (in real samples) for a linear convolution with n_out output samples."""
+    m = 16
+    while m < n_out:
+        m <<= 1
+    return m
+
+
+def rfft_conv(x: torch.Tensor, k: torch.Tensor, reverse_k: bool = False) -> torch.Tensor:
+    """Full linear convolution of the rows of x [B, n] with k [1 or B, m] -> [B, n + m - 1] (a view of the
+    transform buffer).  reverse_k convolves with the time-reversed k, i.e. cross-correlates."""
+    B, n = x.shape
+    Bk, m = k.shape
+    if Bk not in (1, B):
+        raise ValueError("k must have one row or one row per row of x")
+    M = conv_fft_len(n + m - 1)
+    H = M // 2
+    za = fft_pow2_any(pack_rows(x, M).view(B, H, 2))
+    zb = fft_pow2_any(pack_rows(k, M, reverse=reverse_k).view(Bk, H, 2))
+    rc = lib().syg_rconv_spectrum_c64(_ptr(za), _ptr(zb), B, Bk, H, _ptr(za), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_rconv_spectrum_c64")
+    return fft_pow2_any(za, True).view(B, M)[:, : n + m - 1]
+
+
+def analytic_signal(x: torch.Tensor) -> torch.Tensor:
+    """scipy.signal.hilbert of the rows of x [B, n] -> complex [B, n, 2] (exact length-n transforms)."""
+    B, n = x.shape
+    X = fft_any(pack_rows(x, n, cplx=True))
+    rc = lib().syg_analytic_mask_c64(_ptr(X), B, n, C.c_void_p(_stream_ptr()))
+    check(rc, "syg_analytic_mask_c64")
+    return fft_any(X, True)
+
+
+def periodogram(x: torch.Tensor, nfft: int, window_host: Optional[np.ndarray], detrend: bool, scale: float
+                ) -> torch.Tensor:
+    """One-sided periodogram [B, nfft//2 + 1] of the first min(len, nfft) samples of the rows of x."""
+    B = x.shape[0]
+    win = None if window_host is None else _dev(np.asarray(window_host, dtype=np.float32))
+    X = fft_any(pack_rows(x, nfft, window=win, detrend=detrend, cplx=True))
+    out = torch.empty((B, nfft // 2 + 1), dtype=torch.float32, device=x.device)
+    rc = lib().syg_psd_onesided_f32(_ptr(X), B, nfft, float(scale), _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_psd_onesided_f32")
+    return out
+
+
 # ------------------------------------------------------------------ constant-Q transform
 def decimate2(x: torch.Tensor, taps: torch.Tensor, scale: float) -> torch.Tensor:
     """FIR decimation by two of x [B, L] -> [B, ceil(L/2)] (zero padded ends)."""

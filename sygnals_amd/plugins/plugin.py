@@ -79,7 +79,10 @@ class SygnalsAmdPlugin(_Base):
 
     def register_transforms(self, registry):
         from ..core import dsp as D
-        for fn in (D.compute_fft, D.compute_ifft, D.compute_stft, D.compute_cqt, D.compute_psd_welch, D.apply_window):
+        from ..core import transforms as TR
+        for fn in (D.compute_fft, D.compute_ifft, D.compute_stft, D.compute_cqt, D.compute_psd_welch, D.apply_window,
+                   D.apply_convolution, D.compute_correlation, D.compute_autocorrelation, D.compute_psd_periodogram,
+                   D.amplitude_envelope, TR.hilbert_transform):
             registry.add_transform(fn.__name__, fn)
 
     def register_feature_extractors(self, registry):

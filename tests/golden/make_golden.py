@@ -6,7 +6,13 @@ box):   python tests/golden/make_golden.py
 
 What is executed: the SciPy/NumPy-backed functions of
   sygnals/core/filters.py                      (loads as-is)
-  sygnals/core/dsp.py                          (compute_fft/ifft, apply_window, compute_psd_welch)
+  sygnals/core/dsp.py                          (compute_fft/ifft, apply_window, compute_psd_welch; for
+                                               ref_dsp2.npz: apply_convolution, compute_correlation,
+                                               compute_autocorrelation, compute_psd_periodogram,
+                                               amplitude_envelope(method='hilbert'))
+  sygnals/core/transforms.py                   (hilbert_transform; its top-level ``import pywt`` gets the same
+                                               empty placeholder as librosa -- PyWavelets is not installed and no
+                                               wavelet function is called)
   sygnals/core/features/frequency_domain.py    (the five per-frame functions)
   sygnals/core/features/time_domain.py         (the seven per-frame functions; loads as-is)
 loaded BY FILE PATH (``sygnals/core/__init__.py`` pulls pandasql/soundfile,
@@ -164,6 +170,42 @@ def main():
         g[f"short{i}"] = f
         g[f"short{i}_out"] = np.array([td.TIME_DOMAIN_FEATURES[nm](f) for nm in names])
     np.savez_compressed(os.path.join(OUT, "ref_time.npz"), **g)
+
+    # ---- dsp.py / transforms.py: FFT-backed 1-D operations (own generator: earlier files stay bit-identical) ----
+    if "pywt" not in sys.modules:
+        sys.modules["pywt"] = types.ModuleType("pywt")        # empty placeholder, see docstring
+    tr = load("ref_transforms", "transforms.py")
+    rng2 = np.random.default_rng(20250524)
+    g = {}
+    sig = {"a1000": test_signal(rng2, 1000, 1000.0), "b50": rng2.normal(0, 1, 50), "c4096": test_signal(rng2, 4096, 48000.0),
+           "d999": test_signal(rng2, 999, 1000.0) + 0.2, "k31": np.hanning(31) / np.hanning(31).sum(),
+           "k200": rng2.normal(0, 0.1, 200), "k512": rng2.normal(0, 0.05, 512) * np.exp(-np.arange(512) / 90.0),
+           "e7": np.array([0, 0, 1, 1, 1, 0, 0], dtype=float), "k2": np.array([1, -1], dtype=float),
+           "one": np.array([0.75])}
+    for k, v in sig.items():
+        g["sig_" + k] = v
+    for a, b in (("a1000", "k31"), ("b50", "k200"), ("c4096", "k512"), ("e7", "k2"), ("a1000", "one"), ("one", "k2")):
+        for mode in ("full", "same", "valid"):
+            g[f"conv_{a}_{b}_{mode}"] = dsp.apply_convolution(sig[a], sig[b], mode=mode)
+    for a, b in (("a1000", "d999"), ("b50", "k200"), ("k200", "b50"), ("e7", "k2"), ("c4096", "k512")):
+        for mode in ("full", "same", "valid"):
+            g[f"corr_{a}_{b}_{mode}"] = dsp.compute_correlation(sig[a], sig[b], mode=mode)
+    g["corr_a1000_d999_full_fft"] = dsp.compute_correlation(sig["a1000"], sig["d999"], method="fft")
+    g["corr_a1000_d999_full_direct"] = dsp.compute_correlation(sig["a1000"], sig["d999"], method="direct")
+    for a in ("a1000", "b50"):
+        for mode in ("full", "same", "valid"):
+            g[f"acorr_{a}_{mode}"] = dsp.compute_autocorrelation(sig[a], mode=mode)
+    pcases = {"default": {}, "nfft1024": dict(nfft=1024), "nfft2048": dict(nfft=2048), "nfft512": dict(nfft=512),
+              "nfft777": dict(nfft=777), "spectrum": dict(scaling="spectrum"), "nodetrend": dict(detrend=False),
+              "boxcar": dict(window="boxcar"), "hamming": dict(window="hamming")}
+    for a in ("a1000", "d999", "c4096"):
+        for tag, kw in pcases.items():
+            f, p = dsp.compute_psd_periodogram(sig[a], fs=1000.0, **kw)
+            g[f"pgram_{a}_{tag}_f"], g[f"pgram_{a}_{tag}_p"] = f, p
+    for a in ("a1000", "d999", "c4096", "b50", "e7", "one"):
+        g[f"hilbert_{a}"] = tr.hilbert_transform(sig[a])
+        g[f"envelope_{a}"] = dsp.amplitude_envelope(sig[a], method="hilbert")
+    np.savez_compressed(os.path.join(OUT, "ref_dsp2.npz"), **g)
     print("golden vectors written to", OUT)
 
 

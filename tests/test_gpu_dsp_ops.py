@@ -1,0 +1,271 @@
+"""GPU parity of the FFT-backed 1-D operations: convolution, cross/auto-correlation, periodogram,
+analytic signal and Hilbert envelope -- sygnals_amd.core.dsp / core.transforms -> ops -> libsygnals_hip.so
+(syg_pack_rows_f32, syg_rconv_spectrum_c64, syg_analytic_mask_c64, syg_psd_onesided_f32 + the FFT kernels).
+
+Pinned on tests/golden/ref_dsp2.npz (outputs of the reference's own functions), then against the float64 oracle on
+larger and batched inputs, then through size-independent properties at sizes the direct-sum oracle cannot reach.
+Tolerance: 1e-5 of the output's peak (fp32 arithmetic on the device, float64 in the reference)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import cpu_ref as O
+from tests.gpu_util import assert_parity, peak_rel
+from tests.test_oracle_golden import CONV_PAIRS, CORR_PAIRS, PGRAM_CASES
+
+TOL = 1e-5
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return np.load(os.path.join(G, "ref_dsp2.npz"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from sygnals_amd import ops
+    ops.require_gpu()
+
+
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_convolution_vs_reference_golden(g2, mode):
+    from sygnals_amd.core.dsp import apply_convolution
+    for a, b in CONV_PAIRS:
+        got = apply_convolution(g2["sig_" + a], g2["sig_" + b], mode=mode)
+        assert got.dtype == np.float64
+        assert_parity(got, g2[f"conv_{a}_{b}_{mode}"], TOL, f"conv {a}*{b} {mode}")
+
+
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_correlation_vs_reference_golden(g2, mode):
+    from sygnals_amd.core.dsp import compute_autocorrelation, compute_correlation
+    for a, b in CORR_PAIRS:
+        got = compute_correlation(g2["sig_" + a], g2["sig_" + b], mode=mode)
+        assert_parity(got, g2[f"corr_{a}_{b}_{mode}"], TOL, f"corr {a},{b} {mode}")
+    for a in ("a1000", "b50"):
+        assert_parity(compute_autocorrelation(g2["sig_" + a], mode=mode), g2[f"acorr_{a}_{mode}"], TOL, "acorr")
+    for method in ("fft", "direct"):
+        got = compute_correlation(g2["sig_a1000"], g2["sig_d999"], method=method)
+        assert_parity(got, g2[f"corr_a1000_d999_full_{method}"], TOL, method)
+
+
+def test_autocorrelation_docstring_properties():
+    # dsp.py:414-427: peak at zero lag, secondary peak one period (10 samples) later
+    from sygnals_amd.core.dsp import compute_autocorrelation
+    fs = 100
+    x = np.sin(2 * np.pi * 10 * np.arange(fs * 2) / fs)
+    ac = compute_autocorrelation(x, mode="full")
+    zero = len(x) - 1
+    assert np.argmax(ac) == zero
+    assert ac[zero + 10] > 0.8 * ac[zero]
+    # dsp.py:378-383: y is x delayed by one sample -> peak at lag +1
+    from sygnals_amd.core.dsp import compute_correlation
+    a = np.array([0, 1, 2, 1, 0], dtype=float)
+    b = np.array([0, 0, 1, 2, 1], dtype=float)
+    c = compute_correlation(a, b, mode="full")
+    assert_parity(c, O.compute_correlation(a, b), TOL, "corr small")
+
+
+@pytest.mark.parametrize("tag", sorted(PGRAM_CASES))
+def test_periodogram_vs_reference_golden(g2, tag):
+    from sygnals_amd.core.dsp import compute_psd_periodogram
+    for a in ("a1000", "d999", "c4096"):
+        f, p = compute_psd_periodogram(g2["sig_" + a], fs=1000.0, **PGRAM_CASES[tag])
+        assert f.dtype == np.float64 and p.dtype == np.float64
+        np.testing.assert_allclose(f, g2[f"pgram_{a}_{tag}_f"], rtol=0, atol=1e-9)
+        assert_parity(p, g2[f"pgram_{a}_{tag}_p"], TOL, f"periodogram {a} {tag}")
+
+
+def test_periodogram_peak_and_window_array(g2):
+    # dsp.py:470-476: 100 Hz sine at fs = 1000 peaks at 100 Hz
+    from sygnals_amd.core.dsp import compute_psd_periodogram
+    fs = 1000
+    x = np.sin(2 * np.pi * 100 * np.arange(fs) / fs)
+    f, p = compute_psd_periodogram(x, fs=fs)
+    assert abs(f[np.argmax(p)] - 100.0) < 1e-9
+    w = np.kaiser(1000, 5.0)
+    f, p = compute_psd_periodogram(g2["sig_a1000"], fs=1000.0, window=w)
+    assert_parity(p, O.compute_psd_periodogram(g2["sig_a1000"], fs=1000.0, window=w)[1], TOL, "array window")
+    with pytest.raises(ValueError, match="length of nperseg"):
+        compute_psd_periodogram(g2["sig_a1000"], window=np.ones(10))
+
+
+def test_hilbert_and_envelope_vs_reference_golden(g2):
+    from sygnals_amd.core.dsp import amplitude_envelope
+    from sygnals_amd.core.transforms import hilbert_transform
+    for a in ("a1000", "d999", "c4096", "b50", "e7", "one"):
+        h = hilbert_transform(g2["sig_" + a])
+        assert h.dtype == np.complex128
+        assert peak_rel(h, g2[f"hilbert_{a}"]) <= TOL, a
+        assert_parity(amplitude_envelope(g2["sig_" + a]), g2[f"envelope_{a}"], TOL, f"envelope {a}")
+
+
+def test_envelope_rms_method_and_errors():
+    from sygnals_amd.core.dsp import amplitude_envelope
+    rng = np.random.default_rng(3)
+    y = rng.normal(0, 0.3, 8000)
+    got = amplitude_envelope(y, method="rms", frame_length=128, hop_length=64)
+    assert_parity(got, O.amplitude_envelope(y, "rms", 128, 64), TOL, "rms envelope")
+    with pytest.raises(ValueError, match="required for 'rms'"):
+        amplitude_envelope(y, method="rms")
+    with pytest.raises(ValueError, match="Unsupported envelope method"):
+        amplitude_envelope(y, method="peak")
+    with pytest.raises(ValueError, match="must be a 1D"):
+        amplitude_envelope(np.zeros((2, 8)))
+
+
+def test_f3_argument_errors():
+    from sygnals_amd.core.dsp import apply_convolution, compute_correlation, compute_psd_periodogram
+    from sygnals_amd.core.transforms import hilbert_transform
+    with pytest.raises(ValueError, match="must be 1D"):
+        apply_convolution(np.zeros((2, 2)), np.zeros(2))
+    with pytest.raises(ValueError, match="must be 1D"):
+        compute_correlation(np.zeros((2, 2)), np.zeros(2))
+    with pytest.raises(ValueError, match="mode"):
+        apply_convolution(np.zeros(4), np.zeros(2), mode="circular")
+    with pytest.raises(ValueError, match="method"):
+        compute_correlation(np.zeros(4), np.zeros(2), method="magic")
+    with pytest.raises(ValueError, match="must be a 1D"):
+        compute_psd_periodogram(np.zeros((2, 2)))
+    with pytest.raises(ValueError, match="must be a 1D"):
+        hilbert_transform(np.zeros((2, 2)))
+    assert apply_convolution(np.zeros(0), np.zeros(3)).shape == (0,)
+
+
+# ---------------------------------------------------------------- batched forms against the oracle
+@pytest.mark.parametrize("n,m,shared", [(3000, 257, True), (3000, 257, False), (48000, 1023, True), (100, 4000, False),
+                                       (17, 1, True), (1, 1, True), (65536, 2, True)])
+def test_convolve_batch_vs_oracle(n, m, shared):
+    from sygnals_amd import ops
+    from sygnals_amd.core.dsp import convolve_batch
+    rng = np.random.default_rng(n * 7 + m)
+    B = 5
+    X = rng.normal(0, 0.4, (B, n)).astype(np.float32)
+    K = (rng.normal(0, 1.0, (1 if shared else B, m)) / np.sqrt(m)).astype(np.float32)
+    X[1] *= 1e-3                                             # rows of very different scale stay independent
+    xd, kd = ops.to_device_f32(X), ops.to_device_f32(K)
+    for mode in ("full", "same", "valid"):
+        for corr in (False, True):
+            got = convolve_batch(xd, kd[0] if shared else kd, mode, correlate=corr).cpu().numpy()
+            for b in range(B):
+                kb = K[0 if shared else b].astype(np.float64)
+                want = (O.compute_correlation if corr else O.apply_convolution)(X[b].astype(np.float64), kb, mode)
+                assert_parity(got[b], want, TOL, f"n={n} m={m} {mode} corr={corr} row {b}")
+
+
+def test_small_kernel_next_to_large_signal_keeps_its_precision():
+    """The kernel is 1e-4 of the signal's scale; the error stays relative to the product's peak (each sequence has
+    its own transform -- see dsp_extra.hip header)."""
+    from sygnals_amd.core.dsp import apply_convolution
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 50.0, 5000)
+    k = rng.normal(0, 1e-3, 301)
+    assert_parity(apply_convolution(x, k, "full"), O.apply_convolution(x, k, "full"), TOL, "scale split")
+
+
+def test_analytic_and_periodogram_batch_vs_oracle():
+    from sygnals_amd import ops
+    from sygnals_amd.core.dsp import analytic_batch, periodogram_batch
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 64, 777, 2048, 12000):
+        X = (rng.normal(0, 0.5, (4, n)) + 0.3).astype(np.float32)
+        a = analytic_batch(ops.to_device_f32(X)).cpu().numpy().astype(np.float64)
+        for b in range(4):
+            want = O.hilbert_transform(X[b].astype(np.float64))
+            assert peak_rel(a[b, :, 0] + 1j * a[b, :, 1], want) <= TOL, n
+        if n >= 2:
+            f, p = periodogram_batch(ops.to_device_f32(X), fs=8000.0)
+            for b in range(4):
+                wf, wp = O.compute_psd_periodogram(X[b].astype(np.float64), fs=8000.0)
+                assert_parity(p[b].cpu().numpy(), wp, TOL, f"periodogram n={n}")
+                np.testing.assert_allclose(f, wf, rtol=0, atol=1e-9)
+
+
+# ---------------------------------------------------------------- properties at sizes beyond the direct-sum oracle
+def test_long_convolution_properties():
+    """2^20-sample rows against a 4097-tap kernel (four-step FFT of 2^20 complex points):
+    delta kernel = delayed copy, linearity in the signal, and the sum rule sum(x * k) = sum(x) * sum(k)."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.dsp import convolve_batch
+    rng = np.random.default_rng(21)
+    n, m = 1 << 20, 4097
+    X = rng.normal(0, 0.3, (3, n)).astype(np.float32)
+    X[2] = X[0] + 2.0 * X[1]
+    xd = ops.to_device_f32(X)
+    delta = np.zeros(m, dtype=np.float32); delta[100] = 1.0
+    full = convolve_batch(xd, ops.to_device_f32(delta), "full").cpu().numpy()
+    assert full.shape == (3, n + m - 1)
+    assert np.max(np.abs(full[:, 100:100 + n] - X)) <= TOL * np.max(np.abs(X))
+    assert np.max(np.abs(full[:, :100])) <= TOL and np.max(np.abs(full[:, 100 + n:])) <= TOL
+    k = (rng.normal(0, 1.0, m) / np.sqrt(m)).astype(np.float32)
+    y = convolve_batch(xd, ops.to_device_f32(k), "full").cpu().numpy().astype(np.float64)
+    peak = np.max(np.abs(y))
+    assert np.max(np.abs(y[2] - (y[0] + 2.0 * y[1]))) <= 4 * TOL * peak
+    for b in range(3):
+        want = X[b].astype(np.float64).sum() * k.astype(np.float64).sum()
+        assert abs(y[b].sum() - want) <= 1e-3 * max(abs(want), np.abs(y[b]).sum() * 1e-3)
+    # a window of the long result against the direct sum
+    seg = slice(500000, 500512)
+    want = np.array([np.dot(X[0, i - m + 1:i + 1][::-1].astype(np.float64), k.astype(np.float64))
+                     for i in range(seg.start, seg.stop)])
+    assert np.max(np.abs(y[0, seg] - want)) <= TOL * peak
+
+
+def test_long_hilbert_and_periodogram_properties():
+    """n = 2^22 + 17 (Bluestein over the four-step FFT): Re(analytic) = x, a pure tone's envelope is its amplitude,
+    and Parseval: sum(Pxx) * df = mean(x^2) for the boxcar window without detrending."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.dsp import analytic_batch, periodogram_batch
+    n = (1 << 22) + 17
+    t = np.arange(n, dtype=np.float64)
+    tone = 0.7 * np.cos(2 * np.pi * (40000.0 / n) * t)         # integer number of cycles
+    rng = np.random.default_rng(8)
+    X = np.stack([tone, rng.normal(0, 0.3, n)]).astype(np.float32)
+    a = analytic_batch(ops.to_device_f32(X)).cpu().numpy()
+    assert np.max(np.abs(a[:, :, 0] - X)) <= 2 * TOL * np.max(np.abs(X))
+    env = np.hypot(a[0, :, 0], a[0, :, 1])
+    assert np.max(np.abs(env - 0.7)) <= 1e-4
+    f, p = periodogram_batch(ops.to_device_f32(X), fs=1.0, window="boxcar", detrend=False)
+    p = p.cpu().numpy().astype(np.float64)
+    for b in range(2):
+        power = np.mean(X[b].astype(np.float64) ** 2)
+        assert abs(p[b].sum() * (1.0 / n) - power) <= 1e-5 * power
+
+
+def test_cli_dsp_commands(tmp_path):
+    """`sygnals dsp convolution / correlation / psd-periodogram / hilbert` (README.md:748-815, 884-899) end to end."""
+    import pandas as pd
+    from click.testing import CliRunner
+    from sygnals_amd.cli.main import cli
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 0.3, 3000); k = np.hanning(33) / np.hanning(33).sum()
+    pd.DataFrame({"value": x}).to_csv(tmp_path / "x.csv", index=False)
+    np.savez(tmp_path / "k.npz", data=k)
+    run = lambda *a: CliRunner().invoke(cli, ["dsp", *map(str, a)])
+    r = run("convolution", tmp_path / "x.csv", tmp_path / "k.npz", "-o", tmp_path / "c.npz", "--mode", "same")
+    assert r.exit_code == 0, r.output
+    assert_parity(np.load(tmp_path / "c.npz")["data"], O.apply_convolution(x, k, "same"), TOL, "cli conv")
+    r = run("correlation", tmp_path / "x.csv", "-o", tmp_path / "a.npz")
+    assert r.exit_code == 0, r.output
+    assert_parity(np.load(tmp_path / "a.npz")["data"], O.compute_autocorrelation(x), TOL, "cli acorr")
+    r = run("correlation", tmp_path / "x.csv", tmp_path / "k.npz", "-o", tmp_path / "cc.npz", "--mode", "valid")
+    assert r.exit_code == 0, r.output
+    assert_parity(np.load(tmp_path / "cc.npz")["data"], O.compute_correlation(x, k, "valid"), TOL, "cli corr")
+    r = run("psd-periodogram", tmp_path / "x.csv", "--fs", 1000, "-o", tmp_path / "p.csv", "--scaling", "spectrum")
+    assert r.exit_code == 0, r.output
+    df = pd.read_csv(tmp_path / "p.csv")
+    wf, wp = O.compute_psd_periodogram(x, fs=1000.0, scaling="spectrum")
+    assert_parity(df["PSD"].to_numpy(), wp, TOL, "cli periodogram")
+    np.testing.assert_allclose(df["Frequency"].to_numpy(), wf, atol=1e-9)
+    r = run("psd-periodogram", tmp_path / "x.csv", "--fs", 1000, "-o", tmp_path / "p2.csv", "--detrend", "linear")
+    assert r.exit_code != 0                                   # linear detrend is not offloaded: loud, no CPU fallback
+    r = run("hilbert", tmp_path / "x.csv", "-o", tmp_path / "h.npz")
+    assert r.exit_code == 0, r.output
+    z = np.load(tmp_path / "h.npz")
+    assert peak_rel(z["analytic_signal"], O.hilbert_transform(x)) <= TOL
+    assert_parity(z["envelope"], O.amplitude_envelope(x), TOL, "cli envelope")

@@ -183,3 +183,77 @@ def test_time_domain_restatement_agrees_with_scipy_stats():
         c, _ = np.histogram(f, bins=10)
         assert np.array_equal(O.histogram_counts(f, 10), c)
         assert abs(O.signal_entropy(f) - scipy.stats.entropy(c[c > 0] / n)) < 1e-13
+
+
+# ---------------------------------------------------------------- f-3: FFT-backed 1-D operations (ref_dsp2.npz)
+CONV_PAIRS = [("a1000", "k31"), ("b50", "k200"), ("c4096", "k512"), ("e7", "k2"), ("a1000", "one"), ("one", "k2")]
+CORR_PAIRS = [("a1000", "d999"), ("b50", "k200"), ("k200", "b50"), ("e7", "k2"), ("c4096", "k512")]
+PGRAM_CASES = {"default": {}, "nfft1024": dict(nfft=1024), "nfft2048": dict(nfft=2048), "nfft512": dict(nfft=512),
+               "nfft777": dict(nfft=777), "spectrum": dict(scaling="spectrum"), "nodetrend": dict(detrend=False),
+               "boxcar": dict(window="boxcar"), "hamming": dict(window="hamming")}
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return np.load(os.path.join(G, "ref_dsp2.npz"))
+
+
+def _close(got, want, rel=1e-10):
+    assert got.shape == want.shape
+    scale = max(float(np.max(np.abs(want))), 1e-300) if want.size else 1.0
+    assert float(np.max(np.abs(got - want))) <= rel * scale if want.size else True
+
+
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_convolution_matches_reference(g2, mode):
+    for a, b in CONV_PAIRS:
+        _close(O.apply_convolution(g2["sig_" + a], g2["sig_" + b], mode), g2[f"conv_{a}_{b}_{mode}"])
+
+
+def test_convolution_readme_example(g2):
+    # the inputs of the docstring example dsp.py:318-322; the values are what the reference RETURNS for them (the
+    # docstring prints the result shifted by one sample -- scipy centres 'same' at (m - 1) // 2 = 0 for m = 2)
+    np.testing.assert_allclose(g2["conv_e7_k2_same"], [0, 0, 1, 0, 0, -1, 0], atol=1e-12)
+    np.testing.assert_allclose(O.apply_convolution(g2["sig_e7"], g2["sig_k2"], "same"), [0, 0, 1, 0, 0, -1, 0],
+                               atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_correlation_matches_reference(g2, mode):
+    for a, b in CORR_PAIRS:
+        _close(O.compute_correlation(g2["sig_" + a], g2["sig_" + b], mode), g2[f"corr_{a}_{b}_{mode}"])
+    for a in ("a1000", "b50"):
+        _close(O.compute_autocorrelation(g2["sig_" + a], mode), g2[f"acorr_{a}_{mode}"])
+
+
+def test_correlation_methods_agree(g2):
+    want = O.compute_correlation(g2["sig_a1000"], g2["sig_d999"])
+    _close(want, g2["corr_a1000_d999_full_fft"])
+    _close(want, g2["corr_a1000_d999_full_direct"])
+
+
+@pytest.mark.parametrize("tag", sorted(PGRAM_CASES))
+def test_periodogram_matches_reference(g2, tag):
+    for a in ("a1000", "d999", "c4096"):
+        f, p = O.compute_psd_periodogram(g2["sig_" + a], fs=1000.0, **PGRAM_CASES[tag])
+        np.testing.assert_allclose(f, g2[f"pgram_{a}_{tag}_f"], rtol=0, atol=1e-9)
+        _close(p, g2[f"pgram_{a}_{tag}_p"])
+
+
+def test_hilbert_and_envelope_match_reference(g2):
+    for a in ("a1000", "d999", "c4096", "b50", "e7", "one"):
+        _close(O.hilbert_transform(g2["sig_" + a]), g2[f"hilbert_{a}"])
+        _close(O.amplitude_envelope(g2["sig_" + a]), g2[f"envelope_{a}"])
+
+
+def test_f3_error_strings():
+    with pytest.raises(ValueError, match="must be 1D"):
+        O.apply_convolution(np.zeros((2, 2)), np.zeros(2))
+    with pytest.raises(ValueError, match="must be 1D"):
+        O.compute_correlation(np.zeros((2, 2)), np.zeros(2))
+    with pytest.raises(ValueError, match="must be a 1D"):
+        O.compute_psd_periodogram(np.zeros((2, 2)))
+    with pytest.raises(ValueError, match="Unsupported envelope method"):
+        O.amplitude_envelope(np.zeros(8), method="peak")
+    with pytest.raises(ValueError, match="required for 'rms'"):
+        O.amplitude_envelope(np.zeros(8), method="rms")

@@ -30,7 +30,9 @@ def _run_hooks(plugin, reg):
 
 def _check_registered(filters, transforms, features, cli_names):
     assert {"apply_sos_filter", "low_pass_filter", "high_pass_filter", "band_pass_filter", "band_stop_filter"} <= set(filters)
-    assert {"compute_fft", "compute_ifft", "compute_stft", "compute_psd_welch", "apply_window"} <= set(transforms)
+    assert {"compute_fft", "compute_ifft", "compute_stft", "compute_psd_welch", "apply_window", "apply_convolution",
+            "compute_correlation", "compute_autocorrelation", "compute_psd_periodogram", "amplitude_envelope",
+            "hilbert_transform"} <= set(transforms)
     assert {"spectral_centroid", "spectral_bandwidth", "spectral_flatness", "spectral_rolloff", "dominant_frequency",
             "spectral_contrast", "mfcc", "extract_features"} <= set(features)
     assert {"features", "dsp", "filter"} <= set(cli_names)
@@ -84,8 +86,14 @@ def test_cli_surface():
     for opt in ("-o, --output", "-f, --feature", "--frame-length", "--hop-length", "2048", "512"):
         assert opt in out
     out = r.invoke(cli, ["dsp", "--help"]).output
-    for c in ("fft", "ifft", "psd-welch", "stft"):
+    for c in ("fft", "ifft", "psd-welch", "stft", "psd-periodogram", "convolution", "correlation", "hilbert"):
         assert c in out
+    out = r.invoke(cli, ["dsp", "correlation", "--help"]).output          # README.md:768-792
+    for opt in ("--mode", "--method", "[INPUT_FILE_2]", "-o, --output"):
+        assert opt in out
+    out = r.invoke(cli, ["dsp", "psd-periodogram", "--help"]).output      # README.md:795-815
+    for opt in ("--fs", "--window", "--nfft", "--detrend", "--scaling"):
+        assert opt in out
     out = r.invoke(cli, ["filter", "apply", "--help"]).output
     for opt in ("--type", "--cutoff", "--fs", "--order", "-o, --output"):
         assert opt in out

@@ -54,4 +54,12 @@ t = torch.arange(Ls, device=y.device, dtype=torch.float32) / SR
 stream = (0.3 * torch.sin(2 * np.pi * (30.0 + 10.0 * t) * t) + 0.05 * torch.randn(Ls, device=y.device)).reshape(1, Ls)
 report("a14 Welch nperseg 4096 / 50 %, 10 min stream", timeit(lambda: D.welch_batch(stream, fs=SR, nperseg=4096), 5, 2), Ls, 4 * Ls + 4 * 2049)
 report("a15 CQT 84 bins hop 512, 10 min stream", timeit(lambda: ops.cqt(stream, SR), 3, 1), Ls, 4 * Ls + 8 * 84 * (1 + Ls // 512))
+# f-3: FFT-backed 1-D operations on the 1024-clip batch
+kern = ops.to_device_f32((np.random.default_rng(0).normal(0, 1, 1023) / 32).astype(np.float32))
+report("f-3 convolution, 1023-tap shared kernel, mode=same, 1024 clips", timeit(lambda: D.convolve_batch(y, kern, "same")), B * L, B * 8 * L)
+report("f-3 autocorrelation (full), 1024 clips", timeit(lambda: D.convolve_batch(y, y, "full", correlate=True)), B * L, B * (4 * L + 4 * (2 * L - 1)))
+y65 = torch.randn((1024, 65536), dtype=torch.float32, device=y.device)
+report("f-3 Hilbert envelope, 1024 rows x 65536", timeit(lambda: ops.cabs_pow(D.analytic_batch(y65), 1)), 1024 * 65536, 1024 * 8 * 65536)
+report("f-3 Hilbert envelope, 1024 clips x 48000 (Bluestein)", timeit(lambda: ops.cabs_pow(D.analytic_batch(y), 1), 5, 2), B * L, B * 8 * L)
+report("f-3 periodogram, 1024 clips x 48000 (Bluestein)", timeit(lambda: D.periodogram_batch(y, fs=SR), 5, 2), B * L, B * (4 * L + 4 * (L // 2 + 1)))
 json.dump(rows, open("gpurun_out/rows_r01.json", "w"), indent=1)
