@@ -246,6 +246,66 @@ __global__ void fft_pow2_strided_kernel(const float2* __restrict__ in, float2* _
   }
 }
 
+// Column-tiled form of the strided transform for the two passes of a four-step FFT.  The transforms of one pass
+// are the columns of a matrix whose rows are contiguous (in_bs == 1): a workgroup takes CB adjacent columns, so
+// every global access is a run of CB complex values (128 bytes at CB = 16) instead of one 8-byte element per line,
+// transposes them into LDS (one column = one natural-order array, pitch n + COLS_PAD), runs the CB transforms side
+// by side (256 / CB threads each; the trip counts and barriers of block_fft depend on n only) and stores either
+// k-fast (out_es == 1: the transposed layout pass A leaves for pass B) or column-fast (out_bs == 1: final order).
+constexpr int COLS_NT = 256;
+constexpr int COLS_PAD = 2;
+constexpr int COLS_MAXN = 1024;
+
+__device__ __forceinline__ float2 four_step_twiddle(int64_t e, int64_t bign) {
+  if (bign <= (1 << 24)) {                       // e < bign: exact in float, and bign is a power of two
+    float sn, cs;
+    sincospif(-2.0f * ((float)e / (float)bign), &sn, &cs);
+    return make_float2(cs, sn);
+  }
+  double sn, cs;
+  sincospi(-2.0 * (double)e / (double)bign, &sn, &cs);
+  return make_float2((float)cs, (float)sn);
+}
+
+template <bool KFAST>
+__global__ __launch_bounds__(COLS_NT) void fft_cols_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                           int n, int cb_log, int inverse,
+                                                           const float2* __restrict__ tw, int64_t in_os, int64_t in_es,
+                                                           int64_t out_os, int64_t out_bs, int64_t out_es,
+                                                           int64_t bign, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int CB = 1 << cb_log, LP = n + COLS_PAD;
+  float2* x = reinterpret_cast<float2*>(lds);
+  float2* y = x + CB * LP;
+  const int tid = threadIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.x << cb_log, o = blockIdx.y;
+  const float2* ip = in + o * in_os + c0;
+  float2* op = out + o * out_os;
+  const int total = n << cb_log;
+  for (int idx = tid; idx < total; idx += COLS_NT) {
+    const int c = idx & (CB - 1), e = idx >> cb_log;
+    float2 v = ip[(int64_t)e * in_es + c];
+    if (inverse) v.y = -v.y;
+    x[c * LP + e] = v;
+  }
+  __syncthreads();
+  const int tpc_log = 8 - cb_log;                              // threads per column
+  const int g = tid >> tpc_log, lt = tid & ((1 << tpc_log) - 1);
+  const float2* r = block_fft(x + g * LP, y + g * LP, n, tw, lt, 1 << tpc_log) - g * LP;
+  int ln = 0;
+  while ((1 << ln) < n) ++ln;
+  for (int idx = tid; idx < total; idx += COLS_NT) {
+    int c, k;
+    if (KFAST) { k = idx & (n - 1); c = idx >> ln; }
+    else { c = idx & (CB - 1); k = idx >> cb_log; }
+    float2 v = r[c * LP + k];
+    if (bign > 0) v = cmul(v, four_step_twiddle(((c0 + c) * (int64_t)k) % bign, bign));
+    v.x *= scale; v.y *= scale;
+    if (inverse) v.y = -v.y;
+    op[(c0 + c) * out_bs + (int64_t)k * out_es] = v;
+  }
+}
+
 // out[i] = a[i] * b[i mod nb]   (conj_b: multiply by conj(b))
 __global__ void cmul_kernel(const float2* __restrict__ a, const float2* __restrict__ b, float2* __restrict__ out,
                             int64_t na, int64_t nb, int conj_b) {
@@ -396,6 +456,28 @@ extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t
   SYG_REQUIRE(batch >= 1 && batch < (int64_t)0x7fffffff && outer >= 1 && outer <= 65535,
               "fft_pow2_strided: bad batch/outer");
   SYG_REQUIRE(in != out, "fft_pow2_strided: in-place operation is not supported");
+  if (in_bs == 1 && (out_es == 1 || out_bs == 1) && n <= COLS_MAXN && n >= 8) {
+    int cb_log = 4;                                            // 16 columns = 128-byte runs
+    while (cb_log > 2 && ((int64_t)n << cb_log) > 4096) --cb_log;
+    if (batch % (1 << cb_log) == 0) {
+      const bool kfast = out_es == 1;
+      const void* fn = kfast ? (const void*)fft_cols_kernel<true> : (const void*)fft_cols_kernel<false>;
+      const size_t lds = (size_t)2 * ((size_t)(n + COLS_PAD) << cb_log) * sizeof(float2);
+      int rc = set_lds(fn, lds, "fft_pow2_strided(cols)");
+      if (rc) return rc;
+      const dim3 grid((unsigned)(batch >> cb_log), (unsigned)outer);
+      if (kfast)
+        hipLaunchKernelGGL(fft_cols_kernel<true>, grid, dim3(COLS_NT), lds, (hipStream_t)stream, (const float2*)in,
+                           (float2*)out, n, cb_log, inverse, (const float2*)twiddle, in_os, in_es, out_os, out_bs,
+                           out_es, bign, scale);
+      else
+        hipLaunchKernelGGL(fft_cols_kernel<false>, grid, dim3(COLS_NT), lds, (hipStream_t)stream, (const float2*)in,
+                           (float2*)out, n, cb_log, inverse, (const float2*)twiddle, in_os, in_es, out_os, out_bs,
+                           out_es, bign, scale);
+      SYG_CHECK_LAUNCH("fft_pow2_strided(cols)");
+      return SYG_OK;
+    }
+  }
   const size_t lds = (size_t)n * 2 * sizeof(float2);
   int rc = set_lds((const void*)fft_pow2_strided_kernel, lds, "fft_pow2_strided");
   if (rc) return rc;
