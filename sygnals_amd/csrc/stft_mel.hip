@@ -467,35 +467,64 @@ __device__ __noinline__ uint32_t row_kth(lds_row prow, int lane, int lo, int n, 
   return prefix;
 }
 
-// The band sits in R registers per lane (bin lo + 64 r + lane in register r); the k largest and k smallest are
-// extracted one by one, both tails interleaved: wave max / min, the first owning lane retires its element.
+// Data-oblivious sorting networks for the R values a lane holds (Batcher's odd-even merge sort pruned to R wires;
+// checked with the 0-1 principle, tools/sortnet.py).
+template <int R> struct SortNet;
+template <> struct SortNet<1> { static constexpr int N = 0; static constexpr int P[1][2] = {{0, 0}}; };
+template <> struct SortNet<2> { static constexpr int N = 1; static constexpr int P[1][2] = {{0, 1}}; };
+template <> struct SortNet<4> {
+  static constexpr int N = 5;
+  static constexpr int P[5][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}};
+};
+template <> struct SortNet<7> {
+  static constexpr int N = 16;
+  static constexpr int P[16][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {4, 6}, {5, 6},
+                                   {0, 4}, {2, 6}, {2, 4}, {1, 5}, {3, 5}, {1, 2}, {3, 4}, {5, 6}};
+};
+template <> struct SortNet<12> {
+  static constexpr int N = 41;
+  static constexpr int P[41][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4},
+                                   {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11},
+                                   {8, 10}, {9, 11}, {9, 10}, {0, 8}, {4, 8}, {2, 10}, {6, 10}, {2, 4}, {6, 8}, {1, 9},
+                                   {5, 9}, {3, 11}, {7, 11}, {3, 5}, {7, 9}, {1, 2}, {3, 4}, {5, 6}, {7, 8}, {9, 10}};
+};
+
+// The band sits in R registers per lane (bin lo + 64 r + lane in register r).  Each lane first sorts its own R
+// values (two copies: `up` ascending with -1 in the unused slots, `dn` descending with +huge), so that a lane's
+// candidate for the next largest / smallest is always in its last register.  One extraction is then a wave max / min
+// over those heads, and the first owning lane shifts its list by one: 2 R selects per step instead of the
+// 8 R compare / select operations of a search through unsorted registers.
 template <int R>
 __device__ __forceinline__ void contrast_extract(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
-  float hi[R], lw[R];
+  float up[R], dn[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = r * 64 + lane;
     const float p = prow[ppos(lo + (i < n ? i : 0))];
-    hi[r] = (i < n) ? p : -1.f;
-    lw[r] = (i < n) ? p : 3.4e38f;
+    up[r] = (i < n) ? p : -1.f;
+    dn[r] = (i < n) ? p : 3.4e38f;
+  }
+#pragma unroll
+  for (int c = 0; c < SortNet<R>::N; ++c) {
+    constexpr auto& P = SortNet<R>::P;
+    const int i = P[c][0], j = P[c][1];
+    const float ua = up[i], ub = up[j], da = dn[i], db = dn[j];
+    up[i] = fminf(ua, ub); up[j] = fmaxf(ua, ub);
+    dn[i] = fmaxf(da, db); dn[j] = fminf(da, db);
   }
   spk = 0.f; svl = 0.f;
   for (int it = 0; it < k; ++it) {
-    float mh = hi[0], ml = lw[0];
+    const float MH = wave_max(up[R - 1]), ML = wave_min(dn[R - 1]);
+    const int fh = __ffsll((long long)__ballot(up[R - 1] == MH)) - 1;
+    const int fl = __ffsll((long long)__ballot(dn[R - 1] == ML)) - 1;
+    const bool mh = lane == fh, ml = lane == fl;
 #pragma unroll
-    for (int r = 1; r < R; ++r) { mh = fmaxf(mh, hi[r]); ml = fminf(ml, lw[r]); }
-    const float MH = wave_max(mh), ML = wave_min(ml);
-    const int fh = __ffsll((long long)__ballot(mh == MH)) - 1, fl = __ffsll((long long)__ballot(ml == ML)) - 1;
-    bool doneh = lane != fh, donel = lane != fl;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const bool hh = !doneh && hi[r] == MH;
-      hi[r] = hh ? -1.f : hi[r];
-      doneh = doneh || hh;
-      const bool hl = !donel && lw[r] == ML;
-      lw[r] = hl ? 3.4e38f : lw[r];
-      donel = donel || hl;
+    for (int r = R - 1; r > 0; --r) {
+      up[r] = mh ? up[r - 1] : up[r];
+      dn[r] = ml ? dn[r - 1] : dn[r];
     }
+    up[0] = mh ? -1.f : up[0];
+    dn[0] = ml ? 3.4e38f : dn[0];
     spk += fsqrt(MH);
     svl += fsqrt(ML);
   }
