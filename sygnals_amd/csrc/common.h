@@ -220,6 +220,34 @@ __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, dpp_rows_f<DPP_ROW_BCAST31, 0xC>(v));
   return rl_f(v, 63);
 }
+// max of `a` and min of `b` over the wave in one interleaved chain of fused DPP operations (v_max_f32_dpp reads its
+// first source through the DPP network, so a step is ONE instruction; the compiler's own lowering of the builtins is a
+// v_mov_dpp plus a canonicalising v_max plus the v_max itself).  A DPP operand written by the previous VALU
+// instruction needs two wait states: the other chain's step fills one, s_nop 0 the second.
+__device__ __forceinline__ void wave_maxmin(float& a, float& b) {
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_min_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(a), "+v"(b));
+  a = rl_f(a, 63);
+  b = rl_f(b, 63);
+}
 __device__ __forceinline__ int wave_min_i(int v) {
   v = min(v, dpp_i<DPP_QP_1032>(v));
   v = min(v, dpp_i<DPP_QP_2301>(v));

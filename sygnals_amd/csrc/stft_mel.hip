@@ -514,7 +514,8 @@ __device__ __forceinline__ void contrast_extract(lds_row prow, int lane, int lo,
   }
   spk = 0.f; svl = 0.f;
   for (int it = 0; it < k; ++it) {
-    const float MH = wave_max(up[R - 1]), ML = wave_min(dn[R - 1]);
+    float MH = up[R - 1], ML = dn[R - 1];
+    wave_maxmin(MH, ML);
     const int fh = __ffsll((long long)__ballot(up[R - 1] == MH)) - 1;
     const int fl = __ffsll((long long)__ballot(dn[R - 1] == ML)) - 1;
     const bool mh = lane == fh, ml = lane == fl;
