@@ -13,6 +13,7 @@
 // final float32 rounding.  Two passes over the frame (mean first, then central moments + histogram): a frame is
 // at most a few KiB and stays in L1/L2.
 #include "common.h"
+#include <type_traits>
 
 namespace syg {
 namespace {
@@ -20,20 +21,22 @@ namespace {
 constexpr int FS_WAVES = 4;       // frames per workgroup
 constexpr int FS_MAXBINS = 256;
 
+// float64 wave sums on the DPP path (two 32-bit DPP moves per hop; __shfl_xor would be two ds_bpermute_b32 round
+// trips through the LDS crossbar per hop).  Fixed order: butterfly inside each row of 16 lanes, then the four rows.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rl_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ double wmin(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
+  v += dpp_d<DPP_QP_1032>(v);
+  v += dpp_d<DPP_QP_2301>(v);
+  v += dpp_d<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_d<DPP_ROW_MIRROR>(v);
+  return (rl_d(v, 0) + rl_d(v, 16)) + (rl_d(v, 32) + rl_d(v, 48));
 }
 
 // np.linspace(first, last, nb + 1)[j]: arange(j) * step + start with the end point set exactly; mul and add are
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int flen, int hop, int pad, int64_t T, int num_bins,
     int mask, float* __restrict__ out) {
   __shared__ unsigned hist[FS_WAVES][FS_MAXBINS];
+  __shared__ float eu[FS_WAVES][FS_MAXBINS + 1];
   extern __shared__ __attribute__((aligned(16))) float stage[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t t = (int64_t)blockIdx.x * FS_WAVES + w;
@@ -62,7 +66,6 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
   const float* yb = y + b * ldy;
   const int64_t s0 = live ? t * (int64_t)hop - pad : 0;
   const double n = (double)flen;
-  const double THR = 1e-10;
   const int64_t sbase = (int64_t)blockIdx.x * FS_WAVES * hop - pad;      // first staged sample
   const int span = (FS_WAVES - 1) * hop + flen;
   if (STAGED) {
@@ -73,8 +76,10 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
     __syncthreads();
   }
   // sample s of the clip, zero padded / edge padded
-  auto at0 = [&](int64_t s) -> float {
-    if (STAGED) return stage[s - sbase];
+  const float* fr = stage + (int)(s0 - sbase);              // STAGED: sample i of this wave's frame (zero padded)
+  auto at0 = [&](int i) -> float {
+    if (STAGED) return fr[i];
+    const int64_t s = s0 + i;
     return (s >= 0 && s < L) ? yb[s] : 0.f;
   };
   auto ate = [&](int64_t s) -> float {
@@ -84,60 +89,128 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
   };
 
   // ---- pass 1: raw sums, extrema, zero crossings
-  double sx = 0.0, sa = 0.0, sq = 0.0, mx = -1.79e308, mn = 1.79e308, pk = 0.0;
-  double zc = 0.0;
-  if (live) {
+  double sx = 0.0, sa = 0.0, sq = 0.0;
+  float mxf = -3.4e38f, mnf = 3.4e38f;                                    // extrema of float samples are exact in float
+  // |x| <= 1e-10 for a float x  <=>  |x| <= the largest float below 1e-10 (float(1e-10) itself is above it)
+  constexpr float ZTHR = 0x1.b7cdfcp-34f;
+  const bool edge_frame = s0 < 1 || s0 + flen > L;
+  int zci = 0, carry = 0;
+  // the wave-uniform choices (zero crossings wanted? frame touching a clip end?) are made outside the loop: three
+  // straight-line loop bodies instead of per-sample branches
+  auto pass1 = [&](auto want_zcr, auto at_edge) {
+#pragma unroll 4
     for (int i = lane; i < flen; i += 64) {
-      const int64_t s = s0 + i;
-      const double x = (double)at0(s);                                    // zero padding
+      const float xf = at0(i);                                            // zero padding
+      const double x = (double)xf;
       sx += x; sa += fabs(x); sq += x * x;
-      mx = fmax(mx, x); mn = fmin(mn, x); pk = fmax(pk, fabs(x));
-      if ((mask & 256) && i >= 1) {                                       // edge padding for the ZCR
-        double a = (double)ate(s - 1), c = (double)ate(s);
-        a = (fabs(a) <= THR) ? 0.0 : a;
-        c = (fabs(c) <= THR) ? 0.0 : c;
-        zc += ((a < 0.0) != (c < 0.0)) ? 1.0 : 0.0;
+      mxf = fmaxf(mxf, xf); mnf = fminf(mnf, xf);
+      if (decltype(want_zcr)::value) {
+        // sign class of every sample once; its predecessor is the neighbouring lane's (lane 0: lane 63 of the
+        // previous trip).  Only frames that touch a clip end see edge padding instead of the zeros of `xf`.
+        const float xe = decltype(at_edge)::value ? ate(s0 + i) : xf;
+        const int neg = (fabsf(xe) > ZTHR && xe < 0.f) ? 1 : 0;
+        int prev = __builtin_amdgcn_update_dpp(0, neg, DPP_WAVE_SHR1, 0xF, 0xF, false);
+        prev = lane == 0 ? carry : prev;
+        carry = __builtin_amdgcn_readlane(neg, 63);
+        zci += (i >= 1 && prev != neg) ? 1 : 0;
       }
     }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  if (live) {
+    if (!(mask & 256)) pass1(F_{}, F_{});
+    else if (!edge_frame) pass1(T_{}, F_{});
+    else pass1(T_{}, T_{});
   }
-  sx = wsum(sx); sa = wsum(sa); sq = wsum(sq); zc = wsum(zc);
-  mx = wmax(mx); mn = wmin(mn); pk = wmax(pk);
+  double zc = (double)wave_sum_i(zci);
+  sx = wsum(sx); sa = wsum(sa); sq = wsum(sq);
+  wave_maxmin(mxf, mnf);
+  const double mx = (double)mxf, mn = (double)mnf, pk = fmax(fabs(mx), fabs(mn));
   const double mean = sx / n;
 
   // ---- pass 2: central moments and the histogram
   const int nb = num_bins;
-  for (int i = lane; i < nb; i += 64) hist[w][i] = 0u;
-  __syncthreads();
   double m2 = 0.0, m3 = 0.0, m4 = 0.0;
   const bool constant = !(mx > mn);
   const bool want_hist = (mask & 64) && !constant && flen >= 2 && nb >= 1;
   const double first = mn, last = mx;
   const double step = (last - first) / (double)nb;          // linspace: delta / div
-  const double norm = (double)nb / (last - first);
-  if (live) {
+  // NumPy guesses the bin as int((x - first) * nb / (last - first)) and corrects it by one against the float64 edges,
+  // so the result is the bin whose edges enclose x.  For a float32 sample x and a float64 edge e, x < e <=> x < up(e)
+  // with up(e) the smallest float32 >= e: the edges are rounded up once per frame (eu) and the per-sample work --
+  // guess, two table reads, two compares -- runs in float32 with the same outcome.
+  for (int i = lane; i < nb; i += 64) hist[w][i] = 0u;
+  for (int j = lane; j <= nb; j += 64) {
+    const double e = edge_at(first, last, step, j, nb);
+    float f = (float)e;
+    if ((double)f < e)                                       // next float towards +inf (from +-0: the smallest denormal)
+      f = f == 0.f ? __uint_as_float(1u) : __uint_as_float(__float_as_uint(f) + (f > 0.f ? 1u : -1u));
+    eu[w][j] = f;
+  }
+  __syncthreads();
+  const float firstf = mnf, normf = (float)nb / (mxf - mnf);
+  const bool wide = (mxf - mnf) > 1e-30f;
+  // Up to 16 bins and 255 samples per lane (the default: 10 bins, 32 samples): every lane counts in 8-bit fields
+  // of two 64-bit registers and the fields are summed over the wave afterwards -- LDS atomics of 64 lanes on ten
+  // addresses serialise.  Otherwise the LDS histogram.
+  const bool packed = nb <= 16 && flen <= 255 * 64;
+  unsigned long long c0 = 0ull, c1 = 0ull;
+  // HIST: 0 no histogram, 1 packed counters + one-step correction (the common case), 2 everything else
+  auto pass2 = [&](auto hist_mode) {
+    constexpr int HIST = decltype(hist_mode)::value;
+#pragma unroll 4
     for (int i = lane; i < flen; i += 64) {
-      const int64_t s = s0 + i;
-      const double x = (double)at0(s);
+      const float xf = at0(i);
+      const double x = (double)xf;
       const double d = x - mean;
       const double d2 = d * d;
       m2 += d2; m3 += d2 * d; m4 += d2 * d2;
-      if (want_hist) {
-        int idx = (int)((x - first) * norm);                // astype(intp) truncates; the offset is >= 0
-        if (idx == nb) idx -= 1;
-        if (x < edge_at(first, last, step, idx, nb)) idx -= 1;
-        if (idx != nb - 1 && x >= edge_at(first, last, step, idx + 1, nb)) idx += 1;
-        atomicAdd(&hist[w][idx], 1u);
+      if (HIST != 0) {
+        int idx = (int)((xf - firstf) * normf);             // within one bin of the float64 guess
+        idx = idx < 0 ? 0 : (idx > nb - 1 ? nb - 1 : idx);
+        if (HIST == 1 || wide) {                            // the guess is off by one bin at most: branch-free
+          const float e0 = eu[w][idx], e1 = eu[w][idx + 1];
+          idx += (xf >= e1 && idx != nb - 1) ? 1 : ((xf < e0 && idx > 0) ? -1 : 0);
+        } else {                                            // (nearly) denormal range: the float guess means nothing
+          while (idx > 0 && xf < eu[w][idx]) idx -= 1;
+          while (idx != nb - 1 && xf >= eu[w][idx + 1]) idx += 1;
+        }
+        if (HIST == 1 || packed) {
+          const unsigned long long one = 1ull << ((idx & 7) * 8);
+          c0 += idx < 8 ? one : 0ull;
+          c1 += idx < 8 ? 0ull : one;
+        } else {
+          atomicAdd(&hist[w][idx], 1u);
+        }
       }
     }
+  };
+  if (live) {
+    if (!want_hist) pass2(std::integral_constant<int, 0>{});
+    else if (packed && wide) pass2(std::integral_constant<int, 1>{});
+    else pass2(std::integral_constant<int, 2>{});
   }
   m2 = wsum(m2) / n; m3 = wsum(m3) / n; m4 = wsum(m4) / n;
   __syncthreads();
   double ent = 0.0;
-  if (want_hist) {
+  if (want_hist && packed) {
+    int mine = 0;                                           // lane j ends up with the count of bin j
+    for (int j = 0; j < nb; ++j) {                          // wave-uniform trip count
+      const unsigned long long cw = j < 8 ? c0 : c1;
+      const int c = wave_sum_i((int)((cw >> ((j & 7) * 8)) & 0xffull));
+      mine = lane == j ? c : mine;
+    }
+    if (mine > 0) {
+      const double p = (double)mine / n;                    // counts sum to n: scipy's renormalisation is exact
+      ent -= p * log(p);
+    }
+    ent = wsum(ent);
+  } else if (want_hist) {
     for (int i = lane; i < nb; i += 64) {
       const unsigned c = hist[w][i];
       if (c > 0u) {
-        const double p = (double)c / n;                     // counts sum to n: scipy's renormalisation is exact
+        const double p = (double)c / n;
         ent -= p * log(p);
       }
     }

@@ -101,3 +101,41 @@ def test_odd_frame_length_last_frame_is_nan_padded_like_the_reference(ops):
     for k in feats:
         assert np.isnan(ref[k][-1]) and np.isnan(out[k][-1]) and not np.isnan(out[k][:-1]).any()
         assert_parity(out[k][:-1], ref[k][:-1], TOL, k)
+
+
+def test_histogram_counts_identical_on_hard_cases(ops):
+    """The entropy row bins float32 samples against float32-rounded-up edges; the counts must equal NumPy's float64
+    histogram exactly: samples sitting on bin edges, a value range of a few denormals (the float guess is useless
+    there), negative ranges, 2..200 bins (packed counters up to 16, the shared LDS histogram above)."""
+    rng = np.random.default_rng(17)
+    N = 640
+    cases = []
+    for nb in (2, 3, 7, 10, 16, 17, 64, 200):
+        edges = np.linspace(-1.0, 3.0, nb + 1)
+        on_edges = np.resize(edges.astype(np.float32), N)               # float32 neighbours of the float64 edges
+        on_edges[::3] = np.nextafter(on_edges[::3], np.float32(4))
+        on_edges[1::3] = np.nextafter(on_edges[1::3], np.float32(-4))
+        on_edges[0], on_edges[1] = -1.0, 3.0
+        cases.append((nb, on_edges))
+        cases.append((nb, (rng.integers(0, 5, N) * np.float32(1e-45)).astype(np.float32)))     # denormal range
+        cases.append((nb, (-rng.random(N) * 1e-3 - 5.0).astype(np.float32)))                   # narrow, negative
+        cases.append((nb, rng.normal(0, 1, N).astype(np.float32) * np.float32(1e-38)))         # near-denormal scale
+    for nb, x in cases:
+        got = ops.frame_stats(ops.to_device_f32(x[None, :]), N, N, False, num_bins=nb, mask=64).cpu().numpy()[0, 6, 0]
+        want = O.signal_entropy(x.astype(np.float64), nb)
+        assert abs(got - want) <= 1e-6 * max(1.0, abs(want)), (nb, got, want)
+
+
+def test_zero_crossing_threshold_and_edge_frames(ops):
+    """|x| <= 1e-10 counts as zero (librosa's threshold) -- exercised with float32 values around 1e-10 -- and the frames
+    that reach over a clip end see edge padding (the other rows: zeros)."""
+    rng = np.random.default_rng(23)
+    t = np.float32(1e-10)
+    vals = np.array([t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(1)), -t, -np.nextafter(t, np.float32(0)),
+                     -np.nextafter(t, np.float32(1)), 0.0, -0.0, 1e-3, -1e-3], dtype=np.float32)
+    y = vals[rng.integers(0, len(vals), 5000)]
+    y[0], y[-1] = -1e-3, -1e-3                                   # edge padding repeats a negative sample
+    for fl, hop, center in ((256, 64, True), (250, 100, True), (512, 512, False), (64, 1, True)):
+        got = ops.frame_stats(ops.to_device_f32(y[None, :]), fl, hop, center, mask=256).cpu().numpy()[0, 8]
+        want = O.zero_crossing_rate(y.astype(np.float64), fl, hop, center)
+        assert np.array_equal(np.round(got[:len(want)] * fl), np.round(want * fl)), (fl, hop, center)
