@@ -271,6 +271,18 @@ int syg_rconv_spectrum_c64(const float* za, const float* zb, int64_t rows, int64
 int syg_analytic_mask_c64(float* X, int64_t rows, int64_t n, void* stream);
 int syg_psd_onesided_f32(const float* X, int64_t rows, int64_t n, double scale, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Batched audio ingest: integer PCM frames as stored in a WAV file -> float32 mono clips, after the
+ * host-to-device copy (half the PCIe bytes of float32 for 16-bit audio).  Replaces librosa.load's conversion
+ * reached through sygnals/core/audio/io.py:84-90 (scale 2^-(bits-1), mono = mean over channels) and the mix-down of
+ * sygnals/cli/features_cmd.py:66-68.
+ *   pcm   [rows, frames, channels] interleaved; int16 (bits 16), int32 (bits 32; 24-bit files left-justified),
+ *         uint8 (bits 8, offset 128); row stride ld in ELEMENTS
+ *   out   [rows, frames] float32, row stride ldo:  out[r, i] = mean_c pcm[r, i, c] / 2^(bits-1)
+ * ------------------------------------------------------------------------------- */
+int syg_pcm_to_f32(const void* pcm, int bits, int64_t rows, int64_t frames, int channels, int64_t ld, float* out,
+                   int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

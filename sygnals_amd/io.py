@@ -133,3 +133,55 @@ def read_clips(paths, length: Union[int, None] = None, mono: bool = True, pin: b
         t = torch.from_numpy(batch)
         return (t.pin_memory() if torch.cuda.is_available() else t), srs
     return batch, srs
+
+
+def read_wav_pcm(path):
+    """(frames [n, channels] in the file's own integer type, sample rate) -- no conversion on the host.
+    float WAV files come back as float32 (they need no scaling)."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(str(path))
+    if data.ndim == 1:
+        data = data[:, None]
+    if data.dtype.kind == "f":
+        data = data.astype(np.float32)
+    elif data.dtype not in (np.int16, np.int32, np.uint8):
+        raise ValueError(f"{path}: unsupported PCM sample type {data.dtype}")
+    return data, int(sr)
+
+
+def read_clips_pcm(paths, length: Union[int, None] = None, out=None):
+    """Batched ingest WITHOUT host-side conversion: WAV clips -> ONE integer array [B, L, C]
+    (the files' common sample type and channel count, zero padded / cut to `length`) for a single host-to-device
+    copy; scaling and mono mix-down happen on the device (ops.pcm_to_f32).  `out` may be a preallocated (e.g. pinned)
+    array / tensor view to fill.  Returns (batch, sample_rates)."""
+    clips, srs = [], []
+    for p in paths:
+        d, sr = read_wav_pcm(p)
+        clips.append(d)
+        srs.append(sr)
+    if not clips:
+        raise ValueError("read_clips_pcm: no input files")
+    dt, ch = clips[0].dtype, clips[0].shape[1]
+    for p, d in zip(paths, clips):
+        if d.dtype != dt or d.shape[1] != ch:
+            raise ValueError(f"{p}: sample type / channel count differs from the first file ({d.dtype}, {d.shape[1]} "
+                             f"channels vs {dt}, {ch}); batch such files separately")
+    L = int(length) if length is not None else max(d.shape[0] for d in clips)
+    if L < 1:
+        raise ValueError("read_clips_pcm: length must be >= 1")
+    if out is None:
+        out = np.empty((len(clips), L, ch), dtype=dt)
+    elif tuple(out.shape) != (len(clips), L, ch):
+        raise ValueError(f"read_clips_pcm: out has shape {tuple(out.shape)}, need {(len(clips), L, ch)}")
+    fill = 128 if dt == np.uint8 else 0                      # unsigned 8-bit PCM is offset binary: 128 is silence
+    for i, d in enumerate(clips):
+        n = min(d.shape[0], L)
+        out[i, :n] = d[:n] if isinstance(out, np.ndarray) else _as_tensor(d[:n])
+        if n < L:
+            out[i, n:] = fill
+    return out, srs
+
+
+def _as_tensor(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))

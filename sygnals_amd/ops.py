@@ -600,6 +600,29 @@ def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     return cmul(c[:, :n].contiguous(), w_out)
 
 
+# ------------------------------------------------------------------ batched ingest
+_PCM_BITS = {torch.int16: 16, torch.int32: 32, torch.uint8: 8}
+
+
+def pcm_to_f32(pcm: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Integer PCM [B, L] or [B, L, C] (int16 / int32 / uint8, interleaved channels, on the device) -> float32 mono
+    clips [B, L]: samples / 2^(bits-1), channels averaged (librosa.load(mono=True) semantics)."""
+    require_gpu()
+    if pcm.dtype not in _PCM_BITS or pcm.dim() not in (2, 3) or not pcm.is_cuda:
+        raise ValueError("pcm must be an int16 / int32 / uint8 device tensor of shape [B, L] or [B, L, C]")
+    pcm = pcm.contiguous()
+    B, L = pcm.shape[0], pcm.shape[1]
+    Cn = pcm.shape[2] if pcm.dim() == 3 else 1
+    if out is None:
+        out = torch.empty((B, L), dtype=torch.float32, device=pcm.device)
+    elif out.shape != (B, L) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError("out must be a float32 [B, L] tensor with unit inner stride")
+    rc = lib().syg_pcm_to_f32(_ptr(pcm), _PCM_BITS[pcm.dtype], B, L, Cn, L * Cn, _ptr(out), _ld(out),
+                              C.c_void_p(_stream_ptr()))
+    check(rc, "syg_pcm_to_f32")
+    return out
+
+
 # ------------------------------------------------------------------ FFT-backed 1-D operations (SURVEY 8 f-3)
 def pack_rows(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None, detrend: bool = False,
               reverse: bool = False, cplx: bool = False) -> torch.Tensor:

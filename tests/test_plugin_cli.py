@@ -148,3 +148,26 @@ def test_read_clips_batches_mixed_inputs(tmp_path):
     assert cut.shape == (1, 10)
     with pytest.raises(ValueError):
         sio.read_clips([])
+
+
+def test_read_clips_pcm_keeps_integer_samples(tmp_path):
+    """f-2 ingest without host conversion: one integer [B, L, C] array, zero (uint8: 128) padded, cut to length."""
+    from scipy.io import wavfile
+    from sygnals_amd import io as sio
+    rng = np.random.default_rng(1)
+    a = rng.integers(-30000, 30000, (1000, 2), dtype=np.int16)
+    b = rng.integers(-30000, 30000, (700, 2), dtype=np.int16)
+    wavfile.write(str(tmp_path / "a.wav"), 8000, a)
+    wavfile.write(str(tmp_path / "b.wav"), 8000, b)
+    batch, srs = sio.read_clips_pcm([tmp_path / "a.wav", tmp_path / "b.wav"], length=800)
+    assert batch.dtype == np.int16 and batch.shape == (2, 800, 2) and srs == [8000, 8000]
+    assert np.array_equal(batch[0], a[:800]) and np.array_equal(batch[1, :700], b) and not batch[1, 700:].any()
+    u = rng.integers(0, 255, 300, dtype=np.uint8)
+    wavfile.write(str(tmp_path / "u.wav"), 8000, u)
+    batch, _ = sio.read_clips_pcm([tmp_path / "u.wav"], length=400)
+    assert batch.dtype == np.uint8 and batch.shape == (1, 400, 1) and (batch[0, 300:] == 128).all()
+    wavfile.write(str(tmp_path / "m.wav"), 8000, a[:, 0].copy())
+    with pytest.raises(ValueError, match="channel count differs"):
+        sio.read_clips_pcm([tmp_path / "a.wav", tmp_path / "m.wav"])
+    with pytest.raises(ValueError, match="no input files"):
+        sio.read_clips_pcm([])
