@@ -200,7 +200,8 @@ int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const
  * nperseg <= nfft.  twiddle as for syg_stft_pow2_c2c_f32 ([nfft + nfft/2] complex).
  *   x        [B, L] float32
  *   window   [nperseg] float32
- *   detrend  0 none, 1 constant (per-segment mean removal)
+ *   detrend  0 none, 1 constant (per-segment mean removal), 2 linear (per-segment least-squares line,
+ *            scipy.signal.detrend type='linear')
  *   scale    density: 1/(fs*sum(w^2)); spectrum: 1/sum(w)^2   (computed by the caller)
  *   psd_out  [B, 1 + nfft/2] float32 ; partial sums in work (syg_welch_work_bytes)
  * ------------------------------------------------------------------------------- */
@@ -248,7 +249,7 @@ int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_
 /* ---------------------------------------------------------------------------------
  * FFT-backed 1-D operations; the host composes them with the power-of-two complex FFT above.
  *   syg_pack_rows_f32       out[r, i] = (x[r, j] - mean_r) * window[i] for i < min(len, n), 0 up to n;
- *                           j = reverse ? len-1-i : i; mean_r only when detrend != 0 (float64 sum, needs `work` of
+ *                           j = reverse ? len-1-i : i; detrend 0 none, 1 mean_r, 2 least-squares line (float64 sums, need `work` of
  *                           syg_pack_rows_work_bytes(rows) bytes); cplx != 0 writes complex rows (value, 0).
  *                           A real row of n floats is at the same time the packed row z[m] = x[2m] + i x[2m+1]
  *                           of n/2 complex elements consumed by syg_rconv_spectrum_c64.

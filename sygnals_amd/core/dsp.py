@@ -159,13 +159,12 @@ def welch_batch(x, fs=1.0, window="hann", nperseg=None, noverlap=None, nfft=None
         raise ValueError("noverlap must be less than nperseg.")
     if scaling not in ("density", "spectrum"):
         raise ValueError(f"Unknown scaling: {scaling!r}")
-    if detrend not in ("constant", False, None, "none"):
-        raise SygnalsHipError("welch: only detrend='constant' or False run on the device")
+    ops.detrend_code(detrend)                                 # ValueError for anything but constant / linear / False
     if not ops.is_pow2(int(nfft)) or nfft < 8 or nfft > 16384:
         raise SygnalsHipError(f"welch: nfft={nfft} must be a power of two in [8, 16384] on the device")
     w = get_window(window, nperseg)
     scale = 1.0 / (fs * (w * w).sum()) if scaling == "density" else 1.0 / w.sum() ** 2
-    p = ops.welch(x, nperseg, int(noverlap), int(nfft), w, detrend == "constant", scale)
+    p = ops.welch(x, nperseg, int(noverlap), int(nfft), w, detrend, scale)
     return np.fft.rfftfreq(int(nfft), 1 / fs).astype(np.float64), p
 
 
@@ -242,8 +241,7 @@ def periodogram_batch(x, fs=1.0, window="hann", nfft=None, detrend="constant", s
     nperseg = min(L, nfft)                                    # nfft < L truncates x to nfft samples
     if scaling not in ("density", "spectrum"):
         raise ValueError(f"Unknown scaling: {scaling!r}")
-    if detrend not in ("constant", False, None, "none"):
-        raise SygnalsHipError("periodogram: only detrend='constant' or False run on the device")
+    ops.detrend_code(detrend)
     if isinstance(window, (str, tuple)):
         w = get_window(window, nperseg)
     else:
@@ -253,7 +251,7 @@ def periodogram_batch(x, fs=1.0, window="hann", nfft=None, detrend="constant", s
         if w.shape[0] != nperseg:
             raise ValueError("window must have length of nperseg")
     scale = 1.0 / (fs * (w * w).sum()) if scaling == "density" else 1.0 / w.sum() ** 2
-    p = ops.periodogram(x, nfft, w, detrend == "constant", scale)
+    p = ops.periodogram(x, nfft, w, detrend, scale)
     return np.fft.rfftfreq(nfft, 1 / fs).astype(np.float64), p
 
 

@@ -19,45 +19,63 @@ namespace {
 
 constexpr int SUMCH = 64;         // partial sums per row for the mean (detrend='constant')
 
-// part[r, c] = float64 sum of chunk c of row r
-__global__ void row_sum_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, double* __restrict__ part) {
-  __shared__ double red[4];
+// part[r, c] = float64 sum of chunk c of row r;  part[rows * SUMCH + r * SUMCH + c] = the same of (i - (len-1)/2) x[i]
+// (the moment the least-squares line needs; centred so that slope and mean decouple)
+__global__ void row_sum_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, int linear,
+                               double* __restrict__ part, int64_t rows) {
+  __shared__ double red[8];
   const int64_t r = blockIdx.y;
   const int64_t per = (len + SUMCH - 1) / SUMCH;
   const int64_t lo = blockIdx.x * per, hi = lo + per < len ? lo + per : len;
-  double s = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) s += (double)x[r * ldx + i];
+  const double jc = 0.5 * (double)(len - 1);
+  double s = 0.0, sj = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const double v = (double)x[r * ldx + i];
+    s += v;
+    if (linear) sj += ((double)i - jc) * v;
+  }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 64); sj += __shfl_xor(sj, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = sj; }
   __syncthreads();
-  if (threadIdx.x == 0) part[r * SUMCH + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    part[r * SUMCH + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    part[(rows + r) * SUMCH + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
 }
 
-// out[r, i] = ((x[r, j] - mean_r) * (win ? win[i] : 1)) for i < len, 0 for len <= i < n;  j = reverse ? len-1-i : i.
+// out[r, i] = ((x[r, j] - trend_r(j)) * (win ? win[i] : 1)) for i < len, 0 for len <= i < n;  j = reverse ? len-1-i : i;
+// trend: nothing, the row mean, or the least-squares line mean + slope (j - (len-1)/2) (scipy.signal.detrend).
 // CPLX: out rows are complex (value, 0); otherwise real rows of n floats.
 template <bool CPLX>
 __global__ void pack_rows_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, const float* __restrict__ win,
-                                 const double* __restrict__ part, int reverse, float* __restrict__ out, int64_t n) {
-  __shared__ double mean_s;
+                                 const double* __restrict__ part, int linear, int64_t rows, int reverse,
+                                 float* __restrict__ out, int64_t n) {
+  __shared__ double mean_s, slope_s;
   const int64_t r = blockIdx.y;
-  double mean = 0.0;
+  double mean = 0.0, slope = 0.0;
+  const double jc = 0.5 * (double)(len - 1);
   if (part) {
     if (threadIdx.x < 64) {
-      double s = part[r * SUMCH + threadIdx.x];
+      double s = part[r * SUMCH + threadIdx.x], sj = linear ? part[(rows + r) * SUMCH + threadIdx.x] : 0.0;
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (threadIdx.x == 0) mean_s = s / (double)len;
+      for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 64); sj += __shfl_xor(sj, o, 64); }
+      if (threadIdx.x == 0) {
+        const double nn = (double)len;
+        mean_s = s / nn;
+        slope_s = (linear && len > 1) ? sj / (nn * (nn * nn - 1.0) / 12.0) : 0.0;
+      }
     }
     __syncthreads();
-    mean = mean_s;
+    mean = mean_s; slope = slope_s;
   }
   const float* xr = x + r * ldx;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
     if (i < len) {
-      const float s = xr[reverse ? len - 1 - i : i];
-      v = part ? (float)((double)s - mean) : s;
+      const int64_t j = reverse ? len - 1 - i : i;
+      const float s = xr[j];
+      v = part ? (float)((double)s - mean - slope * ((double)j - jc)) : s;
       if (win) v *= win[i];
     }
     if (CPLX) reinterpret_cast<float2*>(out)[r * n + i] = make_float2(v, 0.f);
@@ -146,29 +164,30 @@ unsigned grid_x(int64_t n, int64_t rows) {
 
 using namespace syg;
 
-extern "C" int64_t syg_pack_rows_work_bytes(int64_t rows) { return rows * SUMCH * (int64_t)sizeof(double); }
+extern "C" int64_t syg_pack_rows_work_bytes(int64_t rows) { return 2 * rows * SUMCH * (int64_t)sizeof(double); }
 
 extern "C" int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window,
                                  int detrend, int reverse, int cplx, float* out, int64_t n, void* work,
                                  void* stream) {
   SYG_REQUIRE(x && out, "pack_rows: null pointer argument");
   SYG_REQUIRE(rows >= 1 && rows <= 65535 && len >= 1 && n >= 1 && ldx >= len, "pack_rows: bad sizes");
+  SYG_REQUIRE(detrend >= 0 && detrend <= 2, "pack_rows: detrend must be 0 (none), 1 (constant) or 2 (linear)");
   SYG_REQUIRE(!detrend || work, "pack_rows: detrend needs the work buffer (syg_pack_rows_work_bytes)");
   if (len > n) len = n;
   double* part = nullptr;
   if (detrend) {
     part = (double*)work;
     hipLaunchKernelGGL(row_sum_kernel, dim3(SUMCH, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, len, ldx,
-                       part);
+                       detrend == 2, part, rows);
     SYG_CHECK_LAUNCH("pack_rows(sum)");
   }
   const dim3 grid(grid_x(n, rows), (unsigned)rows);
   if (cplx)
     hipLaunchKernelGGL(pack_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, len, ldx, window, part,
-                       reverse, out, n);
+                       detrend == 2, rows, reverse, out, n);
   else
     hipLaunchKernelGGL(pack_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, len, ldx, window, part,
-                       reverse, out, n);
+                       detrend == 2, rows, reverse, out, n);
   SYG_CHECK_LAUNCH("pack_rows");
   return SYG_OK;
 }

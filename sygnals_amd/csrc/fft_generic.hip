@@ -111,7 +111,7 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
     const float* __restrict__ x, int64_t L, int64_t ldx, int nperseg, int step, int nfft, int64_t nseg,
     const float* __restrict__ win, const float2* __restrict__ tw, int detrend, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ float red[WELCH_NT / 64];
+  __shared__ float red[2 * (WELCH_NT / 64)];
   const int M = nfft >> 1;
   float2* xa = reinterpret_cast<float2*>(lds);
   float2* xb = xa + M;
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
     // windowed and packed (z[m] = x[2m] + i x[2m+1]) into LDS
     constexpr int PER = (MAX_N / 2 + WELCH_NT - 1) / WELCH_NT;       // packed points per thread (16 at n = 8192)
     float2 raw[PER];
-    float s = 0.f;
+    float s = 0.f, sj = 0.f;                                         // sum x, sum (i - (n-1)/2) x
+    const float jc = 0.5f * (float)(nperseg - 1);
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int m = tid + j * WELCH_NT;
@@ -135,24 +136,33 @@ __global__ __launch_bounds__(WELCH_NT) void welch_partial_kernel(
       raw[j].x = (m < M && i0 < nperseg) ? seg[i0] : 0.f;
       raw[j].y = (m < M && i1 < nperseg) ? seg[i1] : 0.f;
       s += raw[j].x + raw[j].y;
+      if (detrend == 2) sj += ((float)i0 - jc) * raw[j].x + ((float)i1 - jc) * raw[j].y;
     }
-    float mean = 0.f;
+    // detrend 1: subtract the mean; 2: subtract the least-squares line (scipy.signal.detrend type='linear'), written
+    // around the segment centre so that slope and mean decouple: x - mean - slope (i - (n-1)/2),
+    // slope = sum (i - c) x / sum (i - c)^2, sum (i - c)^2 = n (n^2 - 1) / 12
+    float mean = 0.f, slope = 0.f;
     if (detrend) {
       s = wave_sum(s);
-      if (lane == 0) red[w] = s;
+      sj = wave_sum(sj);
+      if (lane == 0) { red[w] = s; red[WELCH_NT / 64 + w] = sj; }
       __syncthreads();
-      s = 0.f;
+      s = 0.f; sj = 0.f;
 #pragma unroll
-      for (int i = 0; i < WELCH_NT / 64; ++i) s += red[i];
+      for (int i = 0; i < WELCH_NT / 64; ++i) { s += red[i]; sj += red[WELCH_NT / 64 + i]; }
       mean = s / (float)nperseg;
+      if (detrend == 2 && nperseg > 1) {
+        const double nn = (double)nperseg;
+        slope = (float)((double)sj / (nn * (nn * nn - 1.0) / 12.0));
+      }
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int m = tid + j * WELCH_NT;
       if (m < M) {
         const int i0 = 2 * m, i1 = 2 * m + 1;
-        const float a = (i0 < nperseg) ? (raw[j].x - mean) * win[i0] : 0.f;
-        const float c = (i1 < nperseg) ? (raw[j].y - mean) * win[i1] : 0.f;
+        const float a = (i0 < nperseg) ? (raw[j].x - mean - slope * ((float)i0 - jc)) * win[i0] : 0.f;
+        const float c = (i1 < nperseg) ? (raw[j].y - mean - slope * ((float)i1 - jc)) * win[i1] : 0.f;
         xa[m] = make_float2(a, c);
       }
     }
@@ -428,7 +438,7 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
               2 * MAX_N);
   SYG_REQUIRE(nperseg >= 1 && nperseg <= nfft && step >= 1 && step <= nperseg, "welch: bad nperseg/step");
   SYG_REQUIRE(B >= 1 && B <= 65535 && L >= nperseg && ldx >= L, "welch: bad B/L/ldx");
-  SYG_REQUIRE(detrend == 0 || detrend == 1, "welch: detrend must be 0 (none) or 1 (constant)");
+  SYG_REQUIRE(detrend >= 0 && detrend <= 2, "welch: detrend must be 0 (none), 1 (constant) or 2 (linear)");
   const int64_t nseg = (L - (nperseg - step)) / step;
   SYG_REQUIRE(nseg >= 1, "welch: no complete segment");
   const int M = nfft / 2, F = M + 1;

@@ -469,9 +469,20 @@ def sosfiltfilt(x: torch.Tensor, sos: np.ndarray, zi: np.ndarray, padlen: int) -
     return y
 
 
-def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: np.ndarray, detrend: bool,
+def detrend_code(detrend) -> int:
+    """scipy's detrend argument -> the C ABI's code: 0 none (False / None / 'none'), 1 'constant' (True), 2 'linear'."""
+    if detrend in (False, None, "none", 0):
+        return 0
+    if detrend in (True, "constant", 1):
+        return 1
+    if detrend in ("linear", 2):
+        return 2
+    raise ValueError("Trend type must be 'linear' or 'constant'.")     # scipy.signal.detrend's message
+
+
+def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: np.ndarray, detrend,
           scale: float) -> torch.Tensor:
-    """Welch PSD [B, 1 + nfft/2] of x [B, L]."""
+    """Welch PSD [B, 1 + nfft/2] of x [B, L]; detrend as scipy.signal.welch (False / 'constant' / 'linear')."""
     require_gpu()
     if x.stride(1) != 1:
         x = x.contiguous()
@@ -481,7 +492,7 @@ def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: 
     work = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     out = torch.empty((B, nfft // 2 + 1), dtype=torch.float32, device=x.device)
     rc = lib().syg_welch_f32(_ptr(x), B, L, _ld(x), nperseg, nperseg - noverlap, nfft, _ptr(win),
-                             _ptr(twiddle_rfft_dev(nfft)), int(bool(detrend)), float(scale), _ptr(out), _ptr(work),
+                             _ptr(twiddle_rfft_dev(nfft)), detrend_code(detrend), float(scale), _ptr(out), _ptr(work),
                              C.c_void_p(_stream_ptr()))
     check(rc, "syg_welch_f32")
     return out
@@ -624,10 +635,10 @@ def pcm_to_f32(pcm: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
 
 
 # ------------------------------------------------------------------ FFT-backed 1-D operations
-def pack_rows(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None, detrend: bool = False,
+def pack_rows(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None, detrend=False,
               reverse: bool = False, cplx: bool = False) -> torch.Tensor:
-    """Rows of x [rows, len] -> [rows, n] real (or [rows, n, 2] complex) rows: mean removed (detrend), windowed,
-    optionally time-reversed, zero-padded / truncated to n."""
+    """Rows of x [rows, len] -> [rows, n] real (or [rows, n, 2] complex) rows: mean ('constant') or least-squares
+    line ('linear') removed, windowed, optionally time-reversed, zero-padded / truncated to n."""
     require_gpu()
     if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda:
         raise ValueError("x must be a float32 [rows, len] device tensor")
@@ -636,9 +647,10 @@ def pack_rows(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None, de
     rows, ln = x.shape
     out = torch.empty((rows, n, 2) if cplx else (rows, n), dtype=torch.float32, device=x.device)
     work = None
-    if detrend:
+    dcode = detrend_code(detrend)
+    if dcode:
         work = torch.empty(lib().syg_pack_rows_work_bytes(rows) // 8, dtype=torch.float64, device=x.device)
-    rc = lib().syg_pack_rows_f32(_ptr(x), rows, ln, _ld(x), _ptr(window), int(bool(detrend)), int(bool(reverse)),
+    rc = lib().syg_pack_rows_f32(_ptr(x), rows, ln, _ld(x), _ptr(window), dcode, int(bool(reverse)),
                                  int(bool(cplx)), _ptr(out), n, _ptr(work), C.c_void_p(_stream_ptr()))
     check(rc, "syg_pack_rows_f32")
     return out
@@ -677,7 +689,7 @@ def analytic_signal(x: torch.Tensor) -> torch.Tensor:
     return fft_any(X, True)
 
 
-def periodogram(x: torch.Tensor, nfft: int, window_host: Optional[np.ndarray], detrend: bool, scale: float
+def periodogram(x: torch.Tensor, nfft: int, window_host: Optional[np.ndarray], detrend, scale: float
                 ) -> torch.Tensor:
     """One-sided periodogram [B, nfft//2 + 1] of the first min(len, nfft) samples of the rows of x."""
     B = x.shape[0]

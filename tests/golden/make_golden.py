@@ -205,6 +205,16 @@ def main():
     for a in ("a1000", "d999", "c4096", "b50", "e7", "one"):
         g[f"hilbert_{a}"] = tr.hilbert_transform(sig[a])
         g[f"envelope_{a}"] = dsp.amplitude_envelope(sig[a], method="hilbert")
+    # linear detrending (appended last: no random draws, earlier entries unchanged)
+    ramp = {k: sig[k] + np.linspace(-0.5, 1.5, len(sig[k])) for k in ("a1000", "d999", "c4096")}
+    for a, x in ramp.items():
+        g["ramp_" + a] = x
+        f, p = dsp.compute_psd_periodogram(x, fs=1000.0, detrend="linear")
+        g[f"pgram_{a}_linear_f"], g[f"pgram_{a}_linear_p"] = f, p
+    for tag, kw in (("w256", dict(nperseg=256)), ("w1024o768", dict(nperseg=1024, noverlap=768)),
+                    ("w512nfft1024", dict(nperseg=512, nfft=1024))):
+        f, p = dsp.compute_psd_welch(ramp["c4096"], fs=48000.0, detrend="linear", **kw)
+        g[f"welch_linear_{tag}_f"], g[f"welch_linear_{tag}_p"] = f, p
     np.savez_compressed(os.path.join(OUT, "ref_dsp2.npz"), **g)
     print("golden vectors written to", OUT)
 

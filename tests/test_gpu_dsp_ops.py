@@ -263,9 +263,41 @@ def test_cli_dsp_commands(tmp_path):
     assert_parity(df["PSD"].to_numpy(), wp, TOL, "cli periodogram")
     np.testing.assert_allclose(df["Frequency"].to_numpy(), wf, atol=1e-9)
     r = run("psd-periodogram", tmp_path / "x.csv", "--fs", 1000, "-o", tmp_path / "p2.csv", "--detrend", "linear")
-    assert r.exit_code != 0                                   # linear detrend is not offloaded: loud, no CPU fallback
+    assert r.exit_code == 0, r.output
+    assert_parity(pd.read_csv(tmp_path / "p2.csv")["PSD"].to_numpy(),
+                  O.compute_psd_periodogram(x, fs=1000.0, detrend="linear")[1], TOL, "cli periodogram linear")
     r = run("hilbert", tmp_path / "x.csv", "-o", tmp_path / "h.npz")
     assert r.exit_code == 0, r.output
     z = np.load(tmp_path / "h.npz")
     assert peak_rel(z["analytic_signal"], O.hilbert_transform(x)) <= TOL
     assert_parity(z["envelope"], O.amplitude_envelope(x), TOL, "cli envelope")
+
+
+def test_linear_detrend_vs_reference_golden(g2):
+    """detrend='linear' (scipy.signal.detrend: least-squares line per row / per Welch segment) on ramped signals."""
+    from sygnals_amd.core.dsp import compute_psd_periodogram, compute_psd_welch
+    for a in ("a1000", "d999", "c4096"):
+        f, p = compute_psd_periodogram(g2["ramp_" + a], fs=1000.0, detrend="linear")
+        assert_parity(p, g2[f"pgram_{a}_linear_p"], TOL, f"periodogram linear {a}")
+    for tag, kw in (("w256", dict(nperseg=256)), ("w1024o768", dict(nperseg=1024, noverlap=768)),
+                    ("w512nfft1024", dict(nperseg=512, nfft=1024))):
+        f, p = compute_psd_welch(g2["ramp_c4096"], fs=48000.0, detrend="linear", **kw)
+        np.testing.assert_allclose(f, g2[f"welch_linear_{tag}_f"], rtol=0, atol=1e-6)
+        assert_parity(p, g2[f"welch_linear_{tag}_p"], TOL, f"welch linear {tag}")
+    with pytest.raises(ValueError, match="Trend type"):
+        compute_psd_welch(g2["ramp_c4096"], detrend="quadratic")
+
+
+def test_linear_detrend_large_offset_and_slope():
+    """A steep ramp on a large offset under small noise: the line has to be removed to ~1e-7 of its size before the
+    spectrum of the noise is visible at all."""
+    from sygnals_amd.core.dsp import compute_psd_periodogram, compute_psd_welch
+    rng = np.random.default_rng(4)
+    n = 20000
+    x = (100.0 + 0.01 * np.arange(n) + rng.normal(0, 0.05, n)).astype(np.float32).astype(np.float64)
+    f, p = compute_psd_welch(x, fs=1.0, nperseg=1024, detrend="linear")
+    wf, wp = O.welch_explicit(x, fs=1.0, nperseg=1024, detrend="linear")
+    assert_parity(p[1:], wp[1:], 1e-4, "welch linear, steep ramp")      # stated: cancellation of a 300:0.05 ramp in fp32
+    f, p = compute_psd_periodogram(x, fs=1.0, detrend="linear")
+    wf, wp = O.compute_psd_periodogram(x, fs=1.0, detrend="linear")
+    assert_parity(p[1:], wp[1:], 1e-4, "periodogram linear, steep ramp")

@@ -257,3 +257,15 @@ def test_f3_error_strings():
         O.amplitude_envelope(np.zeros(8), method="peak")
     with pytest.raises(ValueError, match="required for 'rms'"):
         O.amplitude_envelope(np.zeros(8), method="rms")
+
+
+def test_linear_detrend_matches_reference(g2):
+    for a in ("a1000", "d999", "c4096"):
+        f, p = O.compute_psd_periodogram(g2["ramp_" + a], fs=1000.0, detrend="linear")
+        np.testing.assert_allclose(f, g2[f"pgram_{a}_linear_f"], rtol=0, atol=1e-9)
+        _close(p, g2[f"pgram_{a}_linear_p"], 1e-9)
+    for tag, kw in (("w256", dict(nperseg=256)), ("w1024o768", dict(nperseg=1024, noverlap=768)),
+                    ("w512nfft1024", dict(nperseg=512, nfft=1024))):
+        f, p = O.welch_explicit(g2["ramp_c4096"], fs=48000.0, detrend="linear", **kw)
+        np.testing.assert_allclose(f, g2[f"welch_linear_{tag}_f"], rtol=0, atol=1e-6)
+        _close(p, g2[f"welch_linear_{tag}_p"], 1e-9)
