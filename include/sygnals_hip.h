@@ -248,7 +248,8 @@ int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_
 
 /* ---------------------------------------------------------------------------------
  * FFT-backed 1-D operations; the host composes them with the power-of-two complex FFT above.
- *   syg_pack_rows_f32       out[r, i] = (x[r, j] - mean_r) * window[i] for i < min(len, n), 0 up to n;
+ *   syg_pack_rows_f32       (row stride ldx may be smaller than len: overlapping rows = frames of one signal)
+ *                           out[r, i] = (x[r, j] - mean_r) * window[i] for i < min(len, n), 0 up to n;
  *                           j = reverse ? len-1-i : i; detrend 0 none, 1 mean_r, 2 least-squares line (float64 sums, need `work` of
  *                           syg_pack_rows_work_bytes(rows) bytes); cplx != 0 writes complex rows (value, 0).
  *                           A real row of n floats is at the same time the packed row z[m] = x[2m] + i x[2m+1]
@@ -263,6 +264,10 @@ int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_
  *   syg_psd_onesided_f32    out[r, k] = scale * |X[r, k]|^2 * (1 for DC and the even-n Nyquist bin, else 2),
  *                           k <= n/2, from the full spectrum X [rows, n] -- scipy.signal.periodogram as called
  *                           at sygnals/core/dsp.py:484-492
+ *   syg_col_mean_f32        acc[k] (float64 [F], caller-owned) = (first ? 0 : acc[k]) + sum_r in[r, k]; on the `last`
+ *                           call out[k] = acc[k] / divisor: the average of per-segment periodograms for Welch with
+ *                           a segment length that is not a power of two (segments = overlapping rows, row stride
+ *                           ldx = nperseg - noverlap, through syg_pack_rows_f32 -> FFT -> syg_psd_onesided_f32)
  * ------------------------------------------------------------------------------- */
 int64_t syg_pack_rows_work_bytes(int64_t rows);
 int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window, int detrend,
@@ -271,6 +276,8 @@ int syg_rconv_spectrum_c64(const float* za, const float* zb, int64_t rows, int64
                            void* stream);
 int syg_analytic_mask_c64(float* X, int64_t rows, int64_t n, void* stream);
 int syg_psd_onesided_f32(const float* X, int64_t rows, int64_t n, double scale, float* out, void* stream);
+int syg_col_mean_f32(const float* in, int64_t rows, int64_t F, double* acc, int first, int last, double divisor,
+                     float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Batched audio ingest: integer PCM frames as stored in a WAV file -> float32 mono clips, after the

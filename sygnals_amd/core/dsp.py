@@ -160,8 +160,6 @@ def welch_batch(x, fs=1.0, window="hann", nperseg=None, noverlap=None, nfft=None
     if scaling not in ("density", "spectrum"):
         raise ValueError(f"Unknown scaling: {scaling!r}")
     ops.detrend_code(detrend)                                 # ValueError for anything but constant / linear / False
-    if not ops.is_pow2(int(nfft)) or nfft < 8 or nfft > 16384:
-        raise SygnalsHipError(f"welch: nfft={nfft} must be a power of two in [8, 16384] on the device")
     w = get_window(window, nperseg)
     scale = 1.0 / (fs * (w * w).sum()) if scaling == "density" else 1.0 / w.sum() ** 2
     p = ops.welch(x, nperseg, int(noverlap), int(nfft), w, detrend, scale)

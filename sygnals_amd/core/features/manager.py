@@ -14,6 +14,7 @@ import logging
 from typing import Any, Dict, List, Optional
 
 import numpy as np
+import torch
 
 from ... import _tables as T
 from ... import ops
@@ -119,6 +120,7 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     need_stft = bool(want_stats or want_contrast or want_mfcc)
 
     mel = stats = cpv = None
+    t_stft = Tn
     try:
         if not need_stft:
             pass
@@ -128,6 +130,11 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
         else:
             X = ops.stft_any(yd, frame_length, hop_length, center, window)
             F = X.shape[2]
+            if X.shape[1] < Tn:
+                # odd frame_length: the centred STFT has one frame less than the manager's frame count whenever hop
+                # divides len(y); the reference NaN-pads rows that come out short (manager.py:378-386), as above
+                t_stft = X.shape[1]
+                X = torch.cat([X, torch.zeros((B, Tn - t_stft, F, 2), dtype=X.dtype, device=X.device)], dim=1)
             if want_stats or want_contrast:
                 mag = ops.cabs_pow(X, 1).reshape(B * Tn, F)
                 if want_stats:
@@ -148,6 +155,12 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     def host(t):
         return t.cpu().numpy().astype(np.float64) if to_host else t
 
+    def short(v):                                   # STFT-based rows past the last frame the STFT has
+        if t_stft < Tn:
+            v = v.astype(np.float64) if isinstance(v, np.ndarray) else v.clone().float()
+            v[:, t_stft:] = float("nan")
+        return v
+
     for name in features:
         if name in res:
             continue
@@ -155,28 +168,28 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
             res[name] = host(tstats[name])
         elif name in _SPECTRUM_BASED:
             if name == "spectral_centroid":
-                res[name] = host(stats[:, 0])
+                res[name] = short(host(stats[:, 0]))
             elif name == "spectral_bandwidth":
-                res[name] = host(stats[:, 1])
+                res[name] = short(host(stats[:, 1]))
             elif name == "spectral_flatness":
-                res[name] = host(stats[:, 2])
+                res[name] = short(host(stats[:, 2]))
             elif name == "spectral_rolloff":
                 idx = stats[:, 3].cpu().numpy().astype(np.int64)
-                res[name] = freqs[idx] if to_host else stats[:, 3] * float(sr / frame_length)
+                res[name] = short(freqs[idx] if to_host else stats[:, 3] * float(sr / frame_length))
             elif name == "dominant_frequency":
                 idx = stats[:, 4].cpu().numpy().astype(np.int64)
-                res[name] = freqs[idx] if to_host else stats[:, 4] * float(sr / frame_length)
+                res[name] = short(freqs[idx] if to_host else stats[:, 4] * float(sr / frame_length))
         elif name == "spectral_contrast":
             cdb, host_c = ops.contrast_db(cpv, linear=bool(cp.get("linear", False))), host
             R = cdb.shape[1]
             for i in range(R - 1):
-                res[f"contrast_band_{i}"] = host_c(cdb[:, i])
-            res["contrast_delta"] = host_c(cdb[:, R - 1])
+                res[f"contrast_band_{i}"] = short(host_c(cdb[:, i]))
+            res["contrast_delta"] = short(host_c(cdb[:, R - 1]))
         elif name == "mfcc":
             _, mf = ops.logmel_dct(mel, mp.get("n_mfcc", 13), mp.get("dct_type", 2), mp.get("norm", "ortho"),
                                    float(mp.get("lifter", 0.0)), ref="max")
             for i in range(mf.shape[1]):
-                res[f"mfcc_{i}"] = host(mf[:, i])
+                res[f"mfcc_{i}"] = short(host(mf[:, i]))
     return res
 
 

@@ -152,6 +152,18 @@ __global__ void psd_onesided_kernel(const float2* __restrict__ X, int64_t n, flo
   }
 }
 
+// acc[k] = (first ? 0 : acc[k]) + sum_r in[r, k] (float64, rows in order);  last: out[k] = acc[k] / divisor.
+// Averages the per-segment periodograms of the generic Welch path in a fixed order, chunk after chunk.
+__global__ void col_mean_kernel(const float* __restrict__ in, int64_t rows, int64_t F, double* __restrict__ acc,
+                                int first, int last, double divisor, float* __restrict__ out) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k >= F) return;
+  double s = first ? 0.0 : acc[k];
+  for (int64_t r = 0; r < rows; ++r) s += (double)in[r * F + k];
+  acc[k] = s;
+  if (last) out[k] = (float)(s / divisor);
+}
+
 unsigned grid_x(int64_t n, int64_t rows) {
   int64_t b = (n + 255) / 256;
   const int64_t cap = rows >= 64 ? 64 : 4096 / (rows < 1 ? 1 : rows);
@@ -170,7 +182,8 @@ extern "C" int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int6
                                  int detrend, int reverse, int cplx, float* out, int64_t n, void* work,
                                  void* stream) {
   SYG_REQUIRE(x && out, "pack_rows: null pointer argument");
-  SYG_REQUIRE(rows >= 1 && rows <= 65535 && len >= 1 && n >= 1 && ldx >= len, "pack_rows: bad sizes");
+  // ldx < len is allowed: overlapping rows (frames of one signal, row stride = hop)
+  SYG_REQUIRE(rows >= 1 && rows <= 65535 && len >= 1 && n >= 1 && ldx >= 1, "pack_rows: bad sizes");
   SYG_REQUIRE(detrend >= 0 && detrend <= 2, "pack_rows: detrend must be 0 (none), 1 (constant) or 2 (linear)");
   SYG_REQUIRE(!detrend || work, "pack_rows: detrend needs the work buffer (syg_pack_rows_work_bytes)");
   if (len > n) len = n;
@@ -218,5 +231,16 @@ extern "C" int syg_psd_onesided_f32(const float* X, int64_t rows, int64_t n, dou
   hipLaunchKernelGGL(psd_onesided_kernel, dim3(grid_x(n / 2 + 1, rows), (unsigned)rows), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)X, n, (float)scale, out);
   SYG_CHECK_LAUNCH("psd_onesided");
+  return SYG_OK;
+}
+
+extern "C" int syg_col_mean_f32(const float* in, int64_t rows, int64_t F, double* acc, int first, int last,
+                                double divisor, float* out, void* stream) {
+  SYG_REQUIRE(in && acc, "col_mean: null pointer argument");
+  SYG_REQUIRE(rows >= 1 && F >= 1, "col_mean: bad sizes");
+  SYG_REQUIRE(!last || (out && divisor != 0.0), "col_mean: the last call needs out and a non-zero divisor");
+  hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, in, rows, F,
+                     acc, first, last, divisor, out);
+  SYG_CHECK_LAUNCH("col_mean");
   return SYG_OK;
 }

@@ -355,9 +355,46 @@ def stft_any(y, n_fft, hop, center=True, window="hann", win_length=None):
     """Complex STFT [B, T, F, 2]: the wave-FFT kernel for n_fft = 2048, the LDS Stockham kernel otherwise."""
     if n_fft == 2048:
         return stft2048_c2c(y, hop, center, window, 2048 if win_length is None else win_length)
-    if not is_pow2(n_fft) or n_fft < 8 or n_fft > 16384:
-        raise SygnalsHipError(f"n_fft={n_fft}: only powers of two in [8, 16384] are implemented on the device")
-    return stft_pow2(y, n_fft, hop, center, window, win_length)
+    if is_pow2(n_fft) and 8 <= n_fft <= 16384:
+        return stft_pow2(y, n_fft, hop, center, window, win_length)
+    return stft_rows(y, n_fft, hop, center, window, win_length)
+
+
+MAX_ROWS = 65535
+
+
+def frame_rows(sig: torch.Tensor, n: int, step: int, count: int, first: int = 0) -> torch.Tensor:
+    """`count` overlapping rows of length n of the contiguous 1-D device tensor `sig`, row r starting at sample
+    (first + r) * step -- a strided VIEW (no copy) for syg_pack_rows_f32, whose row stride may be below the row length."""
+    return sig.as_strided((count, n), (step, 1), sig.storage_offset() + first * step)
+
+
+def stft_rows(y: torch.Tensor, n_fft: int, hop: int, center: bool = True, window="hann", win_length=None):
+    """Framed STFT for ANY n_fft >= 1 (librosa.stft accepts any frame length): the frames of each clip are windowed
+    and packed as overlapping rows, transformed with the arbitrary-length FFT (four-step / Bluestein) and cut to the
+    1 + n_fft//2 non-negative bins.  Frame-major complex [B, T, F, 2] like the power-of-two kernels."""
+    require_gpu()
+    B, L = y.shape
+    win_length = n_fft if win_length is None else win_length
+    pad = n_fft // 2 if center else 0
+    # librosa's count on the padded signal; equals num_frames() for even n_fft, one less for an odd n_fft when hop
+    # divides L (the padding is n_fft // 2 on both sides, one sample short of n_fft)
+    Tn = 1 + (L + 2 * pad - n_fft) // hop if L + 2 * pad >= n_fft else 0
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    yp = y
+    if pad or y.stride(1) != 1 or not y.is_contiguous():
+        yp = torch.zeros((B, L + 2 * pad), dtype=torch.float32, device=y.device)     # zero padding: data movement only
+        yp[:, pad:pad + L] = y
+    win = window_dev(window, win_length, n_fft)
+    F = n_fft // 2 + 1
+    out = torch.empty((B, Tn, F, 2), dtype=torch.float32, device=y.device)
+    for b in range(B):
+        for t0 in range(0, Tn, MAX_ROWS):
+            tc = min(MAX_ROWS, Tn - t0)
+            X = fft_any(pack_rows(frame_rows(yp[b], n_fft, hop, tc, t0), n_fft, window=win, cplx=True))
+            out[b, t0:t0 + tc] = X[:, :F]
+    return out
 
 
 def cabs_pow(x: torch.Tensor, power: int = 1) -> torch.Tensor:
@@ -487,6 +524,8 @@ def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: 
     if x.stride(1) != 1:
         x = x.contiguous()
     B, L = x.shape
+    if not (is_pow2(nfft) and 8 <= nfft <= 16384):
+        return welch_rows(x, nperseg, noverlap, nfft, window_host, detrend, scale)
     win = _dev(np.asarray(window_host, dtype=np.float32))
     nbytes = lib().syg_welch_work_bytes(B, nfft)
     work = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
@@ -495,6 +534,31 @@ def welch(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: 
                              _ptr(twiddle_rfft_dev(nfft)), detrend_code(detrend), float(scale), _ptr(out), _ptr(work),
                              C.c_void_p(_stream_ptr()))
     check(rc, "syg_welch_f32")
+    return out
+
+
+def welch_rows(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_host: np.ndarray, detrend,
+               scale: float) -> torch.Tensor:
+    """Welch for ANY nperseg / nfft (scipy.signal.welch takes any): segments as overlapping rows -> detrend + window
+    (syg_pack_rows_f32) -> arbitrary-length FFT -> one-sided |X|^2 -> float64 average in segment order."""
+    B, L = x.shape
+    step = nperseg - noverlap
+    nseg = (L - noverlap) // step
+    if nseg < 1:
+        raise ValueError("welch: the signal is shorter than one segment")
+    win = _dev(np.asarray(window_host, dtype=np.float32))
+    F = nfft // 2 + 1
+    out = torch.empty((B, F), dtype=torch.float32, device=x.device)
+    acc = torch.empty(F, dtype=torch.float64, device=x.device)
+    st = C.c_void_p(_stream_ptr())
+    for b in range(B):
+        for s0 in range(0, nseg, MAX_ROWS):
+            sc = min(MAX_ROWS, nseg - s0)
+            X = fft_any(pack_rows(frame_rows(x[b], nperseg, step, sc, s0), nfft, window=win, detrend=detrend, cplx=True))
+            P = torch.empty((sc, F), dtype=torch.float32, device=x.device)
+            check(lib().syg_psd_onesided_f32(_ptr(X), sc, nfft, float(scale), _ptr(P), st), "syg_psd_onesided_f32")
+            check(lib().syg_col_mean_f32(_ptr(P), sc, F, _ptr(acc), int(s0 == 0), int(s0 + sc == nseg), float(nseg),
+                                         _ptr(out[b]), st), "syg_col_mean_f32")
     return out
 
 

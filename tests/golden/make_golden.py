@@ -215,6 +215,12 @@ def main():
                     ("w512nfft1024", dict(nperseg=512, nfft=1024))):
         f, p = dsp.compute_psd_welch(ramp["c4096"], fs=48000.0, detrend="linear", **kw)
         g[f"welch_linear_{tag}_f"], g[f"welch_linear_{tag}_p"] = f, p
+    # Welch with segment lengths that are not powers of two
+    for tag, kw in (("n1000", dict(nperseg=1000)), ("n300nfft500", dict(nperseg=300, nfft=500)),
+                    ("n777o100", dict(nperseg=777, noverlap=100)), ("n1000lin", dict(nperseg=1000, detrend="linear")),
+                    ("n20000", dict(nperseg=20000))):                      # longer than the signal: scipy shortens it
+        f, p = dsp.compute_psd_welch(ramp["c4096"], fs=48000.0, **kw)
+        g[f"welch_any_{tag}_f"], g[f"welch_any_{tag}_p"] = f, p
     np.savez_compressed(os.path.join(OUT, "ref_dsp2.npz"), **g)
     print("golden vectors written to", OUT)
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 from oracle import cpu_ref as O
 from tests.gpu_util import assert_parity, peak_rel
-from tests.test_oracle_golden import CONV_PAIRS, CORR_PAIRS, PGRAM_CASES
+from tests.test_oracle_golden import CONV_PAIRS, CORR_PAIRS, PGRAM_CASES, WELCH_ANY
 
 TOL = 1e-5
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -301,3 +301,56 @@ def test_linear_detrend_large_offset_and_slope():
     f, p = compute_psd_periodogram(x, fs=1.0, detrend="linear")
     wf, wp = O.compute_psd_periodogram(x, fs=1.0, detrend="linear")
     assert_parity(p[1:], wp[1:], 1e-4, "periodogram linear, steep ramp")
+
+
+@pytest.mark.parametrize("tag,kw", WELCH_ANY)
+def test_welch_any_segment_length_vs_reference_golden(g2, tag, kw):
+    """nperseg / nfft that are not powers of two (scipy takes any): overlapping-row path, arbitrary-length FFT."""
+    from sygnals_amd.core.dsp import compute_psd_welch
+    f, p = compute_psd_welch(g2["ramp_c4096"], fs=48000.0, **kw)
+    np.testing.assert_allclose(f, g2[f"welch_any_{tag}_f"], rtol=0, atol=1e-6)
+    assert_parity(p, g2[f"welch_any_{tag}_p"], TOL, f"welch {tag}")
+
+
+def test_welch_batch_any_length_many_segments():
+    """More segments than one launch takes rows (65535): the float64 average runs chunk after chunk."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.dsp import welch_batch
+    rng = np.random.default_rng(12)
+    x = (rng.normal(0, 0.3, (2, 70000 * 6 + 12)) + 0.1).astype(np.float32)
+    f, p = welch_batch(ops.to_device_f32(x), fs=100.0, nperseg=12, noverlap=6)          # 70001 segments
+    for b in range(2):
+        wf, wp = O.welch_explicit(x[b].astype(np.float64), fs=100.0, nperseg=12, noverlap=6)
+        assert_parity(p[b].cpu().numpy(), wp, TOL, "welch nperseg=12")
+
+
+@pytest.mark.parametrize("n_fft,hop,win_length,center", [(1000, 250, None, True), (600, 150, 400, True), (1023, 100, None, False),
+                                                         (3, 1, None, True), (20000, 5000, None, True)])
+def test_stft_any_frame_length_vs_oracle(n_fft, hop, win_length, center):
+    """compute_stft with frame lengths that are not powers of two (librosa.stft takes any n_fft)."""
+    from sygnals_amd.core.dsp import compute_stft
+    y = O.synth_clips(1, 30000, 16000, seed=7)[0].astype(np.float64)
+    X = compute_stft(y, n_fft=n_fft, hop_length=hop, win_length=win_length, center=center)
+    want = O.stft(y, n_fft=n_fft, hop_length=hop, win_length=win_length, center=center)
+    assert X.shape == want.shape and X.dtype == np.complex128
+    assert peak_rel(X, want) <= TOL
+
+
+def test_extract_features_with_odd_frame_length():
+    """`features extract --frame-length 1000`: the manager falls to the generic STFT for any frame length."""
+    from sygnals_amd.core.features.manager import extract_features
+    sr = 16000
+    y = O.synth_clips(1, 24000, sr, seed=9)[0].astype(np.float64)
+    feats = ["mfcc", "spectral_centroid", "spectral_bandwidth", "rms_energy"]
+    got = extract_features(y, sr, feats, frame_length=1000, hop_length=250, output_format="dict_of_arrays")
+    want = O.extract_features(y, sr, feats, frame_length=1000, hop_length=250)
+    for k in ("mfcc_0", "mfcc_5", "mfcc_12", "spectral_centroid", "spectral_bandwidth", "rms_energy"):
+        assert_parity(got[k], want[k], TOL, k)
+    # odd frame_length, hop dividing len(y): the centred STFT is one frame short of the manager's count; the missing
+    # value is NaN (the reference pads rows that come out short, manager.py:378-386)
+    got = extract_features(y, sr, ["spectral_centroid", "mfcc"], frame_length=999, hop_length=250, output_format="dict_of_arrays")
+    want = O.extract_features(y, sr, ["spectral_centroid", "mfcc"], frame_length=999, hop_length=250)
+    T = len(got["time"])
+    assert len(want["spectral_centroid"]) == T - 1 and np.isnan(got["spectral_centroid"][-1]) and np.isnan(got["mfcc_3"][-1])
+    assert_parity(got["spectral_centroid"][:-1], want["spectral_centroid"], TOL, "odd centroid")
+    assert_parity(got["mfcc_3"][:-1], want["mfcc_3"], TOL, "odd mfcc")

@@ -269,3 +269,15 @@ def test_linear_detrend_matches_reference(g2):
         f, p = O.welch_explicit(g2["ramp_c4096"], fs=48000.0, detrend="linear", **kw)
         np.testing.assert_allclose(f, g2[f"welch_linear_{tag}_f"], rtol=0, atol=1e-6)
         _close(p, g2[f"welch_linear_{tag}_p"], 1e-9)
+
+
+WELCH_ANY = [("n1000", dict(nperseg=1000)), ("n300nfft500", dict(nperseg=300, nfft=500)),
+             ("n777o100", dict(nperseg=777, noverlap=100)), ("n1000lin", dict(nperseg=1000, detrend="linear")),
+             ("n20000", dict(nperseg=20000))]
+
+
+@pytest.mark.parametrize("tag,kw", WELCH_ANY)
+def test_welch_any_segment_length_matches_reference(g2, tag, kw):
+    f, p = O.welch_explicit(g2["ramp_c4096"], fs=48000.0, **kw)
+    np.testing.assert_allclose(f, g2[f"welch_any_{tag}_f"], rtol=0, atol=1e-6)
+    _close(p, g2[f"welch_any_{tag}_p"], 1e-9)
