@@ -298,8 +298,13 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
     fused=None picks the one-launch clip-resident form when the clip's mel matrix fits in LDS and there are
     enough clips to fill the chip (a workgroup owns whole clips); True / False force either form.
     """
-    if n_fft != 2048:
-        raise SygnalsHipError("mfcc_batch: only n_fft=2048 has a fused path; use features.extract_features_batch")
+    if n_fft != 2048 or n_mels > 16 * fused_waves():
+        # no fused kernel for this shape: complex STFT (any frame length) -> |X|^2 -> dense mel -> dB + DCT
+        if fused:
+            raise SygnalsHipError(f"mfcc_batch: no fused kernel for n_fft={n_fft}, n_mels={n_mels}")
+        P = cabs_pow(stft_any(y, n_fft, hop, center, window), 2)
+        mel = mel_dense(P, mel_config(sr, n_fft, n_mels, fmin, fmax).basis)
+        return logmel_dct(mel, n_mfcc, lifter=lifter)[1]
     if fused is None:
         fused = mfcc_fused_fits(n_mels, num_frames(y.shape[1], 2048, hop, center), n_mfcc) and y.shape[0] >= 128
     if fused:

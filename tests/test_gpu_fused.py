@@ -230,3 +230,16 @@ def test_mfcc_one_launch_rejects_oversized_clip(ops):
         ops.stft2048_mfcc(y, 16000, n_mels=128)
     out = ops.mfcc_batch(y, 16000, n_mels=128)          # falls back to the two-launch form
     assert out.shape == (2, 13, 313)
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(1024, 256, 40), (512, 128, 64), (1000, 250, 40), (4096, 1024, 128), (2048, 512, 300)])
+def test_mfcc_batch_other_frame_lengths(n_fft, hop, n_mels):
+    """mfcc_batch away from the fused shape (n_fft != 2048, or more mel bands than the fused kernel holds): complex
+    STFT of any frame length -> |X|^2 -> dense mel -> dB + DCT, same numbers as the oracle's chain."""
+    from sygnals_amd import ops
+    Y = O.synth_clips(3, 24000, 16000, seed=31)
+    out = ops.mfcc_batch(ops.to_device_f32(Y), 16000, n_fft=n_fft, hop=hop, n_mels=n_mels).cpu().numpy()
+    ref = O.mfcc_batch(Y, 16000, n_fft=n_fft, hop_length=hop, n_mels=n_mels)
+    assert out.shape == ref.shape
+    for b in range(3):
+        assert_parity(out[b], ref[b], 1e-5, f"n_fft={n_fft} clip {b}")
