@@ -4,15 +4,22 @@
 Workload (BASELINE.json configs[1], "C2"): per GPU 1024 synthetic clips of 1 s @ 48 kHz
 (49 152 000 samples), STFT n_fft=2048 hop=512 hann center -> |X|^2 -> 40 Slaney mel bands ->
 power_to_db(ref=max, top_db=80) -> DCT-II ortho, 13 coefficients.  Inputs are resident in HBM
-when the timed region starts.  One step = one pass of the hot path over the batch (two kernel
-launches: the fused STFT/mel kernel and the per-clip dB+DCT kernel).
+when the timed region starts.  One step = one pass of the hot path over the batch: ONE kernel launch
+(samples in, MFCCs out) on a single GPU.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, every rank owns its own 1024 clips (weak scaling), no data-path
 collective; the only exchange is the RCCL gather of the [1024, 13, 94] result blocks to rank 0,
-inside the timed region.  Rank 0 prints ONE JSON line.
+inside the timed region, asynchronous: the gather of step k runs beside the kernels of step k+1.
+A workgroup of the fused kernels fills a whole CU, so a communication kernel that needs CUs at the
+same time either waits for a full launch or makes that launch wait for it (measured with a stand-in:
+tools/queue_bench.py -> profiles/r01_coresidency.json, 167 -> 217 us per step).  For N > 1 the step
+therefore runs as the two-launch form (STFT->mel kernel + per-clip dB/DCT kernel, +3 us) on all but
+RESERVE_CUS compute units, and RCCL's point-to-point channels are capped so that its workgroups fit
+the CUs set aside (NCCL_NCHANNELS_PER_PEER / NCCL_MAX_P2P_NCHANNELS; all three can be overridden from
+the environment).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -28,6 +35,7 @@ import numpy as np
 SR = 48000
 L = 48000
 B_PER_GPU = 1024
+RESERVE_CUS = 32     # N > 1: compute units left to RCCL's send / receive workgroups (4 channels x 7 peers at the root)
 N_FFT, HOP, N_MELS, N_MFCC = 2048, 512, 40, 13
 T_FRAMES = 1 + L // HOP
 ALGO_BYTES_PER_CLIP = 4 * L + 4 * N_MFCC * T_FRAMES        # 196 888 B: read samples, write MFCCs
@@ -108,7 +116,14 @@ def main():
     same_gpu = os.environ.get("SYG_BENCH_SAME_GPU") == "1"
     dev_index = 0 if same_gpu else local_rank
     torch.cuda.set_device(dev_index)
+    reserve = 0
     if world > 1:
+        # CUs set aside for the collective + RCCL capped to fit them (see the module docstring); set before the
+        # process group and the first launch read them
+        os.environ.setdefault("SYGNALS_AMD_RESERVE_CUS", str(RESERVE_CUS))
+        os.environ.setdefault("NCCL_NCHANNELS_PER_PEER", "4")
+        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", str(4 * (world - 1)))
+        reserve = int(os.environ["SYGNALS_AMD_RESERVE_CUS"])
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if same_gpu:
             dist.init_process_group("gloo")
@@ -127,7 +142,8 @@ def main():
     gat = RootGather(n_total, (B, N_MFCC, T_frames), torch.float32, "cpu" if same_gpu else torch.device("cuda", dev_index))
 
     def step():
-        out = ops.mfcc_batch(y, SR, N_FFT, HOP, N_MELS, N_MFCC)
+        # N > 1: two-launch form (tile-granular shares; robust to the CUs the gather holds), else one launch
+        out = ops.mfcc_batch(y, SR, N_FFT, HOP, N_MELS, N_MFCC, fused=False if world > 1 else None)
         if world > 1:
             gat.finish()                               # (the previous step's gather; a stream-side wait)
             gat.start(out.cpu() if same_gpu else out)
@@ -162,25 +178,32 @@ def main():
         reps = max(10, min(a.steps, 100))
         # back-to-back launches between two events on the launch stream (steady clock: the timed steps above
         # have just run); the average includes the ~2 us dispatch gap, as rocprofv3's per-dispatch average does not
+        one_launch = world == 1
         e0.record()
         for _ in range(reps):
-            ops.stft2048_mfcc(y, SR, HOP, True, "hann", N_MELS, N_MFCC)
+            if one_launch:
+                ops.stft2048_mfcc(y, SR, HOP, True, "hann", N_MELS, N_MFCC)
+            else:                                   # N > 1 runs the two-launch form: its dominant kernel is the mel kernel
+                ops.stft2048_mel(y, SR, HOP, True, "hann", 2048, N_MELS)
         e1.record()
         e1.synchronize()
         kdur = e0.elapsed_time(e1) * 1e-3 / reps
-        # algorithmic bytes of the path this launch carries: every sample read once, MFCCs written once
-        kbytes = B * ALGO_BYTES_PER_CLIP           # SURVEY 8d per-clip figure x clips per launch
+        # algorithmic bytes of the path this launch carries: every sample read once, MFCCs (N > 1: the mel matrix,
+        # which the second launch turns into MFCCs) written once
+        kbytes = B * ALGO_BYTES_PER_CLIP if one_launch else B * (4 * L + 4 * N_MELS * T_frames)
         achieved = kbytes / kdur / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("dominant_kernel_bytes_per_launch")
+                traffic = json.load(open(tp)).get("dominant_kernel_bytes_per_launch") if one_launch else None
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "stft2048_kernel<16,2,3> (16 waves, staged tiles, clip-resident MFCC)", "kernel_avg_us": round(kdur * 1e6, 2),
+                "kernel": "stft2048_kernel<16,2,3> (16 waves, staged tiles, clip-resident MFCC)" if one_launch else
+                          f"stft2048_kernel<16,2,0> (16 waves, staged tiles, mel out) on all but {reserve} CUs",
+                "kernel_avg_us": round(kdur * 1e6, 2),
                 "algorithmic_bytes_per_launch": kbytes}
 
     if rank == 0:
@@ -195,7 +218,8 @@ def main():
                                    "40-band Slaney mel -> power_to_db(ref=max, top_db=80) -> 13 MFCC (DCT-II ortho)",
                        "clips_per_gpu": B, "clip_samples": L, "sr": SR, "n_fft": N_FFT, "hop": HOP,
                        "n_mels": N_MELS, "n_mfcc": N_MFCC, "parallelism": f"clip-sharded x{world}" +
-                       (", RCCL gather to rank 0 in the timed region" if world > 1 else "")},
+                       (f", two-launch form on all but {reserve} CUs, asynchronous RCCL gather to rank 0 in the timed "
+                        f"region" if world > 1 else ", one launch per step")},
             "hbm_roofline_frac_whole_step": round(job_bytes / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "roofline": roof, "cpu_baseline": cpu,
         }

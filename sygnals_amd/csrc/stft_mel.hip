@@ -27,6 +27,7 @@
 // 198, 219-223 and cepstral.py:106-115; per-frame statistics follow sygnals/core/features/frequency_domain.py:24-386.
 // Index maps and LDS bank behaviour are validated by tools/wave_fft_model_v4.py.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 #ifndef SYG_ABL
@@ -989,6 +990,10 @@ constexpr size_t lds_bytes() {
 }
 
 // Workgroups per CU: two of 8 waves or one of 16; each takes a contiguous chunk of tiles.
+// SYGNALS_AMD_RESERVE_CUS=n (read at every launch) leaves n CUs out of the grid.  A workgroup of these kernels fills a
+// CU (16 waves x 128 VGPRs), so a kernel of another stream that needs a few CUs at the same time -- RCCL's send /
+// receive workgroups while the previous batch is gathered -- either waits for a whole launch or makes this launch wait
+// for it (tools/queue_bench.py: 167 -> 256 us for every second launch).  With the CUs set aside both run side by side.
 void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -998,7 +1003,12 @@ void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
       n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  const int64_t slots = (int64_t)n_cu * (waves == 8 ? 2 : 1);
+  int use_cu = n_cu;
+  if (const char* e = getenv("SYGNALS_AMD_RESERVE_CUS")) {
+    const int r = atoi(e);
+    if (r > 0 && r < n_cu) use_cu = n_cu - r;
+  }
+  const int64_t slots = (int64_t)use_cu * (waves == 8 ? 2 : 1);
   int64_t p = (total_tiles + slots - 1) / slots;
   if (p < 1) p = 1;
   per = (int)p;
