@@ -243,3 +243,16 @@ def test_mfcc_batch_other_frame_lengths(n_fft, hop, n_mels):
     assert out.shape == ref.shape
     for b in range(3):
         assert_parity(out[b], ref[b], 1e-5, f"n_fft={n_fft} clip {b}")
+
+
+def test_reserved_cus_change_shares_not_results(monkeypatch):
+    """SYGNALS_AMD_RESERVE_CUS leaves compute units out of the persistent grids (room for a collective's workgroups):
+    other tile / clip shares per workgroup, the same bits."""
+    from sygnals_amd import ops
+    Y = ops.to_device_f32(O.synth_clips(300, 30000, 48000, seed=3))
+    ref1 = ops.mfcc_batch(Y, 48000, n_mels=40, fused=True)
+    ref2 = ops.mfcc_batch(Y, 48000, n_mels=40, fused=False)
+    for r in ("32", "200", "255", "1000", "junk"):
+        monkeypatch.setenv("SYGNALS_AMD_RESERVE_CUS", r)
+        assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=True), ref1), r
+        assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=False), ref2), r
