@@ -291,6 +291,24 @@ int syg_col_mean_f32(const float* in, int64_t rows, int64_t F, double* acc, int 
 int syg_pcm_to_f32(const void* pcm, int bits, int64_t rows, int64_t frames, int channels, int64_t ld, float* out,
                    int64_t ldo, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Feature formatting for ML on the device.  x is a [n, F] float32 matrix (frames x features);
+ * statistics are float64 and NaN-aware like scikit-learn's fit (NaNs ignored; all-NaN column -> NaN).
+ *   syg_col_stats_f32      out [5, F] float64: count, mean, population variance, min, max per column -- the fit
+ *                          of StandardScaler / MinMaxScaler, sygnals/core/ml_utils/scaling.py:108-118
+ *   syg_affine_cols_f32    out[r, c] = (x[r, c] - sub[c]) * mul[c] + add[c] (float64 arithmetic): every scaler's
+ *                          transform, scaling.py:118, 133
+ *   syg_col_quantiles_f32  out [nq, F] float64 = np.nanpercentile(x, 100 q, axis=0) (linear interpolation), q in
+ *                          [0, 1]; n <= 32768 -- RobustScaler's centre and scale, scaling.py:114
+ *   syg_zoom_f32           scipy.ndimage.zoom(img [H, W], order 0 | 1, mode='nearest') to [H2, W2] --
+ *                          format_features_as_image, sygnals/core/ml_utils/formatters.py:296-316
+ * ------------------------------------------------------------------------------- */
+int syg_col_stats_f32(const float* x, int64_t n, int64_t F, double* out, void* stream);
+int syg_affine_cols_f32(const float* x, int64_t n, int64_t F, const double* sub, const double* mul, const double* add,
+                        float* out, void* stream);
+int syg_col_quantiles_f32(const float* x, int64_t n, int64_t F, const double* q, int nq, double* out, void* stream);
+int syg_zoom_f32(const float* img, int H, int W, int H2, int W2, int order, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

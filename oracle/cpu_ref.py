@@ -16,7 +16,8 @@ PARITY STATUS
              dominant_frequency, the seven time-domain frame functions
              (mean/std/skewness/kurtosis/peak/crest/entropy), apply_convolution,
              compute_correlation, compute_autocorrelation, compute_psd_periodogram,
-             hilbert_transform, amplitude_envelope(hilbert)  -- checked against
+             hilbert_transform, amplitude_envelope(hilbert), apply_scaling,
+             format_feature_sequences, format_features_as_image  -- checked against
              tests/golden/ref_*.npz, which were produced by executing the
              reference's own functions.
   UNPINNED : stft, mel_filterbank, power_to_db, melspectrogram, mfcc,
@@ -911,6 +912,53 @@ def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=
             for i in range(C.shape[0]):
                 res[f"mfcc_{i}"] = C[i]
     return res
+
+
+# --------------------------------------------------------------------------
+# f-4  feature formatting for ML: scalers (core/ml_utils/scaling.py:49-175 -> scikit-learn) and the sequence /
+#      image formatters (core/ml_utils/formatters.py:166-334 -> NumPy, scipy.ndimage.zoom).  Where the reference
+#      calls scikit-learn / SciPy the same routine is called here; pinned on tests/golden/ref_ml.npz.
+# --------------------------------------------------------------------------
+def apply_scaling(features, scaler_type="standard", scaler_params=None):
+    """(scaled float64 array, dict of the fitted attributes) -- scaling.py:49-143 with fit=True."""
+    from sklearn.preprocessing import MinMaxScaler, RobustScaler, StandardScaler
+    X = np.asarray(features, dtype=np.float64)
+    if X.ndim == 1:
+        X = X.reshape(-1, 1)
+    cls = {"standard": StandardScaler, "minmax": MinMaxScaler, "robust": RobustScaler}[scaler_type]
+    sc = cls(**(scaler_params or {}))
+    out = sc.fit_transform(X)
+    attrs = {k: getattr(sc, k) for k in ("mean_", "var_", "scale_", "min_", "data_min_", "data_max_", "center_")
+             if getattr(sc, k, None) is not None}
+    return out.astype(np.float64), attrs
+
+
+def format_feature_sequences(features_dict, max_sequence_length=None, padding_value=0.0, truncation_strategy="post",
+                             output_format="list_of_arrays"):                    # formatters.py:166-253
+    names = list(features_dict.keys())
+    seq = np.stack([np.asarray(features_dict[k], dtype=np.float64) for k in names], axis=1)
+    n = seq.shape[0]
+    if max_sequence_length is not None and max_sequence_length > 0:
+        if n > max_sequence_length:
+            seq = seq[:max_sequence_length] if truncation_strategy == "post" else seq[n - max_sequence_length:]
+        elif n < max_sequence_length:
+            seq = np.pad(seq, ((0, max_sequence_length - n), (0, 0)), mode="constant", constant_values=padding_value)
+    return [seq] if output_format == "list_of_arrays" else seq[None]
+
+
+def format_features_as_image(feature_map, output_shape=None, resize_order=1, normalize=True):   # formatters.py:256-334
+    import scipy.ndimage
+    img = np.asarray(feature_map, dtype=np.float64)
+    if output_shape is not None and img.shape != tuple(output_shape):
+        img = scipy.ndimage.zoom(img, (output_shape[0] / img.shape[0], output_shape[1] / img.shape[1]),
+                                 order=resize_order, mode="nearest")
+        h, w = output_shape
+        img = img[:h, :w]
+        img = np.pad(img, ((0, h - img.shape[0]), (0, w - img.shape[1])), mode="constant")
+    if normalize:
+        lo, hi = np.min(img), np.max(img)
+        img = np.zeros_like(img) if hi - lo < EPS64 else (img - lo) / (hi - lo)
+    return img
 
 
 # --------------------------------------------------------------------------

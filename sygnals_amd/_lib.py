@@ -50,6 +50,10 @@ SIGNATURES = {
     "syg_analytic_mask_c64": (_i, [_p, _l, _l, _p]),
     "syg_psd_onesided_f32": (_i, [_p, _l, _l, _d, _p, _p]),
     "syg_col_mean_f32": (_i, [_p, _l, _l, _p, _i, _i, _d, _p, _p]),
+    "syg_col_stats_f32": (_i, [_p, _l, _l, _p, _p]),
+    "syg_affine_cols_f32": (_i, [_p, _l, _l, _p, _p, _p, _p, _p]),
+    "syg_col_quantiles_f32": (_i, [_p, _l, _l, _p, _i, _p, _p]),
+    "syg_zoom_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "syg_pcm_to_f32": (_i, [_p, _i, _l, _l, _i, _l, _p, _l, _p]),
 }
 

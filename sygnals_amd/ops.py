@@ -680,6 +680,61 @@ def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     return cmul(c[:, :n].contiguous(), w_out)
 
 
+# ------------------------------------------------------------------ feature formatting for ML (SURVEY 8 f-4)
+def _mat32(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda:
+        require_gpu()
+        raise ValueError("x must be a float32 [n, F] device tensor")
+    return x.contiguous()
+
+
+def col_stats(x: torch.Tensor) -> torch.Tensor:
+    """[5, F] float64: count of non-NaN, mean, population variance, min, max of every column of x [n, F]."""
+    x = _mat32(x)
+    n, F = x.shape
+    out = torch.empty((5, F), dtype=torch.float64, device=x.device)
+    check(lib().syg_col_stats_f32(_ptr(x), n, F, _ptr(out), C.c_void_p(_stream_ptr())), "syg_col_stats_f32")
+    return out
+
+
+def affine_cols(x: torch.Tensor, sub, mul, add) -> torch.Tensor:
+    """(x - sub[c]) * mul[c] + add[c] per column, float64 arithmetic; sub / mul / add: length-F float64 (host or device)."""
+    x = _mat32(x)
+    n, F = x.shape
+    vecs = [torch.as_tensor(np.asarray(v.cpu() if isinstance(v, torch.Tensor) else v, dtype=np.float64)).to(x.device)
+            for v in (sub, mul, add)]
+    if any(v.shape != (F,) for v in vecs):
+        raise ValueError(f"sub / mul / add must have length {F}")
+    out = torch.empty_like(x)
+    check(lib().syg_affine_cols_f32(_ptr(x), n, F, _ptr(vecs[0]), _ptr(vecs[1]), _ptr(vecs[2]), _ptr(out),
+                                    C.c_void_p(_stream_ptr())), "syg_affine_cols_f32")
+    return out
+
+
+def col_quantiles(x: torch.Tensor, q) -> torch.Tensor:
+    """np.nanpercentile(x, 100 * q, axis=0) -> [len(q), F] float64 (q: fractions in [0, 1]); at most 32768 rows."""
+    x = _mat32(x)
+    n, F = x.shape
+    qv = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    if qv.ndim != 1 or qv.size < 1 or (qv < 0).any() or (qv > 1).any():
+        raise ValueError("q must be fractions in [0, 1]")
+    qd = torch.from_numpy(qv).to(x.device)
+    out = torch.empty((qv.size, F), dtype=torch.float64, device=x.device)
+    check(lib().syg_col_quantiles_f32(_ptr(x), n, F, _ptr(qd), int(qv.size), _ptr(out), C.c_void_p(_stream_ptr())),
+          "syg_col_quantiles_f32")
+    return out
+
+
+def zoom2d(img: torch.Tensor, out_shape, order: int = 1) -> torch.Tensor:
+    """scipy.ndimage.zoom(img, out_shape / img.shape, order=0|1, mode='nearest') of a [H, W] float32 device tensor."""
+    img = _mat32(img)
+    H, W = img.shape
+    H2, W2 = int(out_shape[0]), int(out_shape[1])
+    out = torch.empty((H2, W2), dtype=torch.float32, device=img.device)
+    check(lib().syg_zoom_f32(_ptr(img), H, W, H2, W2, int(order), _ptr(out), C.c_void_p(_stream_ptr())), "syg_zoom_f32")
+    return out
+
+
 # ------------------------------------------------------------------ batched ingest (SURVEY 8 f-2)
 _PCM_BITS = {torch.int16: 16, torch.int32: 32, torch.uint8: 8}
 

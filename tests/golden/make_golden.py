@@ -10,6 +10,9 @@ What is executed: the SciPy/NumPy-backed functions of
                                                ref_dsp2.npz: apply_convolution, compute_correlation,
                                                compute_autocorrelation, compute_psd_periodogram,
                                                amplitude_envelope(method='hilbert'))
+  sygnals/core/ml_utils/{scaling,formatters}.py (apply_scaling and the three *_scale helpers, format_feature_sequences,
+                                               format_features_as_image; load as-is: scikit-learn, SciPy and pandas are
+                                               installed)
   sygnals/core/transforms.py                   (hilbert_transform; its top-level ``import pywt`` gets the same
                                                empty placeholder as librosa -- PyWavelets is not installed and no
                                                wavelet function is called)
@@ -222,6 +225,42 @@ def main():
         f, p = dsp.compute_psd_welch(ramp["c4096"], fs=48000.0, **kw)
         g[f"welch_any_{tag}_f"], g[f"welch_any_{tag}_p"] = f, p
     np.savez_compressed(os.path.join(OUT, "ref_dsp2.npz"), **g)
+    # ---- ml_utils: scalers and formatters (scikit-learn / scipy.ndimage behind the reference's functions) ----
+    REFML = "ml_utils"
+    sc = load("ref_scaling", os.path.join(REFML, "scaling.py"))
+    fm = load("ref_formatters", os.path.join(REFML, "formatters.py"))
+    rng3 = np.random.default_rng(20250525)
+    g = {}
+    X = rng3.normal(0, 1, (300, 6)) * np.array([1.0, 10.0, 0.01, 5.0, 1.0, 3.0]) + np.array([0.0, 100.0, -3.0, 0.0, 7.0, 1e3])
+    X[:, 4] = 7.0                                             # constant feature
+    X = X.astype(np.float32).astype(np.float64)               # float32-representable: the device sees the same values
+    g["X"] = X
+    for tag, kind, kw in (("std", "standard", {}), ("std_nomean", "standard", {"with_mean": False}),
+                          ("std_nostd", "standard", {"with_std": False}), ("mm", "minmax", {}),
+                          ("mm_m11", "minmax", {"feature_range": (-1, 1)}), ("rob", "robust", {}),
+                          ("rob_1090", "robust", {"quantile_range": (10.0, 90.0)}),
+                          ("rob_nocenter", "robust", {"with_centering": False})):
+        out, scaler = sc.apply_scaling(X, scaler_type=kind, scaler_params=kw)
+        g[f"scale_{tag}"] = out
+        for attr in ("mean_", "var_", "scale_", "min_", "center_"):
+            if getattr(scaler, attr, None) is not None:
+                g[f"scale_{tag}_{attr}"] = np.asarray(getattr(scaler, attr))
+    out, scaler = sc.standard_scale(X[:, 1])                  # 1-D input is reshaped to one column
+    g["scale_1d"] = out
+    feats = {f"f{i}": X[:40, i] for i in range(4)}
+    g["seq_list"] = fm.format_feature_sequences(feats)[0]
+    g["seq_pad64"] = fm.format_feature_sequences(feats, max_sequence_length=64, padding_value=-1.0, output_format="padded_array")
+    g["seq_cut16_post"] = fm.format_feature_sequences(feats, max_sequence_length=16, output_format="padded_array")
+    g["seq_cut16_pre"] = fm.format_feature_sequences(feats, max_sequence_length=16, truncation_strategy="pre",
+                                                     output_format="padded_array")
+    M = np.abs(rng3.normal(0, 1, (40, 94))).astype(np.float32).astype(np.float64) * np.linspace(3, 0.1, 40)[:, None]
+    g["img_in"] = M
+    g["img_norm"] = fm.format_features_as_image(M)
+    g["img_64x64"] = fm.format_features_as_image(M, output_shape=(64, 64))
+    g["img_20x200_nonorm"] = fm.format_features_as_image(M, output_shape=(20, 200), normalize=False)
+    g["img_128x32_nearest"] = fm.format_features_as_image(M, output_shape=(128, 32), resize_order=0)
+    g["img_const"] = fm.format_features_as_image(np.full((5, 7), 2.5))
+    np.savez_compressed(os.path.join(OUT, "ref_ml.npz"), **g)
     print("golden vectors written to", OUT)
 
 

@@ -1,0 +1,125 @@
+"""GPU parity of the ML formatting helpers: scalers (fit + transform on the device, a genuine
+scikit-learn scaler back), sequence stacking and the image formatter -- sygnals_amd.core.ml_utils -> ops ->
+libsygnals_hip.so (syg_col_stats_f32, syg_col_quantiles_f32, syg_affine_cols_f32, syg_zoom_f32).
+Pinned on tests/golden/ref_ml.npz (outputs of the reference's functions), then against scikit-learn / SciPy directly
+(the reference's own arithmetic) on random shapes with NaNs.  Tolerance 1e-5 of the output's peak."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from oracle import cpu_ref as O
+from tests.gpu_util import assert_parity
+from tests.test_oracle_golden import SCALER_CASES
+
+TOL = 1e-5
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gm():
+    from sygnals_amd import ops
+    ops.require_gpu()
+    return np.load(os.path.join(G, "ref_ml.npz"))
+
+
+@pytest.mark.parametrize("tag,kind,kw", SCALER_CASES)
+def test_scalers_vs_reference_golden(gm, tag, kind, kw):
+    from sygnals_amd.core.ml_utils import apply_scaling
+    X = gm["X"]
+    out, scaler = apply_scaling(X, scaler_type=kind, scaler_params=kw)
+    assert out.dtype == np.float64 and out.shape == X.shape
+    want = gm[f"scale_{tag}"]
+    for c in range(X.shape[1]):                       # per column: the features live on very different scales
+        assert_parity(out[:, c], want[:, c], TOL, f"{tag} column {c}")
+    for a in ("mean_", "var_", "scale_", "min_", "center_"):
+        if f"scale_{tag}_{a}" in gm.files:
+            np.testing.assert_allclose(getattr(scaler, a), gm[f"scale_{tag}_{a}"], rtol=2e-6, atol=1e-9, err_msg=a)
+    # the scaler that comes back is a working scikit-learn object: its own transform / inverse agree with the device
+    np.testing.assert_allclose(scaler.transform(X), want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+    np.testing.assert_allclose(scaler.inverse_transform(out), X, rtol=1e-4, atol=1e-4 * np.abs(X).max())
+    # and a fitted instance can be applied without fitting again (scaling.py:121-141)
+    out2, same = apply_scaling(X[:50], fit=False, scaler_instance=scaler)
+    assert same is scaler
+    np.testing.assert_allclose(out2, out[:50], rtol=0, atol=1e-6 * max(1.0, np.abs(out).max()))
+
+
+def test_scaling_helpers_errors_and_1d(gm):
+    from sygnals_amd.core.ml_utils import apply_scaling, minmax_scale, robust_scale, standard_scale
+    out, _ = standard_scale(gm["X"][:, 1])
+    assert out.shape == (300, 1)
+    assert_parity(out, gm["scale_1d"], TOL, "1-D input")
+    assert_parity(minmax_scale(gm["X"], (-1, 1))[0], gm["scale_mm_m11"], TOL, "minmax helper")
+    assert_parity(robust_scale(gm["X"], quantile_range=(10.0, 90.0))[0][:, 0], gm["scale_rob_1090"][:, 0], TOL, "robust helper")
+    with pytest.raises(ValueError, match="Unsupported scaler_type"):
+        apply_scaling(gm["X"], scaler_type="log")
+    with pytest.raises(ValueError, match="must be provided when `fit=False`"):
+        apply_scaling(gm["X"], fit=False)
+    with pytest.raises(ValueError, match="1D or 2D"):
+        apply_scaling(np.zeros((2, 2, 2)))
+    from sklearn.preprocessing import StandardScaler
+    with pytest.raises(ValueError, match="does not appear to be fitted"):
+        apply_scaling(gm["X"], fit=False, scaler_instance=StandardScaler())
+
+
+def test_scalers_with_nans_and_random_shapes_vs_sklearn():
+    from sygnals_amd.core.ml_utils import apply_scaling
+    rng = np.random.default_rng(3)
+    for n, F in ((1, 1), (2, 3), (65, 130), (1000, 7), (5000, 33), (32768, 2)):
+        X = (rng.normal(0, 1, (n, F)) * rng.uniform(0.1, 50, F) + rng.uniform(-20, 20, F)).astype(np.float32).astype(np.float64)
+        if n > 10:
+            X[rng.integers(0, n, n // 10), rng.integers(0, F, n // 10)] = np.nan      # NaN-padded frames (odd frame lengths)
+        for kind in ("standard", "minmax", "robust"):
+            out, _ = apply_scaling(X, kind)
+            want, _ = O.apply_scaling(X, kind)
+            assert np.array_equal(np.isnan(out), np.isnan(want))
+            for c in range(F):
+                m = ~np.isnan(want[:, c])
+                if m.any():
+                    pk = max(np.abs(want[m, c]).max(), 1e-30)
+                    assert np.abs(out[m, c] - want[m, c]).max() <= 2e-5 * pk + 1e-6, (kind, n, F, c)
+
+
+def test_sequences_and_images_vs_reference_golden(gm):
+    from sygnals_amd import ops
+    from sygnals_amd.core.ml_utils import format_feature_sequences, format_features_as_image
+    feats = {f"f{i}": gm["X"][:40, i] for i in range(4)}
+    assert np.array_equal(format_feature_sequences(feats)[0], gm["seq_list"])
+    assert np.array_equal(format_feature_sequences(feats, 64, -1.0, output_format="padded_array"), gm["seq_pad64"])
+    assert np.array_equal(format_feature_sequences(feats, 16, truncation_strategy="pre", output_format="padded_array"),
+                          gm["seq_cut16_pre"])
+    dev = {k: ops.to_device_f32(v) for k, v in feats.items()}                 # device tensors in -> device tensor out
+    seq = format_feature_sequences(dev, 64, -1.0, output_format="padded_array")
+    assert seq.is_cuda and np.array_equal(seq.cpu().numpy(), gm["seq_pad64"].astype(np.float32))
+    with pytest.raises(ValueError, match="same length"):
+        format_feature_sequences({"a": np.zeros(3), "b": np.zeros(4)})
+    assert format_feature_sequences({}) == []
+    M = gm["img_in"]
+    assert_parity(format_features_as_image(M), gm["img_norm"], TOL, "normalise")
+    assert_parity(format_features_as_image(M, output_shape=(64, 64)), gm["img_64x64"], TOL, "64x64 linear")
+    assert_parity(format_features_as_image(M, output_shape=(20, 200), normalize=False), gm["img_20x200_nonorm"], TOL, "20x200")
+    assert_parity(format_features_as_image(M, output_shape=(128, 32), resize_order=0), gm["img_128x32_nearest"], TOL, "nearest")
+    assert np.array_equal(format_features_as_image(np.full((5, 7), 2.5)), gm["img_const"])
+    with pytest.raises(ValueError, match="must be a 2D"):
+        format_features_as_image(np.zeros(5))
+    with pytest.raises(ValueError, match="two positive integers"):
+        format_features_as_image(M, output_shape=(0, 5))
+
+
+def test_zoom_random_shapes_vs_scipy():
+    from sygnals_amd.core.ml_utils import format_features_as_image
+    rng = np.random.default_rng(9)
+    for _ in range(25):
+        h, w, h2, w2 = (int(v) for v in rng.integers(1, 200, 4))
+        M = rng.normal(0, 1, (h, w)).astype(np.float32).astype(np.float64)
+        for order in (0, 1):
+            got = format_features_as_image(M, output_shape=(h2, w2), resize_order=order, normalize=False)
+            want = O.format_features_as_image(M, (h2, w2), order, False)
+            assert got.shape == (h2, w2)
+            if order == 1:
+                assert_parity(got, want, TOL, f"{h}x{w}->{h2}x{w2}")
+            else:       # nearest: identical picks except where the sampling point is within rounding of a half-way tie
+                assert (np.abs(got - want) > 1e-6).mean() < 0.02, (h, w, h2, w2)

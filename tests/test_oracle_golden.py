@@ -281,3 +281,39 @@ def test_welch_any_segment_length_matches_reference(g2, tag, kw):
     f, p = O.welch_explicit(g2["ramp_c4096"], fs=48000.0, **kw)
     np.testing.assert_allclose(f, g2[f"welch_any_{tag}_f"], rtol=0, atol=1e-6)
     _close(p, g2[f"welch_any_{tag}_p"], 1e-9)
+
+
+# ---------------------------------------------------------------- f-4: scalers and formatters (ref_ml.npz)
+SCALER_CASES = [("std", "standard", {}), ("std_nomean", "standard", {"with_mean": False}),
+                ("std_nostd", "standard", {"with_std": False}), ("mm", "minmax", {}),
+                ("mm_m11", "minmax", {"feature_range": (-1, 1)}), ("rob", "robust", {}),
+                ("rob_1090", "robust", {"quantile_range": (10.0, 90.0)}), ("rob_nocenter", "robust", {"with_centering": False})]
+
+
+@pytest.fixture(scope="module")
+def gm():
+    return np.load(os.path.join(G, "ref_ml.npz"))
+
+
+@pytest.mark.parametrize("tag,kind,kw", SCALER_CASES)
+def test_scalers_match_reference(gm, tag, kind, kw):
+    out, attrs = O.apply_scaling(gm["X"], kind, kw)
+    assert_allclose(out, gm[f"scale_{tag}"], rtol=1e-12, atol=1e-12)
+    for a in ("mean_", "var_", "scale_", "min_", "center_"):
+        if f"scale_{tag}_{a}" in gm.files:
+            assert_allclose(attrs[a], gm[f"scale_{tag}_{a}"], rtol=1e-12, atol=1e-12)
+
+
+def test_formatters_match_reference(gm):
+    feats = {f"f{i}": gm["X"][:40, i] for i in range(4)}
+    assert_array_equal(O.format_feature_sequences(feats)[0], gm["seq_list"])
+    assert_array_equal(O.format_feature_sequences(feats, 64, -1.0, output_format="padded_array"), gm["seq_pad64"])
+    assert_array_equal(O.format_feature_sequences(feats, 16, output_format="padded_array"), gm["seq_cut16_post"])
+    assert_array_equal(O.format_feature_sequences(feats, 16, truncation_strategy="pre", output_format="padded_array"),
+                       gm["seq_cut16_pre"])
+    M = gm["img_in"]
+    assert_allclose(O.format_features_as_image(M), gm["img_norm"], rtol=0, atol=1e-15)
+    assert_allclose(O.format_features_as_image(M, (64, 64)), gm["img_64x64"], rtol=0, atol=1e-15)
+    assert_allclose(O.format_features_as_image(M, (20, 200), normalize=False), gm["img_20x200_nonorm"], rtol=0, atol=1e-15)
+    assert_allclose(O.format_features_as_image(M, (128, 32), resize_order=0), gm["img_128x32_nearest"], rtol=0, atol=1e-15)
+    assert_array_equal(O.format_features_as_image(np.full((5, 7), 2.5)), gm["img_const"])
