@@ -53,6 +53,7 @@ __global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restri
       const int r = c - 2 * q;                               // 0 or 1
       const float* src = (r ? O : E) + (int)(n0 - mbase) + q + tid;
       const float h = hs[j];
+      if (h == 0.f) continue;        // half-band filters: every other tap beside the centre is zero (wave-uniform skip)
 #pragma unroll
       for (int o = 0; o < DEC_OUTS; ++o) acc[o] = fmaf(h, src[o * DEC_NT], acc[o]);
     }
