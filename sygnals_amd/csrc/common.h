@@ -87,6 +87,16 @@ __device__ __forceinline__ void dft8(float2 (&a)[8]) {
   a[3] = cadd(e3, t3); a[7] = csub(e3, t3);
 }
 
+// Lanes of one wave exchange data through LDS without a workgroup barrier (the LDS executes a wave's
+// DS instructions in order).  To the COMPILER that is a data race: it may assume a lane that did not store
+// re-reads unchanged memory.  This wavefront-scope release/acquire pair emits no instruction but makes every
+// later LDS read observe the stores of the other lanes.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stockham autosort FFT of N = 2^m complex points in LDS (ping-pong buffers x, y; N >= 2), shared by the generic
 // FFT / STFT / Welch kernels (a workgroup of `nt` threads) and the CQT (one wave, nt = 64 -- its callers keep
@@ -99,8 +109,12 @@ __device__ __forceinline__ void dft8(float2 (&a)[8]) {
 // Returns the buffer that holds the result.
 __device__ __forceinline__ int fft_swz(int i, bool on) { return on ? (i ^ ((i >> 4) & 15)) : i; }
 
+// WAVE: the transform belongs to ONE wave (nt = 64, buffers of its own): the passes are ordered by the wave itself
+// (wave_lds_sync) instead of a workgroup barrier that would tie independent transforms of other waves together.
+template <bool WAVE = false>
 __device__ __forceinline__ float2* block_fft(float2* x, float2* y, int N, const float2* __restrict__ tw, int tid,
                                              int nt) {
+  auto pass_sync = [] { if (WAVE) wave_lds_sync(); else __syncthreads(); };
   int lN = 0;
   while ((1 << lN) < N) ++lN;
   const int n8 = lN / 3, tail = lN - 3 * n8;          // radix-8 passes, then a radix-4 (tail 2) or radix-2 (tail 1)
@@ -130,7 +144,7 @@ __device__ __forceinline__ float2* block_fft(float2* x, float2* y, int N, const 
       y[fft_swz(ob + (6 << ls), sout)] = cmul(a[6], w6);
       y[fft_swz(ob + (7 << ls), sout)] = cmul(a[7], w7);
     }
-    __syncthreads();
+    pass_sync();
     float2* t = x; x = y; y = t;
     ls += 3;
   }
@@ -143,7 +157,7 @@ __device__ __forceinline__ float2* block_fft(float2* x, float2* y, int N, const 
             o2, o3);
       y[i] = o0; y[i + s] = o1; y[i + 2 * s] = o2; y[i + 3 * s] = o3;
     }
-    __syncthreads();
+    pass_sync();
     float2* t = x; x = y; y = t;
   } else if (tail == 1) {
     const bool sin = pass > 0;
@@ -153,20 +167,10 @@ __device__ __forceinline__ float2* block_fft(float2* x, float2* y, int N, const 
       y[i] = cadd(a, b);
       y[i + s] = csub(a, b);
     }
-    __syncthreads();
+    pass_sync();
     float2* t = x; x = y; y = t;
   }
   return x;
-}
-
-// Lanes of one wave exchange data through LDS without a workgroup barrier (the LDS executes a wave's
-// DS instructions in order).  To the COMPILER that is a data race: it may assume a lane that did not store
-// re-reads unchanged memory.  This wavefront-scope release/acquire pair emits no instruction but makes every
-// later LDS read observe the stores of the other lanes.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ---------------------------------------------------------------------------------------------

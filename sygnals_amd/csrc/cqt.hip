@@ -99,7 +99,7 @@ __global__ __launch_bounds__(FPW * 64) void cqt_octave_kernel(
     xa[m] = make_float2(a, c);
   }
   __syncthreads();
-  float2* Z = block_fft(xa, xb, M, tw + n_fft, lane, 64);   // one wave per frame; all waves run the same trip counts
+  float2* Z = block_fft<true>(xa, xb, M, tw + n_fft, lane, 64);   // one wave per frame, ordered by the wave itself
   for (int k = lane; k <= M; k += 64) {
     const float2 zk = Z[k & (M - 1)], zm = Z[(M - k) & (M - 1)];
     const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(FPW * 64) void cqt_octave_kernel(
     const float2 wO = cmul(tw[k], O);
     X[k] = make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
   }
-  __syncthreads();
+  wave_lds_sync();
   // n_filt sparse complex dot products: each 16-lane row of the wave takes one filter at a time (filter f -> row
   // f & 3 of pass f >> 2) and walks only the filter's non-zero bin run; the row sum is four DPP steps.
   const int row = lane >> 4, l16 = lane & 15;
