@@ -141,6 +141,16 @@ int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t outer, int
                                  int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale,
                                  void* stream);
 
+/* The same for lengths n = 2^a 3^b 5^c 7^d <= 8192 (mixed-radix Stockham: one second of audio at 48 / 44.1 / 16 kHz is
+ * such a length, none a power of two); twiddle [n] = W_n^k.  syg_fft_mixed_plan returns the number of passes (0: n has
+ * another prime factor -> Bluestein) and, if radices_host is given, their radices.  Longer 7-smooth lengths are
+ * composed four-step from two such transforms by the caller, exactly like the power-of-two case. */
+int syg_fft_mixed_plan(int64_t n, int32_t* radices_host, int max_passes);
+int syg_fft_mixed_strided_c2c_f32(const float* in, float* out, int64_t outer, int64_t batch, int n, int inverse,
+                                  const float* twiddle, int64_t in_os, int64_t in_bs, int64_t in_es,
+                                  int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale,
+                                  void* stream);
+
 /* out[i] = a[i] * b[i mod nb] (complex64; conj_b != 0 multiplies by conj(b)); may be in place. */
 int syg_cmul_c64(const float* a, const float* b, float* out, int64_t na, int64_t nb, int conj_b, void* stream);
 

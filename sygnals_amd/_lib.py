@@ -50,6 +50,8 @@ SIGNATURES = {
     "syg_analytic_mask_c64": (_i, [_p, _l, _l, _p]),
     "syg_psd_onesided_f32": (_i, [_p, _l, _l, _d, _p, _p]),
     "syg_col_mean_f32": (_i, [_p, _l, _l, _p, _i, _i, _d, _p, _p]),
+    "syg_fft_mixed_plan": (_i, [_l, _p, _i]),
+    "syg_fft_mixed_strided_c2c_f32": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _l, _l, _l, _l, _l, _l, _f, _p]),
     "syg_col_stats_f32": (_i, [_p, _l, _l, _p, _p]),
     "syg_affine_cols_f32": (_i, [_p, _l, _l, _p, _p, _p, _p, _p]),
     "syg_col_quantiles_f32": (_i, [_p, _l, _l, _p, _i, _p, _p]),

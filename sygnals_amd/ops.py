@@ -662,14 +662,74 @@ def _bluestein_tables(n: int):
     return m, fwd, inv
 
 
+MAX_MIXED_FFT = 8192
+
+
+def smooth_split(n: int):
+    """None when n has a prime factor other than 2, 3, 5, 7 (or is too long); (n, 1) when one mixed-radix launch
+    takes it; else the most balanced (n1, n2), n1 * n2 = n, both <= 8192 -- the four-step factors."""
+    if n < 2 or not _is_smooth(n):
+        return None
+    if n <= MAX_MIXED_FFT:
+        return n, 1
+    best = None
+    d = 1
+    while d * d <= n:
+        if n % d == 0 and n // d <= MAX_MIXED_FFT:
+            best = (d, n // d)                       # d <= sqrt(n): the largest such d is the most balanced split
+        d += 1
+    return best
+
+
+def _is_smooth(n: int) -> bool:
+    for p in (2, 3, 5, 7):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+def _fft_mixed_strided(x, out, outer, batch, n, inverse, strides, bign=0, scale=1.0):
+    in_os, in_bs, in_es, out_os, out_bs, out_es = strides
+    rc = lib().syg_fft_mixed_strided_c2c_f32(_ptr(x), _ptr(out), outer, batch, n, int(inverse), _ptr(twiddle_dev(n)),
+                                             in_os, in_bs, in_es, out_os, out_bs, out_es, bign, float(scale),
+                                             C.c_void_p(_stream_ptr()))
+    check(rc, "syg_fft_mixed_strided_c2c_f32")
+
+
+def fft_smooth(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """Complex FFT of rows of x [rows, n, 2] for n = 2^a 3^b 5^c 7^d: one mixed-radix launch up to 8192 points,
+    four-step (two passes of mixed-radix transforms) above."""
+    rows, n, _ = x.shape
+    split = smooth_split(n)
+    if split is None:
+        raise SygnalsHipError(f"fft_smooth: n = {n} is not a product of 2, 3, 5, 7 that splits into factors <= 8192")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    n1, n2 = split
+    if n2 == 1:
+        _fft_mixed_strided(x, out, 1, rows, n, inverse, (0, n, 1, 0, n, 1), scale=(1.0 / n if inverse else 1.0))
+        return out
+    if rows > MAX_ROWS:
+        raise SygnalsHipError("too many rows for the four-step FFT")
+    tmp = torch.empty_like(x)
+    # step A: n2 transforms of length n1 over the slow index (stride n2), twiddle W_n^(i2 k1), stored [i2][k1];
+    # step B: n1 transforms of length n2 over i2 (stride n1), output X[k1 + n1 k2]
+    _fft_mixed_strided(x, tmp, rows, n2, n1, inverse, (n, 1, n2, n, n1, 1), bign=n)
+    _fft_mixed_strided(tmp, out, rows, n1, n2, inverse, (n, 1, n1, n, 1, n1), scale=(1.0 / n if inverse else 1.0))
+    return out
+
+
 def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
-    """Complex FFT / IFFT of rows of x [rows, n, 2] for ANY n >= 1 (Bluestein when n is not a power of two)."""
+    """Complex FFT / IFFT of rows of x [rows, n, 2] for ANY n >= 1: LDS / four-step kernels for powers of two, the
+    mixed-radix kernel for other products of 2, 3, 5, 7 (48000, 44100, 16000 ...), Bluestein for the rest."""
     require_gpu()
     rows, n, _ = x.shape
     if n == 1:
         return x.clone()
     if is_pow2(n):
         return fft_pow2_any(x, inverse)
+    if _is_smooth(n) and smooth_split(n) is not None and (n <= MAX_MIXED_FFT or rows <= MAX_ROWS):
+        return fft_smooth(x, inverse)
     m, fwd, inv = _cached(("blue", n), lambda: _bluestein_tables(n))
     w_in, bf, w_out = inv if inverse else fwd
     a = torch.zeros((rows, m, 2), dtype=torch.float32, device=x.device)

@@ -354,3 +354,41 @@ def test_extract_features_with_odd_frame_length():
     assert len(want["spectral_centroid"]) == T - 1 and np.isnan(got["spectral_centroid"][-1]) and np.isnan(got["mfcc_3"][-1])
     assert_parity(got["spectral_centroid"][:-1], want["spectral_centroid"], TOL, "odd centroid")
     assert_parity(got["mfcc_3"][:-1], want["mfcc_3"], TOL, "odd mfcc")
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 6, 7, 10, 12, 15, 21, 30, 35, 49, 100, 105, 240, 375, 441, 1000, 1500, 2401, 3000,
+                               4410, 5000, 7000, 7680, 8000])
+def test_mixed_radix_fft_vs_numpy(n):
+    """Lengths 2^a 3^b 5^c 7^d up to 8192: one mixed-radix launch (syg_fft_mixed_strided_c2c_f32), forward and inverse."""
+    from sygnals_amd import ops
+    rng = np.random.default_rng(n)
+    z = (rng.normal(0, 1, (3, n)) + 1j * rng.normal(0, 1, (3, n))).astype(np.complex64)
+    x = torch.from_numpy(np.stack([z.real, z.imag], axis=-1)).cuda()
+    assert ops.smooth_split(n) == (n, 1)
+    for inverse, ref in ((False, np.fft.fft(z.astype(np.complex128), axis=1)), (True, np.fft.ifft(z.astype(np.complex128), axis=1))):
+        got = ops.fft_any(x, inverse).cpu().numpy().astype(np.float64)
+        assert peak_rel(got[..., 0] + 1j * got[..., 1], ref) <= TOL, (n, inverse)
+
+
+@pytest.mark.parametrize("n", [16000, 22050, 44100, 48000, 96000, 1000000, 8192 * 8192 // 64 * 3])
+def test_long_smooth_fft_vs_numpy(n):
+    """One second of audio at the usual rates, 10^6 and 3 * 2^20 points: four-step over two mixed-radix passes (no
+    Bluestein); compute_fft's default n = len(data) lands here."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.dsp import compute_fft, compute_ifft
+    assert ops.smooth_split(n) is not None and not ops.is_pow2(n)
+    rng = np.random.default_rng(n % 1000)
+    y = rng.normal(0, 0.3, n)
+    f, s = compute_fft(y, fs=float(n), window=None)
+    ref = np.fft.fft(y.astype(np.float32).astype(np.float64))
+    assert peak_rel(s, ref) <= TOL
+    back = compute_ifft(s)
+    assert_parity(back, y, 2 * TOL, "round trip")
+
+
+def test_smooth_split_rules():
+    from sygnals_amd import ops
+    assert ops.smooth_split(48000) == (200, 240) and ops.smooth_split(44100) == (210, 210)
+    assert ops.smooth_split(8192) == (8192, 1) and ops.smooth_split(2 * 8192) == (128, 128)
+    assert ops.smooth_split(11) is None and ops.smooth_split(48000 * 11) is None
+    assert ops.smooth_split(7 ** 9) is None                      # smooth, but no split into two factors <= 8192

@@ -48,6 +48,10 @@ report("f-1 time-domain frame features (9 rows), 1024 clips", timeit(lambda: ops
 # a10: batched FFT
 xf = torch.randn((4096, 4096, 2), dtype=torch.float32, device=y.device)
 report("a10 complex FFT n=4096 x 4096 signals", timeit(lambda: ops.fft_pow2(xf)), 4096 * 4096, 2 * 8 * 4096 * 4096)
+x48 = torch.randn((1024, 48000, 2), dtype=torch.float32, device=y.device)
+report("a10 complex FFT n=48000 (2^7 3 5^3) x 1024 signals", timeit(lambda: ops.fft_any(x48), 10, 3), 1024 * 48000, 2 * 8 * 1024 * 48000)
+x6k = torch.randn((8192, 6000, 2), dtype=torch.float32, device=y.device)
+report("a10 complex FFT n=6000 (2^4 3 5^3) x 8192 signals", timeit(lambda: ops.fft_any(x6k), 10, 3), 8192 * 6000, 2 * 8 * 8192 * 6000)
 # C5: one 1-hour stream per GPU (here 10 minutes to bound the run; rates are per sample)
 Ls = 48000 * 600
 t = torch.arange(Ls, device=y.device, dtype=torch.float32) / SR
@@ -60,6 +64,6 @@ report("f-3 convolution, 1023-tap shared kernel, mode=same, 1024 clips", timeit(
 report("f-3 autocorrelation (full), 1024 clips", timeit(lambda: D.convolve_batch(y, y, "full", correlate=True)), B * L, B * (4 * L + 4 * (2 * L - 1)))
 y65 = torch.randn((1024, 65536), dtype=torch.float32, device=y.device)
 report("f-3 Hilbert envelope, 1024 rows x 65536", timeit(lambda: ops.cabs_pow(D.analytic_batch(y65), 1)), 1024 * 65536, 1024 * 8 * 65536)
-report("f-3 Hilbert envelope, 1024 clips x 48000 (Bluestein)", timeit(lambda: ops.cabs_pow(D.analytic_batch(y), 1), 5, 2), B * L, B * 8 * L)
-report("f-3 periodogram, 1024 clips x 48000 (Bluestein)", timeit(lambda: D.periodogram_batch(y, fs=SR), 5, 2), B * L, B * (4 * L + 4 * (L // 2 + 1)))
+report("f-3 Hilbert envelope, 1024 clips x 48000 (mixed radix 200 x 240)", timeit(lambda: ops.cabs_pow(D.analytic_batch(y), 1), 5, 2), B * L, B * 8 * L)
+report("f-3 periodogram, 1024 clips x 48000 (mixed radix 200 x 240)", timeit(lambda: D.periodogram_batch(y, fs=SR), 5, 2), B * L, B * (4 * L + 4 * (L // 2 + 1)))
 json.dump(rows, open("gpurun_out/rows_r01.json", "w"), indent=1)
