@@ -264,7 +264,7 @@ int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_
  *                           syg_pack_rows_work_bytes(rows) bytes); cplx != 0 writes complex rows (value, 0).
  *                           A real row of n floats is at the same time the packed row z[m] = x[2m] + i x[2m+1]
  *                           of n/2 complex elements consumed by syg_rconv_spectrum_c64.
- *   syg_rconv_spectrum_c64  za [rows, H], zb [rows_b (1 or rows), H]: length-H complex FFTs of two packed real
+ *   syg_rconv_spectrum_c64  za [rows, H], zb [rows_b (1 or rows), H] (any H >= 2): length-H complex FFTs of two packed real
  *                           rows of 2H samples -> out [rows, H] (may alias za): the packed transform of their
  *                           circular convolution; its inverse length-H FFT, read as 2H floats, is the real
  *                           result.  scipy.signal.fftconvolve / correlate as called at sygnals/core/dsp.py:333,

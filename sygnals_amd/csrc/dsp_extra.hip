@@ -209,7 +209,7 @@ extern "C" int syg_rconv_spectrum_c64(const float* za, const float* zb, int64_t 
                                       float* out, void* stream) {
   SYG_REQUIRE(za && zb && out, "rconv_spectrum: null pointer argument");
   SYG_REQUIRE(rows >= 1 && rows <= 65535 && (rows_b == 1 || rows_b == rows), "rconv_spectrum: bad row counts");
-  SYG_REQUIRE(H >= 2 && (H & (H - 1)) == 0, "rconv_spectrum: H must be a power of two >= 2");
+  SYG_REQUIRE(H >= 2, "rconv_spectrum: H must be >= 2");
   hipLaunchKernelGGL(rconv_spectrum_kernel, dim3(grid_x(H / 2 + 1, rows), (unsigned)rows), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)za, (const float2*)zb, rows_b, H, (float2*)out);
   SYG_CHECK_LAUNCH("rconv_spectrum");

@@ -841,11 +841,15 @@ def pack_rows(x: torch.Tensor, n: int, window: Optional[torch.Tensor] = None, de
 
 
 def conv_fft_len(n_out: int) -> int:
-    """Power-of-two transform length (in real samples) for a linear convolution with n_out output samples."""
-    m = 16
-    while m < n_out:
-        m <<= 1
-    return m
+    """Transform length (in real samples, even) for a linear convolution with n_out output samples: the smallest
+    M >= n_out, M >= 16, whose half M/2 is a product of 2, 3, 5, 7 that the FFT kernels take directly -- what
+    scipy.fft.next_fast_len does for fftconvolve.  (A power of two can be up to twice the needed length.)"""
+    m = max(16, n_out + (n_out & 1))
+    while True:
+        h = m // 2
+        if is_pow2(h) or (_is_smooth(h) and smooth_split(h) is not None):
+            return m
+        m += 2
 
 
 def rfft_conv(x: torch.Tensor, k: torch.Tensor, reverse_k: bool = False) -> torch.Tensor:
@@ -857,11 +861,11 @@ def rfft_conv(x: torch.Tensor, k: torch.Tensor, reverse_k: bool = False) -> torc
         raise ValueError("k must have one row or one row per row of x")
     M = conv_fft_len(n + m - 1)
     H = M // 2
-    za = fft_pow2_any(pack_rows(x, M).view(B, H, 2))
-    zb = fft_pow2_any(pack_rows(k, M, reverse=reverse_k).view(Bk, H, 2))
+    za = fft_any(pack_rows(x, M).view(B, H, 2))
+    zb = fft_any(pack_rows(k, M, reverse=reverse_k).view(Bk, H, 2))
     rc = lib().syg_rconv_spectrum_c64(_ptr(za), _ptr(zb), B, Bk, H, _ptr(za), C.c_void_p(_stream_ptr()))
     check(rc, "syg_rconv_spectrum_c64")
-    return fft_pow2_any(za, True).view(B, M)[:, : n + m - 1]
+    return fft_any(za, True).view(B, M)[:, : n + m - 1]
 
 
 def analytic_signal(x: torch.Tensor) -> torch.Tensor:
