@@ -644,9 +644,9 @@ def _bluestein_tables(n: int):
     w[k] = exp(-i*pi*k^2/n); forward: X = w * IFFT_M(FFT_M(x*w) * FFT_M(wrap(conj w)));
     the inverse uses the conjugate chirp and folds the 1/n into the final multiply.
     """
-    m = 1
-    while m < 2 * n - 1:
-        m <<= 1
+    m = max(2, 2 * n - 1)                      # any length the FFT kernels take directly will do for the chirp
+    while not (is_pow2(m) or (_is_smooth(m) and smooth_split(m) is not None)):   # convolution: the next 7-smooth one
+        m += 1
     k = np.arange(n, dtype=np.int64)
     w = np.exp(-1j * np.pi * ((k * k) % (2 * n)).astype(np.float64) / n)
 
@@ -734,9 +734,9 @@ def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     w_in, bf, w_out = inv if inverse else fwd
     a = torch.zeros((rows, m, 2), dtype=torch.float32, device=x.device)
     a[:, :n].copy_(cmul(x, w_in))                 # zero-padded copy (data movement)
-    A = fft_pow2_any(a, False)
+    A = fft_any(a, False)
     cmul(A, bf, out=A)
-    c = fft_pow2_any(A, True)
+    c = fft_any(A, True)
     return cmul(c[:, :n].contiguous(), w_out)
 
 

@@ -392,3 +392,17 @@ def test_smooth_split_rules():
     assert ops.smooth_split(8192) == (8192, 1) and ops.smooth_split(2 * 8192) == (128, 128)
     assert ops.smooth_split(11) is None and ops.smooth_split(48000 * 11) is None
     assert ops.smooth_split(7 ** 9) is None                      # smooth, but no split into two factors <= 8192
+
+
+@pytest.mark.parametrize("n", [11, 13, 17, 97, 1009, 4099, 9973, 47999, 65537])
+def test_fft_prime_lengths_bluestein(n):
+    """Lengths with a prime factor above 7: chirp-z over the next 7-smooth transform length."""
+    from sygnals_amd import ops
+    rng = np.random.default_rng(n)
+    z = (rng.normal(0, 1, (2, n)) + 1j * rng.normal(0, 1, (2, n))).astype(np.complex64)
+    x = torch.from_numpy(np.stack([z.real, z.imag], axis=-1)).cuda()
+    assert ops.smooth_split(n) is None
+    got = ops.fft_any(x).cpu().numpy().astype(np.float64)
+    assert peak_rel(got[..., 0] + 1j * got[..., 1], np.fft.fft(z.astype(np.complex128), axis=1)) <= TOL
+    got = ops.fft_any(x, True).cpu().numpy().astype(np.float64)
+    assert peak_rel(got[..., 0] + 1j * got[..., 1], np.fft.ifft(z.astype(np.complex128), axis=1)) <= TOL
