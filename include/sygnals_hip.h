@@ -282,6 +282,11 @@ int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_
 int64_t syg_pack_rows_work_bytes(int64_t rows);
 int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window, int detrend,
                       int reverse, int cplx, float* out, int64_t n, void* work, void* stream);
+/* syg_pack_rows_f32 for the frames of several clips at once: row r starts at
+ * x + (r / rows_per_group) * group_stride + (r % rows_per_group) * ldx  (rows_per_group = 0: x + r * ldx). */
+int syg_pack_frames_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, int64_t rows_per_group,
+                        int64_t group_stride, const float* window, int detrend, int reverse, int cplx, float* out,
+                        int64_t n, void* work, void* stream);
 int syg_rconv_spectrum_c64(const float* za, const float* zb, int64_t rows, int64_t rows_b, int64_t H, float* out,
                            void* stream);
 int syg_analytic_mask_c64(float* X, int64_t rows, int64_t n, void* stream);

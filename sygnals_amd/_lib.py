@@ -46,6 +46,7 @@ SIGNATURES = {
     "syg_welch_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _p, _p, _i, _d, _p, _p, _p]),
     "syg_pack_rows_work_bytes": (_l, [_l]),
     "syg_pack_rows_f32": (_i, [_p, _l, _l, _l, _p, _i, _i, _i, _p, _l, _p, _p]),
+    "syg_pack_frames_f32": (_i, [_p, _l, _l, _l, _l, _l, _p, _i, _i, _i, _p, _l, _p, _p]),
     "syg_rconv_spectrum_c64": (_i, [_p, _p, _l, _l, _l, _p, _p]),
     "syg_analytic_mask_c64": (_i, [_p, _l, _l, _p]),
     "syg_psd_onesided_f32": (_i, [_p, _l, _l, _d, _p, _p]),

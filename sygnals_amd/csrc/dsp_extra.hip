@@ -21,16 +21,25 @@ constexpr int SUMCH = 64;         // partial sums per row for the mean (detrend=
 
 // part[r, c] = float64 sum of chunk c of row r;  part[rows * SUMCH + r * SUMCH + c] = the same of (i - (len-1)/2) x[i]
 // (the moment the least-squares line needs; centred so that slope and mean decouple)
-__global__ void row_sum_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, int linear,
-                               double* __restrict__ part, int64_t rows) {
+// Row r starts at x + (r / grp) * gstride + (r % grp) * ldx when grp > 0 (frames of several clips: grp frames per
+// clip, clip stride gstride), else at x + r * ldx.
+__device__ __forceinline__ const float* row_base(const float* x, int64_t r, int64_t ldx, int64_t grp, int64_t gstride) {
+  if (grp <= 0) return x + r * ldx;
+  const int64_t g = r / grp;
+  return x + g * gstride + (r - g * grp) * ldx;
+}
+
+__global__ void row_sum_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, int64_t grp, int64_t gstride,
+                               int linear, double* __restrict__ part, int64_t rows) {
   __shared__ double red[8];
   const int64_t r = blockIdx.y;
+  const float* xr = row_base(x, r, ldx, grp, gstride);
   const int64_t per = (len + SUMCH - 1) / SUMCH;
   const int64_t lo = blockIdx.x * per, hi = lo + per < len ? lo + per : len;
   const double jc = 0.5 * (double)(len - 1);
   double s = 0.0, sj = 0.0;
   for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const double v = (double)x[r * ldx + i];
+    const double v = (double)xr[i];
     s += v;
     if (linear) sj += ((double)i - jc) * v;
   }
@@ -48,9 +57,9 @@ __global__ void row_sum_kernel(const float* __restrict__ x, int64_t len, int64_t
 // trend: nothing, the row mean, or the least-squares line mean + slope (j - (len-1)/2) (scipy.signal.detrend).
 // CPLX: out rows are complex (value, 0); otherwise real rows of n floats.
 template <bool CPLX>
-__global__ void pack_rows_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, const float* __restrict__ win,
-                                 const double* __restrict__ part, int linear, int64_t rows, int reverse,
-                                 float* __restrict__ out, int64_t n) {
+__global__ void pack_rows_kernel(const float* __restrict__ x, int64_t len, int64_t ldx, int64_t grp, int64_t gstride,
+                                 const float* __restrict__ win, const double* __restrict__ part, int linear,
+                                 int64_t rows, int reverse, float* __restrict__ out, int64_t n) {
   __shared__ double mean_s, slope_s;
   const int64_t r = blockIdx.y;
   double mean = 0.0, slope = 0.0;
@@ -69,7 +78,7 @@ __global__ void pack_rows_kernel(const float* __restrict__ x, int64_t len, int64
     __syncthreads();
     mean = mean_s; slope = slope_s;
   }
-  const float* xr = x + r * ldx;
+  const float* xr = row_base(x, r, ldx, grp, gstride);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
     if (i < len) {
@@ -178,12 +187,13 @@ using namespace syg;
 
 extern "C" int64_t syg_pack_rows_work_bytes(int64_t rows) { return 2 * rows * SUMCH * (int64_t)sizeof(double); }
 
-extern "C" int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window,
-                                 int detrend, int reverse, int cplx, float* out, int64_t n, void* work,
-                                 void* stream) {
+extern "C" int syg_pack_frames_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, int64_t rows_per_group,
+                                   int64_t group_stride, const float* window, int detrend, int reverse, int cplx,
+                                   float* out, int64_t n, void* work, void* stream) {
   SYG_REQUIRE(x && out, "pack_rows: null pointer argument");
   // ldx < len is allowed: overlapping rows (frames of one signal, row stride = hop)
   SYG_REQUIRE(rows >= 1 && rows <= 65535 && len >= 1 && n >= 1 && ldx >= 1, "pack_rows: bad sizes");
+  SYG_REQUIRE(rows_per_group >= 0 && (rows_per_group == 0 || group_stride >= 1), "pack_rows: bad row grouping");
   SYG_REQUIRE(detrend >= 0 && detrend <= 2, "pack_rows: detrend must be 0 (none), 1 (constant) or 2 (linear)");
   SYG_REQUIRE(!detrend || work, "pack_rows: detrend needs the work buffer (syg_pack_rows_work_bytes)");
   if (len > n) len = n;
@@ -191,18 +201,24 @@ extern "C" int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int6
   if (detrend) {
     part = (double*)work;
     hipLaunchKernelGGL(row_sum_kernel, dim3(SUMCH, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, len, ldx,
-                       detrend == 2, part, rows);
+                       rows_per_group, group_stride, detrend == 2, part, rows);
     SYG_CHECK_LAUNCH("pack_rows(sum)");
   }
   const dim3 grid(grid_x(n, rows), (unsigned)rows);
   if (cplx)
-    hipLaunchKernelGGL(pack_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, len, ldx, window, part,
-                       detrend == 2, rows, reverse, out, n);
+    hipLaunchKernelGGL(pack_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, len, ldx, rows_per_group,
+                       group_stride, window, part, detrend == 2, rows, reverse, out, n);
   else
-    hipLaunchKernelGGL(pack_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, len, ldx, window, part,
-                       detrend == 2, rows, reverse, out, n);
+    hipLaunchKernelGGL(pack_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, len, ldx, rows_per_group,
+                       group_stride, window, part, detrend == 2, rows, reverse, out, n);
   SYG_CHECK_LAUNCH("pack_rows");
   return SYG_OK;
+}
+
+extern "C" int syg_pack_rows_f32(const float* x, int64_t rows, int64_t len, int64_t ldx, const float* window,
+                                 int detrend, int reverse, int cplx, float* out, int64_t n, void* work,
+                                 void* stream) {
+  return syg_pack_frames_f32(x, rows, len, ldx, 0, 0, window, detrend, reverse, cplx, out, n, work, stream);
 }
 
 extern "C" int syg_rconv_spectrum_c64(const float* za, const float* zb, int64_t rows, int64_t rows_b, int64_t H,

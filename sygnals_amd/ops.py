@@ -368,10 +368,21 @@ def stft_any(y, n_fft, hop, center=True, window="hann", win_length=None):
 MAX_ROWS = 65535
 
 
-def frame_rows(sig: torch.Tensor, n: int, step: int, count: int, first: int = 0) -> torch.Tensor:
-    """`count` overlapping rows of length n of the contiguous 1-D device tensor `sig`, row r starting at sample
-    (first + r) * step -- a strided VIEW (no copy) for syg_pack_rows_f32, whose row stride may be below the row length."""
-    return sig.as_strided((count, n), (step, 1), sig.storage_offset() + first * step)
+def pack_frames(y: torch.Tensor, n_rows: int, length: int, step: int, first: int, n_out: int,
+                window: Optional[torch.Tensor] = None, detrend=False, cplx: bool = True) -> torch.Tensor:
+    """Frames first .. first + n_rows - 1 (length `length`, start (first + r) * step) of EVERY row of the contiguous
+    y [B, Lp] -> [B * n_rows, n_out(, 2)] detrended / windowed / zero-padded rows, clip-major: one launch for the whole
+    batch (syg_pack_frames_f32; B * n_rows <= 65535)."""
+    B, Lp = y.shape
+    rows = B * n_rows
+    out = torch.empty((rows, n_out, 2) if cplx else (rows, n_out), dtype=torch.float32, device=y.device)
+    dcode = detrend_code(detrend)
+    work = torch.empty(lib().syg_pack_rows_work_bytes(rows) // 8, dtype=torch.float64, device=y.device) if dcode else None
+    base = y.data_ptr() + 4 * first * step
+    rc = lib().syg_pack_frames_f32(C.c_void_p(base), rows, length, step, n_rows, Lp, _ptr(window), dcode, 0, int(cplx),
+                                   _ptr(out), n_out, _ptr(work), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_pack_frames_f32")
+    return out
 
 
 def stft_rows(y: torch.Tensor, n_fft: int, hop: int, center: bool = True, window="hann", win_length=None):
@@ -394,10 +405,18 @@ def stft_rows(y: torch.Tensor, n_fft: int, hop: int, center: bool = True, window
     win = window_dev(window, win_length, n_fft)
     F = n_fft // 2 + 1
     out = torch.empty((B, Tn, F, 2), dtype=torch.float32, device=y.device)
-    for b in range(B):
+    yp = yp.contiguous()
+    if Tn <= MAX_ROWS:                                        # whole clips per launch: as many as fit 65535 rows
+        per = max(1, MAX_ROWS // Tn)
+        for b0 in range(0, B, per):
+            bc = min(per, B - b0)
+            X = fft_any(pack_frames(yp[b0:b0 + bc], Tn, n_fft, hop, 0, n_fft, window=win))
+            out[b0:b0 + bc] = X.view(bc, Tn, n_fft, 2)[:, :, :F]
+        return out
+    for b in range(B):                                        # long clips: 65535 frames of one clip at a time
         for t0 in range(0, Tn, MAX_ROWS):
             tc = min(MAX_ROWS, Tn - t0)
-            X = fft_any(pack_rows(frame_rows(yp[b], n_fft, hop, tc, t0), n_fft, window=win, cplx=True))
+            X = fft_any(pack_frames(yp[b:b + 1], tc, n_fft, hop, t0, n_fft, window=win))
             out[b, t0:t0 + tc] = X[:, :F]
     return out
 
@@ -556,10 +575,11 @@ def welch_rows(x: torch.Tensor, nperseg: int, noverlap: int, nfft: int, window_h
     out = torch.empty((B, F), dtype=torch.float32, device=x.device)
     acc = torch.empty(F, dtype=torch.float64, device=x.device)
     st = C.c_void_p(_stream_ptr())
+    x = x.contiguous()
     for b in range(B):
         for s0 in range(0, nseg, MAX_ROWS):
             sc = min(MAX_ROWS, nseg - s0)
-            X = fft_any(pack_rows(frame_rows(x[b], nperseg, step, sc, s0), nfft, window=win, detrend=detrend, cplx=True))
+            X = fft_any(pack_frames(x[b:b + 1], sc, nperseg, step, s0, nfft, window=win, detrend=detrend))
             P = torch.empty((sc, F), dtype=torch.float32, device=x.device)
             check(lib().syg_psd_onesided_f32(_ptr(X), sc, nfft, float(scale), _ptr(P), st), "syg_psd_onesided_f32")
             check(lib().syg_col_mean_f32(_ptr(P), sc, F, _ptr(acc), int(s0 == 0), int(s0 + sc == nseg), float(nseg),

@@ -406,3 +406,20 @@ def test_fft_prime_lengths_bluestein(n):
     assert peak_rel(got[..., 0] + 1j * got[..., 1], np.fft.fft(z.astype(np.complex128), axis=1)) <= TOL
     got = ops.fft_any(x, True).cpu().numpy().astype(np.float64)
     assert peak_rel(got[..., 0] + 1j * got[..., 1], np.fft.ifft(z.astype(np.complex128), axis=1)) <= TOL
+
+
+def test_generic_stft_batched_over_clips():
+    """Frame lengths that are not powers of two: the frames of many clips go through one packing launch
+    (syg_pack_frames_f32); every clip equals its own single-clip result and the oracle."""
+    from sygnals_amd import ops
+    Y = O.synth_clips(37, 9000, 16000, seed=5)
+    yd = ops.to_device_f32(Y)
+    for n_fft, hop, center in ((1000, 250, True), (600, 200, False), (90, 7, True)):
+        X = ops.stft_any(yd, n_fft, hop, center).cpu().numpy().astype(np.float64)
+        for b in (0, 17, 36):
+            want = O.stft(Y[b].astype(np.float64), n_fft=n_fft, hop_length=hop, center=center).T   # [T, F]
+            assert peak_rel(X[b, :, :, 0] + 1j * X[b, :, :, 1], want) <= TOL, (n_fft, b)
+    # a non-contiguous view of the clips
+    wide = ops.to_device_f32(np.pad(Y, ((0, 0), (3, 5))))[:, 3:3 + 9000]
+    X2 = ops.stft_any(wide, 1000, 250, False).cpu().numpy()
+    assert np.array_equal(X2, ops.stft_any(yd, 1000, 250, False).cpu().numpy())
