@@ -134,12 +134,19 @@ __global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in,
     wave_lds_sync();
     float* row = &tile[lane * LSTR];
     int jb = 0;
-    if (j0 == 0 && c0 == 0) {
-      // the wave that holds chunk 0: its first `skip` (< TS) grid positions are not samples -- this one tile is
-      // walked sample by sample with the chunk-0 lane sitting those positions out
+    // the wave that holds chunk 0: its first `skip` (< CS) grid positions are not samples.  A tile that lies wholly
+    // in front of the first sample runs as usual and the chunk-0 lane takes its state back afterwards; the one tile
+    // the first sample falls into is walked sample by sample with that lane sitting the leading positions out
+    const bool dead_tile = (c0 == 0) && (j0 + TS <= skip);
+    double s0[S], s1[S];
+    if (dead_tile) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) { s0[s] = z0[s]; s1[s] = z1[s]; }
+    }
+    if (c0 == 0 && j0 < skip && !dead_tile) {
       for (int j = 0; j < TS; ++j) {
         float o = 0.f;
-        if (c != 0 || j >= skip) o = (float)step((double)row[j]);
+        if (c != 0 || j0 + j >= skip) o = (float)step((double)row[j]);
         if (MODE != 0) row[j] = o;
       }
       jb = TS;
@@ -150,6 +157,10 @@ __global__ __launch_bounds__(64) void chunk_kernel(const float* __restrict__ in,
       const float o0 = (float)step((double)q.x), o1 = (float)step((double)q.y), o2 = (float)step((double)q.z),
                   o3 = (float)step((double)q.w);
       if (MODE != 0) *reinterpret_cast<float4*>(row + j) = make_float4(o0, o1, o2, o3);
+    }
+    if (dead_tile && c == 0) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) { z0[s] = s0[s]; z1[s] = s1[s]; }
     }
     if (MODE != 0) {
       wave_lds_sync();
@@ -316,10 +327,12 @@ int launch_all(const float* x, int64_t B, int64_t L, int64_t ldx, const SosParam
   // 32-sample (128-byte) alignment of every 8-lane segment: x index of grid g = g - skip_f - pad = 0 (mod 32);
   // forward stores K - g - 31 .. K - g land on aligned 128-byte segments of G
   const int skip_f = (TS - pad % TS) % TS;
-  const int skip_b = (int)((TS - (lext + skip_f) % TS) % TS);
+  // skip_b makes K + 1 a multiple of the chunk length: forward chunk c and backward chunk nch_f - 1 - c then cover
+  // the same samples (and every 128-byte segment stays aligned, CS being a multiple of TS)
+  const int skip_b = (int)((CS - (lext + skip_f) % CS) % CS);
   const int64_t K = lext - 1 + skip_f + skip_b;                  // forward grid g  <->  backward grid K - g
   const int nch_f = (int)grid_chunks(lext, skip_f), nch_b = (int)grid_chunks(lext, skip_b);
-  const int nch_w = (int)grid_chunks(lext, TS - 1);              // what syg_sosfiltfilt_work_bytes sized the buffers for
+  const int nch_w = (int)grid_chunks(lext, CS - 1);              // what syg_sosfiltfilt_work_bytes sized the buffers for
   const int64_t lpad = (int64_t)nch_w * CS;
   float* G = (float*)work;                                       // forward output, reversed: [B, lpad]
   double* zs = (double*)(G + B * lpad);
@@ -355,7 +368,7 @@ using namespace syg;
 extern "C" int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, int n_sections) {
   if (B < 1 || L < 1 || padlen < 0 || n_sections < 1 || n_sections > MAXS) return -1;
   const int64_t lext = L + 2 * (int64_t)padlen;
-  const int64_t nch = (lext + (TS - 1) + CS - 1) / CS;   // grid = sequence + up to TS - 1 alignment positions
+  const int64_t nch = (lext + (CS - 1) + CS - 1) / CS;   // grid = sequence + up to CS - 1 alignment positions
   return B * nch * CS * (int64_t)sizeof(float) + 2 * B * nch * 2 * n_sections * (int64_t)sizeof(double);
 }
 
