@@ -17,7 +17,7 @@ A workgroup of the fused kernels fills a whole CU, so a communication kernel tha
 same time either waits for a full launch or makes that launch wait for it (measured with a stand-in:
 tools/queue_bench.py -> profiles/r01_coresidency.json, 167 -> 217 us per step).  For N > 1 the step
 therefore runs as the two-launch form (STFT->mel kernel + per-clip dB/DCT kernel, +3 us) on all but
-RESERVE_CUS compute units, and RCCL's point-to-point channels are capped so that its workgroups fit
+8 / 16 / 32 compute units (N = 2 / 4 / 8: four RCCL channels per peer at the root, plus a few), and RCCL's point-to-point channels are capped so that its workgroups fit
 the CUs set aside (NCCL_NCHANNELS_PER_PEER / NCCL_MAX_P2P_NCHANNELS; all three can be overridden from
 the environment).  Rank 0 prints ONE JSON line.
 """
@@ -35,7 +35,7 @@ import numpy as np
 SR = 48000
 L = 48000
 B_PER_GPU = 1024
-RESERVE_CUS = 32     # N > 1: compute units left to RCCL's send / receive workgroups (4 channels x 7 peers at the root)
+P2P_CHANNELS_PER_PEER = 4     # N > 1: RCCL point-to-point channels (= workgroups) per peer; the CUs set aside follow
 N_FFT, HOP, N_MELS, N_MFCC = 2048, 512, 40, 13
 T_FRAMES = 1 + L // HOP
 ALGO_BYTES_PER_CLIP = 4 * L + 4 * N_MFCC * T_FRAMES        # 196 888 B: read samples, write MFCCs
@@ -120,9 +120,10 @@ def main():
     if world > 1:
         # CUs set aside for the collective + RCCL capped to fit them (see the module docstring); set before the
         # process group and the first launch read them
-        os.environ.setdefault("SYGNALS_AMD_RESERVE_CUS", str(RESERVE_CUS))
-        os.environ.setdefault("NCCL_NCHANNELS_PER_PEER", "4")
-        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", str(4 * (world - 1)))
+        nch = P2P_CHANNELS_PER_PEER * (world - 1)             # RCCL workgroups at the root while a gather runs
+        os.environ.setdefault("SYGNALS_AMD_RESERVE_CUS", str(8 * ((nch + 4 + 7) // 8)))   # 8 / 16 / 32 for N = 2 / 4 / 8
+        os.environ.setdefault("NCCL_NCHANNELS_PER_PEER", str(P2P_CHANNELS_PER_PEER))
+        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", str(nch))
         reserve = int(os.environ["SYGNALS_AMD_RESERVE_CUS"])
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if same_gpu:
