@@ -18,10 +18,11 @@
 // Data movement (it, not the fp64 arithmetic, bounds these passes).  Each sweep works on an ALIGNED GRID: grid
 // position g = sequence index + skip, with skip chosen per sweep so that every 4-sample group of the grid is
 // a 16-byte aligned float4 -- and every 8-lane, 32-sample segment a whole 128-byte line -- both where it is read and
-// where it is written (skip in 0..31):
+// where it is written:
 //   forward sweep   reads the clip itself (odd extension computed on the fly): skip_f = -pad mod 32 aligns x;
 //                   writes its output reversed into the work buffer G at grid K - g (K fixed by skip_b);
-//   backward sweep  reads G in place order: skip_b = -(lext + skip_f) mod 32 makes the forward stores aligned.
+//   backward sweep  reads G in place order: skip_b = -(lext + skip_f) mod 256 makes the forward stores aligned and
+//                   lets forward chunk c and backward chunk n - 1 - c cover the same samples.
 // The skip leading positions of chunk 0 are not samples: its lane leaves the state untouched there.  Chunk 0 is
 // therefore short, so its pass A starts from the true initial state zi * first sample (known up front) and what
 // it reports is already the true state at the start of chunk 1 -- the scan takes it as is.  A wave owns 64 consecutive chunks of one clip and moves 64 x 32-sample
