@@ -423,3 +423,32 @@ def test_generic_stft_batched_over_clips():
     wide = ops.to_device_f32(np.pad(Y, ((0, 0), (3, 5))))[:, 3:3 + 9000]
     X2 = ops.stft_any(wide, 1000, 250, False).cpu().numpy()
     assert np.array_equal(X2, ops.stft_any(yd, 1000, 250, False).cpu().numpy())
+
+
+def test_reference_dsp_cases():
+    """The reference's own cases for these functions (tests/test_dsp.py:109-200), same inputs and assertions."""
+    from sygnals_amd.core.dsp import (amplitude_envelope, apply_convolution, compute_autocorrelation, compute_correlation,
+                                      compute_psd_periodogram, compute_psd_welch)
+    x = np.array([1, 2, 3, 4, 5], dtype=float)
+    k = np.array([1, 0, -1], dtype=float)
+    np.testing.assert_allclose(apply_convolution(x, k, mode="same"), np.convolve(x, k, mode="same"), atol=1e-5)
+    a = np.array([1, 2, 3, 2, 1], dtype=float)
+    b = np.array([0, 1, 2, 1, 0], dtype=float)
+    assert np.argmax(compute_correlation(a, b, mode="full")) == 4
+    fs, freq = 1000, 50.0                                       # the sine_wave fixture: 1 s, amplitude 1
+    t = np.linspace(0, 1, fs, endpoint=False)
+    s = np.sin(2 * np.pi * freq * t)
+    ac = compute_autocorrelation(s, mode="full")
+    c = len(s) - 1
+    assert np.argmax(ac) == c
+    lag = int(round(fs / freq))
+    assert ac[c + lag] > 0.8 * ac[c] and ac[c - lag] > 0.8 * ac[c]
+    for f, p in (compute_psd_periodogram(s, fs=fs, window="hann"), compute_psd_welch(s, fs=fs, nperseg=256)):
+        assert f.shape == p.shape and f.dtype == np.float64 and p.dtype == np.float64
+        assert abs(f[np.argmax(p)] - freq) < 1.0 + fs / 256
+    env = amplitude_envelope(s, method="hilbert")
+    assert env.shape == s.shape and env.dtype == np.float64 and np.all(env >= 0)
+    np.testing.assert_allclose(np.mean(env), 1.0, atol=0.05)
+    env = amplitude_envelope(s, method="rms", frame_length=256, hop_length=128)
+    assert env.dtype == np.float64 and len(env) == 1 + len(s) // 128 and np.all(env >= 0)
+    np.testing.assert_allclose(np.mean(env), 1.0 / np.sqrt(2), atol=0.05)

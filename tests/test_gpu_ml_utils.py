@@ -123,3 +123,79 @@ def test_zoom_random_shapes_vs_scipy():
                 assert_parity(got, want, TOL, f"{h}x{w}->{h2}x{w2}")
             else:       # nearest: identical picks except where the sampling point is within rounding of a half-way tie
                 assert (np.abs(got - want) > 1e-6).mean() < 0.02, (h, w, h2, w2)
+
+
+# ---------------------------------------------------------------- the reference's own test cases, same inputs
+# (tests/test_ml_utils.py:36-80 fixtures, :83-150 and :233-345 assertions); tolerances are those of an fp32 device path
+def _ref_fixtures():
+    rng = np.random.default_rng(123)
+    arr = np.hstack([rng.normal(loc=10, scale=2, size=(50, 1)), rng.normal(loc=0, scale=0.1, size=(50, 1)),
+                     rng.uniform(low=-5, high=5, size=(50, 1))]).astype(np.float64)
+    one_d = np.random.default_rng(456).normal(loc=5, scale=3, size=100).astype(np.float64)
+    rng = np.random.default_rng(789)
+    feats = {"rms": rng.random(50) * 0.5, "zcr": rng.random(50) * 0.1, "centroid": rng.random(50) * 1000 + 500}
+    fmap = np.random.default_rng(101).random((64, 80)) * 10
+    return arr, one_d, feats, fmap
+
+
+def test_reference_scaling_cases(gm):
+    from sklearn.preprocessing import MinMaxScaler, RobustScaler, StandardScaler
+    from sygnals_amd.core.ml_utils import apply_scaling
+    arr, one_d, _, _ = _ref_fixtures()
+    out, sc = apply_scaling(arr, scaler_type="standard")
+    assert isinstance(sc, StandardScaler) and out.shape == arr.shape and out.dtype == np.float64
+    np.testing.assert_allclose(out.mean(axis=0), 0.0, atol=1e-6)
+    np.testing.assert_allclose(out.std(axis=0), 1.0, atol=1e-6)
+    out, sc = apply_scaling(arr, scaler_type="minmax")
+    assert isinstance(sc, MinMaxScaler)
+    np.testing.assert_allclose(out.min(axis=0), 0.0, atol=1e-6)
+    np.testing.assert_allclose(out.max(axis=0), 1.0, atol=1e-6)
+    out, sc = apply_scaling(arr, scaler_type="robust")
+    assert isinstance(sc, RobustScaler)
+    np.testing.assert_allclose(np.median(out, axis=0), 0.0, atol=1e-6)
+    out, sc = apply_scaling(one_d, scaler_type="standard")
+    assert out.shape == (100, 1)
+    np.testing.assert_allclose([out.mean(), out.std()], [0.0, 1.0], atol=1e-6)
+    fitted = StandardScaler().fit(arr[:25])
+    out, used = apply_scaling(arr[25:], fit=False, scaler_instance=fitted)
+    assert used is fitted and out.shape == (25, 3)
+    np.testing.assert_allclose(used.inverse_transform(out), arr[25:], atol=1e-5)
+    with pytest.raises(ValueError):
+        apply_scaling(arr, scaler_type="invalid_scaler")
+    with pytest.raises(ValueError):
+        apply_scaling(arr, fit=False, scaler_instance=None)
+    with pytest.raises(ValueError):
+        apply_scaling(arr, fit=False, scaler_instance=StandardScaler())
+
+
+def test_reference_formatter_cases(gm):
+    from sygnals_amd.core.ml_utils import format_feature_sequences, format_features_as_image
+    _, _, feats, fmap = _ref_fixtures()
+    res = format_feature_sequences(feats, output_format="list_of_arrays")
+    assert isinstance(res, list) and len(res) == 1 and res[0].shape == (50, 3) and res[0].dtype == np.float64
+    pad = format_feature_sequences(feats, max_sequence_length=60, padding_value=-1.0, output_format="padded_array")
+    assert pad.shape == (1, 60, 3) and np.all(pad[0, 50:, :] == -1.0)
+    np.testing.assert_allclose(pad[0, :50, list(feats).index("rms")], feats["rms"])
+    post = format_feature_sequences(feats, max_sequence_length=40, truncation_strategy="post", output_format="padded_array")
+    np.testing.assert_allclose(post[0, :, 0], feats["rms"][:40])
+    pre = format_feature_sequences(feats, max_sequence_length=40, truncation_strategy="pre", output_format="padded_array")
+    np.testing.assert_allclose(pre[0, :, 0], feats["rms"][10:])
+    bad = dict(feats); bad["rms"] = bad["rms"][:-1]
+    with pytest.raises(ValueError, match="All feature arrays.*must have the same length"):
+        format_feature_sequences(bad)
+    with pytest.raises(ValueError, match="Unknown truncation_strategy"):
+        format_feature_sequences(feats, max_sequence_length=40, truncation_strategy="middle")
+    same = format_features_as_image(fmap, normalize=False)
+    assert same.shape == fmap.shape and same.dtype == np.float64
+    np.testing.assert_allclose(same, fmap, rtol=1e-6)                      # (fp32 on the device)
+    assert format_features_as_image(fmap, output_shape=(32, 40), normalize=False).shape == (32, 40)
+    for shape in (None, (100, 100)):
+        img = format_features_as_image(fmap, output_shape=shape, normalize=True)
+        assert img.shape == (shape or fmap.shape) and img.min() >= 0.0 and img.max() <= 1.0
+        assert np.isclose(img.min(), 0.0) and np.isclose(img.max(), 1.0)
+    with pytest.raises(ValueError, match="Input feature_map must be a 2D array"):
+        format_features_as_image(np.random.rand(10))
+    with pytest.raises(ValueError, match="output_shape must be a tuple of two positive integers"):
+        format_features_as_image(fmap, output_shape=(10,))
+    with pytest.raises(ValueError, match="output_shape must be a tuple of two positive integers"):
+        format_features_as_image(fmap, output_shape=(-10, 10))
