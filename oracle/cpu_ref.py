@@ -933,6 +933,24 @@ def apply_scaling(features, scaler_type="standard", scaler_params=None):
     return out.astype(np.float64), attrs
 
 
+def format_feature_vectors_per_segment(features_dict, segment_indices, aggregation="mean"):      # formatters.py:51-163
+    """[n_segments, n_features] float64; invalid segments stay NaN; NaN-aware aggregations (formatters.py:28-45)."""
+    names = list(features_dict.keys())
+    n = len(features_dict[names[0]])
+    fn = {"mean": np.mean, "std": np.std, "median": np.median, "min": np.min, "max": np.max}
+    how = {k: (aggregation if isinstance(aggregation, str) else aggregation.get(k, "mean")) for k in names}
+    out = np.full((len(segment_indices), len(names)), np.nan)
+    for i, (a, b) in enumerate(segment_indices):
+        if not (0 <= a < n and a < b and b <= n):
+            continue
+        for j, k in enumerate(names):
+            v = np.asarray(features_dict[k], dtype=np.float64)[a:b]
+            v = v[~np.isnan(v)]
+            if v.size:
+                out[i, j] = fn[how[k]](v)
+    return out
+
+
 def format_feature_sequences(features_dict, max_sequence_length=None, padding_value=0.0, truncation_strategy="post",
                              output_format="list_of_arrays"):                    # formatters.py:166-253
     names = list(features_dict.keys())

@@ -1,13 +1,16 @@
-"""Device-backed mirror of the sequence / image formatters of sygnals/core/ml_utils/formatters.py:166-334.
+"""Device-backed mirror of sygnals/core/ml_utils/formatters.py:51-334 (per-segment vectors, sequences, images).
 
 `format_feature_sequences` is pure data movement (stack, cut, pad): it accepts NumPy arrays or device tensors and
 returns the same kind, so features can go from the extraction kernels to a training loop without leaving HBM.
 `format_features_as_image` resizes (scipy.ndimage.zoom order 0 / 1, mode='nearest') and normalises on the device.
+`format_feature_vectors_per_segment` aggregates the frames of every segment with the NaN-aware column statistics
+(mean / std / min / max: syg_col_stats_f32; median: syg_col_quantiles_f32) of the stacked [frames, features] matrix.
 """
 from __future__ import annotations
 
 import logging
-from typing import Dict, Optional, Tuple
+import warnings
+from typing import Any, Dict, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -17,6 +20,65 @@ from ..._lib import SygnalsHipError
 
 logger = logging.getLogger(__name__)
 _EPSILON = np.finfo(np.float64).eps
+
+
+AGGREGATIONS = ("mean", "std", "median", "min", "max")          # formatters.py:39-45 (NaN-aware)
+
+
+def format_feature_vectors_per_segment(features_dict: Dict[str, object], segment_indices: List[Tuple[int, int]],
+                                       aggregation: Union[str, Dict[str, str]] = "mean",
+                                       output_format: str = "dataframe", segment_labels: Optional[List[Any]] = None):
+    import pandas as pd
+    if not features_dict:
+        logger.warning("Input features_dict is empty. Returning empty result.")
+        return pd.DataFrame() if output_format == "dataframe" else np.empty((0, 0), dtype=np.float64)
+    names = list(features_dict.keys())
+    counts = [len(v) for v in features_dict.values()]
+    n = counts[0]
+    if not all(c == n for c in counts):
+        raise ValueError(f"All feature arrays in features_dict must have the same length. Found lengths: {counts}")
+    if not segment_indices:
+        logger.warning("No segment indices provided. Returning empty result.")
+        return pd.DataFrame() if output_format == "dataframe" else np.empty((0, len(names)), dtype=np.float64)
+    if segment_labels is not None and len(segment_labels) != len(segment_indices):
+        raise ValueError("Length of segment_labels must match length of segment_indices.")
+    if isinstance(aggregation, str):
+        if aggregation not in AGGREGATIONS:
+            raise ValueError(f"Unknown global aggregation function: '{aggregation}'. Available: {list(AGGREGATIONS)}")
+        how = {k: aggregation for k in names}
+    elif isinstance(aggregation, dict):
+        how = {}
+        for k in names:
+            m = aggregation.get(k, "mean")
+            if m not in AGGREGATIONS:
+                raise ValueError(f"Unknown aggregation function '{m}' for feature '{k}'. Available: {list(AGGREGATIONS)}")
+            how[k] = m
+    else:
+        raise TypeError("aggregation must be a string or a dictionary.")
+    if output_format not in ("dataframe", "numpy"):
+        raise ValueError(f"Unknown output_format: '{output_format}'. Choose 'dataframe' or 'numpy'.")
+    dev = ops.require_gpu()
+    X = torch.stack([torch.as_tensor(np.asarray(features_dict[k].cpu() if isinstance(features_dict[k], torch.Tensor)
+                                                else features_dict[k], dtype=np.float32)) for k in names], dim=1).to(dev)
+    out = np.full((len(segment_indices), len(names)), np.nan, dtype=np.float64)
+    need_median = any(m == "median" for m in how.values())
+    row_of = {"mean": 1, "min": 3, "max": 4}
+    for i, (a, b) in enumerate(segment_indices):
+        if not (0 <= a < n and a < b and b <= n):
+            msg = f"Invalid segment indices ({a}, {b}) for num_frames={n}. Skipping segment {i}."
+            logger.warning(msg)
+            warnings.warn(msg, UserWarning, stacklevel=2)
+            continue                                              # the row stays NaN
+        seg = X[a:b]
+        st = ops.col_stats(seg).cpu().numpy()                     # count, mean, population variance, min, max
+        med = ops.col_quantiles(seg, [0.5]).cpu().numpy()[0] if need_median else None
+        for j, k in enumerate(names):
+            m = how[k]
+            out[i, j] = med[j] if m == "median" else (np.sqrt(st[2, j]) if m == "std" else st[row_of[m], j])
+    if output_format == "numpy":
+        return out
+    index = segment_labels if segment_labels is not None else pd.RangeIndex(len(segment_indices), name="segment_index")
+    return pd.DataFrame(out, columns=names, index=index)
 
 
 def format_feature_sequences(features_dict: Dict[str, object], max_sequence_length: Optional[int] = None,

@@ -253,6 +253,11 @@ def main():
     g["seq_cut16_post"] = fm.format_feature_sequences(feats, max_sequence_length=16, output_format="padded_array")
     g["seq_cut16_pre"] = fm.format_feature_sequences(feats, max_sequence_length=16, truncation_strategy="pre",
                                                      output_format="padded_array")
+    segs = [(0, 15), (15, 30), (30, 40), (5, 6)]
+    for agg in ("mean", "std", "median", "min", "max"):
+        g[f"vec_{agg}"] = fm.format_feature_vectors_per_segment(feats, segs, aggregation=agg, output_format="numpy")
+    g["vec_mixed"] = fm.format_feature_vectors_per_segment(feats, segs, aggregation={"f0": "max", "f1": "min", "f2": "std"},
+                                                           output_format="numpy")
     M = np.abs(rng3.normal(0, 1, (40, 94))).astype(np.float32).astype(np.float64) * np.linspace(3, 0.1, 40)[:, None]
     g["img_in"] = M
     g["img_norm"] = fm.format_features_as_image(M)

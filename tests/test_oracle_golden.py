@@ -317,3 +317,14 @@ def test_formatters_match_reference(gm):
     assert_allclose(O.format_features_as_image(M, (20, 200), normalize=False), gm["img_20x200_nonorm"], rtol=0, atol=1e-15)
     assert_allclose(O.format_features_as_image(M, (128, 32), resize_order=0), gm["img_128x32_nearest"], rtol=0, atol=1e-15)
     assert_array_equal(O.format_features_as_image(np.full((5, 7), 2.5)), gm["img_const"])
+
+
+def test_segment_vectors_match_reference(gm):
+    feats = {f"f{i}": gm["X"][:40, i] for i in range(4)}
+    segs = [(0, 15), (15, 30), (30, 40), (5, 6)]
+    for agg in ("mean", "std", "median", "min", "max"):
+        assert_allclose(O.format_feature_vectors_per_segment(feats, segs, agg), gm[f"vec_{agg}"], rtol=1e-13, atol=0)
+    assert_allclose(O.format_feature_vectors_per_segment(feats, segs, {"f0": "max", "f1": "min", "f2": "std"}),
+                    gm["vec_mixed"], rtol=1e-13, atol=0)
+    nanrow = O.format_feature_vectors_per_segment(feats, [(0, 10), (10, 60)])
+    assert np.isnan(nanrow[1]).all() and not np.isnan(nanrow[0]).any()
