@@ -61,3 +61,28 @@ def test_argument_errors_are_reported_without_device_work():
     assert h.syg_stft2048_mfcc_fits(40, 94, 41) == 0 and h.syg_stft2048_mfcc_fits(0, 94, 1) == 0
     with pytest.raises(_lib.SygnalsHipError, match="padlen"):
         _lib.check(-1, "x")
+
+
+def test_header_is_valid_c_and_cpp(tmp_path):
+    """include/sygnals_hip.h is what a maintainer binds against: it must compile as plain C99 and as C++ on its own,
+    and a C translation unit that calls every entry point through it must link against the library."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "sygnals_hip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    names = sorted(set(re.findall(r"\b(syg_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    src = tmp_path / "link.c"
+    src.write_text('#include "sygnals_hip.h"\n#include <stdio.h>\nint main(void) {\n  const void* p[] = {'
+                   + ", ".join(f"(const void*){n}" for n in names) + '};\n  printf("%d %d\\n", (int)(sizeof(p) / sizeof(p[0])), '
+                   'syg_abi_version());\n  return 0;\n}\n')
+    lib = os.path.join(root, "sygnals_amd", "lib")
+    exe = tmp_path / "link"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-L", lib, "-lsygnals_hip",
+                    f"-Wl,-rpath,{lib}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == len(names) and int(out[1]) == 1
