@@ -1,25 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Msamples/s of batched STFT -> mel -> MFCC on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): per GPU 1024 synthetic clips of 1 s @ 48 kHz
+Default workload (BASELINE.json configs[1], "C2"): per GPU 1024 synthetic clips of 1 s @ 48 kHz
 (49 152 000 samples), STFT n_fft=2048 hop=512 hann center -> |X|^2 -> 40 Slaney mel bands ->
 power_to_db(ref=max, top_db=80) -> DCT-II ortho, 13 coefficients.  Inputs are resident in HBM
 when the timed region starts.  One step = one pass of the hot path over the batch: ONE kernel launch
-(samples in, MFCCs out) on a single GPU.
+(samples in, MFCCs out) on every GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4] [--prewarm P]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank owns its own 1024 clips (weak scaling), no data-path
-collective; the only exchange is the RCCL gather of the [1024, 13, 94] result blocks to rank 0,
-inside the timed region, asynchronous: the gather of step k runs beside the kernels of step k+1.
-A workgroup of the fused kernels fills a whole CU, so a communication kernel that needs CUs at the
-same time either waits for a full launch or makes that launch wait for it (measured with a stand-in:
-tools/queue_bench.py -> profiles/r01_coresidency.json, 167 -> 217 us per step).  For N > 1 the step
-therefore runs as the two-launch form (STFT->mel kernel + per-clip dB/DCT kernel, +3 us) on all but
-8 / 16 / 32 compute units (N = 2 / 4 / 8: four RCCL channels per peer at the root, plus a few), and RCCL's point-to-point channels are capped so that its workgroups fit
-the CUs set aside (NCCL_NCHANNELS_PER_PEER / NCCL_MAX_P2P_NCHANNELS; all three can be overridden from
-the environment).  Rank 0 prints ONE JSON line.
+`--config c4` (BASELINE.json configs[3]): per GPU 2048 clips, MFCC + spectral centroid + rolloff + contrast packed
+to one [2048, 22, 94] block per step, gathered to rank 0.
+
+N > 1: one process per GPU, every rank owns its own clips (weak scaling), no data-path collective; the only
+exchange is the RCCL gather of the result blocks to rank 0, inside the timed region, asynchronous: the gather of
+step k runs beside the kernels of step k+1.  Every rank runs exactly the kernels of the N = 1 run.  `--reserve-cus n`
+(opt-in, unmeasured on a multi-GPU node) switches to the two-launch form on all but n CUs and caps RCCL's
+point-to-point channels to fit them.
+
+The clock pre-warm (`--prewarm`, untimed, reported) runs before the driver's own warm-up: the GPU needs ~150
+launches (30 ms) from idle to reach its steady clock.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -34,12 +35,19 @@ import numpy as np
 
 SR = 48000
 L = 48000
-B_PER_GPU = 1024
-P2P_CHANNELS_PER_PEER = 4     # N > 1: RCCL point-to-point channels (= workgroups) per peer; the CUs set aside follow
 N_FFT, HOP, N_MELS, N_MFCC = 2048, 512, 40, 13
 T_FRAMES = 1 + L // HOP
-ALGO_BYTES_PER_CLIP = 4 * L + 4 * N_MFCC * T_FRAMES        # 196 888 B: read samples, write MFCCs
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3                               # MI355X_MICROARCH.md: fp32-input MFMA, dense
+CONFIGS = {
+    # clips per GPU, feature rows per clip, algorithmic bytes per clip (read samples, write the rows)
+    "c2": {"clips": 1024, "rows": N_MFCC},
+    "c4": {"clips": 2048, "rows": N_MFCC + 1 + 1 + 7},
+}
+
+
+def algo_bytes_per_clip(rows):
+    return 4 * L + 4 * rows * T_FRAMES                     # C2: 196 888 B, C4: 200 272 B
 
 
 def _cpu_worker(args):
@@ -77,20 +85,33 @@ def cpu_baseline(target_seconds=10.0):
     wall = time.perf_counter() - t0
     clips = cores * n_per
     return {"value": round(clips * L / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{clips} clips x 1 s @ 48 kHz (same recipe/config as the GPU workload), float64 oracle, "
+            "sample": f"{clips} clips x 1 s @ 48 kHz (same recipe/config as the C2 GPU workload), float64 oracle, "
                       f"one clip per call, {cores} processes x 1 thread, {wall:.1f} s wall",
             "single_core_value": round(L / per_clip / 1e6, 3)}
+
+
+def mfma_flops_per_launch(ops, B):
+    """fp32 MFMA flops one launch of the one-launch MFCC kernel issues (zero-weight padding steps included -- they
+    are issued): block-sparse filterbank steps per 16-frame tile + the per-clip dB/DCT epilogue."""
+    cfg = ops.mel_config(SR, N_FFT, N_MELS, waves=16)
+    steps_per_tile = int(np.asarray(cfg.plan[2 + 2 * 16: 2 + 3 * 16]).sum())
+    tiles = (T_FRAMES + 15) // 16
+    dct_steps = ((N_MFCC + 15) // 16) * tiles * (4 * ((N_MELS + 15) // 16))
+    return B * (tiles * steps_per_tile + dct_steps) * (16 * 16 * 4 * 2)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step is ~0.2 ms and the GPU needs ~150 steps (30 ms) from idle to reach its steady clock
-    # (tools/warm_curve.py), hence the long default warm-up; the whole default run is still ~0.2 s of GPU time
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--prewarm", type=int, default=300,
+                    help="untimed launches ahead of --warmup that bring the GPU from idle to its steady clock")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--clips", type=int, default=B_PER_GPU, help="clips per GPU (default: the C2 batch)")
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the configuration's)")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="N > 1, opt-in: leave this many CUs to RCCL (two-launch form, capped p2p channels)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,44 +128,52 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from oracle import cpu_ref as O           # synthetic-input recipe only
     from sygnals_amd import ops
     from sygnals_amd.distributed import RootGather
+    from sygnals_amd.synth import synth_clips
 
     # rehearsal on a 1-GPU box: SYG_BENCH_SAME_GPU=1 puts every rank on cuda:0 and exchanges through gloo
     # (RCCL refuses two ranks on one device); the real multi-GPU run uses one GPU per rank over RCCL
     same_gpu = os.environ.get("SYG_BENCH_SAME_GPU") == "1"
     dev_index = 0 if same_gpu else local_rank
     torch.cuda.set_device(dev_index)
-    reserve = 0
+    reserve = a.reserve_cus if world > 1 else 0
     if world > 1:
-        # CUs set aside for the collective + RCCL capped to fit them (see the module docstring); set before the
-        # process group and the first launch read them
-        nch = P2P_CHANNELS_PER_PEER * (world - 1)             # RCCL workgroups at the root while a gather runs
-        os.environ.setdefault("SYGNALS_AMD_RESERVE_CUS", str(8 * ((nch + 4 + 7) // 8)))   # 8 / 16 / 32 for N = 2 / 4 / 8
-        os.environ.setdefault("NCCL_NCHANNELS_PER_PEER", str(P2P_CHANNELS_PER_PEER))
-        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", str(nch))
-        reserve = int(os.environ["SYGNALS_AMD_RESERVE_CUS"])
+        if reserve > 0:
+            # opt-in: CUs set aside for the collective + RCCL capped to fit them; set before the process group and
+            # the first launch read them
+            per_peer = max(1, (reserve - 4) // (world - 1))
+            os.environ["SYGNALS_AMD_RESERVE_CUS"] = str(reserve)
+            os.environ.setdefault("NCCL_NCHANNELS_PER_PEER", str(min(4, per_peer)))
+            os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", str(min(4, per_peer) * (world - 1)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if same_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
-    B = a.clips
-    base = O.synth_clips(64, L, SR, seed=20250523 + rank)          # 64 distinct clips, tiled to the batch
+    cfgc = CONFIGS[a.config]
+    B = a.clips or cfgc["clips"]
+    rows = cfgc["rows"]
+    base = synth_clips(64, L, SR, seed=20250523 + rank)          # 64 distinct clips, tiled to the batch
     y = ops.to_device_f32(np.tile(base, (B // 64 + 1, 1))[:B])
     n_total = B * world
+    one_launch = reserve == 0
 
-    # N > 1: every step's MFCC block is gathered to rank 0 (the only exchange of the path).  The gather
-    # of step k is asynchronous and overlaps the kernel of step k+1; all gathers are finished inside the timed
-    # region.
-    T_frames = 1 + L // HOP
-    gat = RootGather(n_total, (B, N_MFCC, T_frames), torch.float32, "cpu" if same_gpu else torch.device("cuda", dev_index))
+    if a.config == "c2":
+        def compute():
+            return ops.mfcc_batch(y, SR, N_FFT, HOP, N_MELS, N_MFCC, fused=None if one_launch else False)
+    else:
+        from sygnals_amd.core.features.manager import feature_block
+        def compute():
+            return feature_block(y, SR, HOP, n_mels=N_MELS, n_mfcc=N_MFCC)
+
+    # N > 1: every step's result block is gathered to rank 0 (the only exchange of the path).  The gather
+    # of step k is asynchronous and overlaps the kernel of step k+1; all gathers are finished inside the timed region.
+    gat = RootGather(n_total, (B, rows, T_FRAMES), torch.float32, "cpu" if same_gpu else torch.device("cuda", dev_index))
 
     def step():
-        # N > 1: two-launch form (tile-granular shares; robust to the CUs the gather holds), else one launch
-        out = ops.mfcc_batch(y, SR, N_FFT, HOP, N_MELS, N_MFCC, fused=False if world > 1 else None)
+        out = compute()
         if world > 1:
             gat.finish()                               # (the previous step's gather; a stream-side wait)
             gat.start(out.cpu() if same_gpu else out)
@@ -158,6 +187,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    for _ in range(a.prewarm):                         # clock pre-warm: compute only, untimed, reported
+        compute()
     for _ in range(a.warmup):
         step()
     sync()
@@ -171,56 +202,71 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: the one-launch STFT -> mel -> dB -> DCT kernel (MODE 3 of stft2048_kernel; the whole step
-    # at this configuration), HIP events on the stream it is launched on
+    # dominant kernel: HIP events on the stream it is launched on, back-to-back launches (steady clock: the timed
+    # steps above have just run); the average includes the ~2 us dispatch gap, rocprofv3's per-dispatch average does not
     roof = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = max(10, min(a.steps, 100))
-        # back-to-back launches between two events on the launch stream (steady clock: the timed steps above
-        # have just run); the average includes the ~2 us dispatch gap, as rocprofv3's per-dispatch average does not
-        one_launch = world == 1
+        if a.config == "c2" and one_launch:
+            kname = "stft2048_kernel<16,2,3> (16 waves, staged tiles, clip-resident MFCC; the whole step)"
+            kfn = lambda: ops.stft2048_mfcc(y, SR, HOP, True, "hann", N_MELS, N_MFCC)
+            kbytes = B * algo_bytes_per_clip(N_MFCC)
+        elif a.config == "c2":
+            kname = f"stft2048_kernel<16,2,0> (16 waves, staged tiles, mel out) on all but {reserve} CUs"
+            kfn = lambda: ops.stft2048_mel(y, SR, HOP, True, "hann", 2048, N_MELS)
+            kbytes = B * (4 * L + 4 * N_MELS * T_FRAMES)
+        else:
+            from sygnals_amd.core.features.manager import feature_block_dominant
+            kname, kfn, krows = feature_block_dominant(y, SR, HOP, N_MELS, N_MFCC)
+            kbytes = B * (4 * L + 4 * krows * T_FRAMES)
+        kfn()
         e0.record()
         for _ in range(reps):
-            if one_launch:
-                ops.stft2048_mfcc(y, SR, HOP, True, "hann", N_MELS, N_MFCC)
-            else:                                   # N > 1 runs the two-launch form: its dominant kernel is the mel kernel
-                ops.stft2048_mel(y, SR, HOP, True, "hann", 2048, N_MELS)
+            kfn()
         e1.record()
         e1.synchronize()
         kdur = e0.elapsed_time(e1) * 1e-3 / reps
-        # algorithmic bytes of the path this launch carries: every sample read once, MFCCs (N > 1: the mel matrix,
-        # which the second launch turns into MFCCs) written once
-        kbytes = B * ALGO_BYTES_PER_CLIP if one_launch else B * (4 * L + 4 * N_MELS * T_frames)
         achieved = kbytes / kdur / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and a.config == "c2" and one_launch:
             try:
-                traffic = json.load(open(tp)).get("dominant_kernel_bytes_per_launch") if one_launch else None
+                traffic = json.load(open(tp)).get("dominant_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "stft2048_kernel<16,2,3> (16 waves, staged tiles, clip-resident MFCC)" if one_launch else
-                          f"stft2048_kernel<16,2,0> (16 waves, staged tiles, mel out) on all but {reserve} CUs",
-                "kernel_avg_us": round(kdur * 1e6, 2),
-                "algorithmic_bytes_per_launch": kbytes}
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kname,
+                "kernel_avg_us": round(kdur * 1e6, 2), "algorithmic_bytes_per_launch": kbytes}
+        if a.config == "c2" and one_launch:
+            fl = mfma_flops_per_launch(ops, B)
+            roof["mfma_util"] = {"flops_per_launch": fl, "achieved_tflops": round(fl / kdur / 1e12, 2),
+                                 "peak_tflops": MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                                 "frac": round(fl / kdur / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                 "note": "mel filterbank (block-sparse) + dB/DCT epilogue; the FFT runs on the vector pipe"}
 
     if rank == 0:
         samples = n_total * L * a.steps
         value = samples / elapsed / 1e6
-        job_bytes = n_total * ALGO_BYTES_PER_CLIP * a.steps
+        job_bytes = n_total * algo_bytes_per_clip(rows) * a.steps
+        if a.config == "c2":
+            workload = ("C2: 1024 x 1 s @ 48 kHz clips per GPU, STFT n_fft=2048 hop=512 hann center -> 40-band Slaney "
+                        "mel -> power_to_db(ref=max, top_db=80) -> 13 MFCC (DCT-II ortho)")
+        else:
+            workload = ("C4: 2048 x 1 s @ 48 kHz clips per GPU (16 384 over 8), STFT n_fft=2048 hop=512 -> 13 MFCC "
+                        "(40 mel) + spectral centroid + rolloff (0.85) + contrast (6 bands + delta) -> [B, 22, 94] "
+                        "block per step, gathered to rank 0")
+        par = f"clip-sharded x{world}"
+        if world > 1:
+            par += (", asynchronous RCCL gather to rank 0 in the timed region" +
+                    (f", two-launch form on all but {reserve} CUs" if reserve else ", same kernels as N = 1"))
         line = {
             "metric": "Msamples/s STFT->MFCC (n_fft=2048, hop=512)", "value": round(value, 1), "unit": "Msamples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_steps": a.prewarm,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 1024 x 1 s @ 48 kHz clips per GPU, STFT n_fft=2048 hop=512 hann center -> "
-                                   "40-band Slaney mel -> power_to_db(ref=max, top_db=80) -> 13 MFCC (DCT-II ortho)",
-                       "clips_per_gpu": B, "clip_samples": L, "sr": SR, "n_fft": N_FFT, "hop": HOP,
-                       "n_mels": N_MELS, "n_mfcc": N_MFCC, "parallelism": f"clip-sharded x{world}" +
-                       (f", two-launch form on all but {reserve} CUs, asynchronous RCCL gather to rank 0 in the timed "
-                        f"region" if world > 1 else ", one launch per step")},
+            "config": {"workload": workload, "clips_per_gpu": B, "clip_samples": L, "sr": SR, "n_fft": N_FFT, "hop": HOP,
+                       "n_mels": N_MELS, "n_mfcc": N_MFCC, "rows_per_clip": rows, "parallelism": par},
             "hbm_roofline_frac_whole_step": round(job_bytes / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "roofline": roof, "cpu_baseline": cpu,
         }

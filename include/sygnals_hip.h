@@ -10,7 +10,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
  *   - the caller owns every buffer (inputs, outputs, tables, workspaces); the library
- *     allocates nothing and keeps no global state besides a thread-local error string;
+ *     allocates nothing; its only state is a thread-local error string (no caches keyed by shape or
+ *     device: kernel attributes are set at every launch, the CU count is queried per call);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
  *     enqueue work on it and never synchronise;
  *   - return value: 0 on success, negative SYG_E_* on error, message via syg_last_error();
@@ -35,6 +36,9 @@ extern "C" {
 #define SYG_E_UNSUPPORTED (-3)
 
 int syg_abi_version(void);
+/* 0 = product build; non-zero = a development variant (ablation / in-kernel timeline builds, -DSYG_ABL=n) whose
+ * results are wrong by design: a binding must refuse to use such a library. */
+int syg_build_variant(void);
 const char* syg_last_error(void);
 
 /* ---------------------------------------------------------------------------------

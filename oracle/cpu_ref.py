@@ -849,10 +849,18 @@ def _nan_pad(a, T):
 
 def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=True,
                      window="hann", feature_params=None, per_frame_loop=False):
-    """Oracle for the spectrum / spectrogram / mel feature groups (dict_of_arrays).
+    """Oracle for manager.py:78-445 (dict_of_arrays), features processed IN THE ORDER GIVEN as the reference does:
 
-    ``per_frame_loop=True`` drives a6/a7/a9 one frame at a time exactly as
-    manager.py:304-316 does (used for the 'reference-equivalent' CPU timing).
+    * `time` starts from the frame-count rule (:149-169); the first feature that needs the STFT computes it, and
+      when the STFT has another frame count (odd frame_length with hop | len(y)) `time` is re-made from the STFT
+      (:186-194);
+    * every feature array is NaN-padded / cut to the frame count current WHEN IT IS PROCESSED (:376-387);
+    * `spectral_bandwidth` without an earlier `spectral_centroid` stores the centroid it depends on as an output
+      column of its own (:296-301);
+    * rows whose length differs from the final `time` are dropped (:408-420).
+
+    ``per_frame_loop=True`` drives a6/a7/a9 one frame at a time exactly as manager.py:304-316 does (used for the
+    'reference-equivalent' CPU timing).
     """
     feature_params = feature_params or {}
     y = np.asarray(y, dtype=np.float64)
@@ -865,22 +873,39 @@ def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=
     if T <= 0:
         return {"time": np.array([], dtype=np.float64)}
     res = {"time": frames_to_time(np.arange(T), sr, hop_length, frame_length if center else None).astype(np.float64)}
-    S_mag = np.abs(stft(y, frame_length, hop_length, frame_length, window, center))
     freqs = fft_frequencies(sr, frame_length)
+    box = {}
+
+    def s_mag():
+        if "S" not in box:
+            box["S"] = np.abs(stft(y, frame_length, hop_length, frame_length, window, center))
+            if box["S"].shape[1] != len(res["time"]):                     # manager.py:186-194
+                res["time"] = frames_to_time(np.arange(box["S"].shape[1]), sr, hop_length, frame_length).astype(np.float64)
+        return box["S"]
+
     stats = None
     tstats = None
+    done = set()
     for name in features:
+        if name in done:
+            continue
         p = feature_params.get(name, {})
+        cur = len(res["time"])
         if name in TIME_FEATURES:
             if tstats is None:
                 tstats = time_features_frames(y, frame_length, hop_length, center,
                                               feature_params.get("signal_entropy", {}).get("num_bins", 10))
-            res[name] = _nan_pad(tstats[name], T)
+            res[name] = _nan_pad(tstats[name], cur)
         elif name == "rms_energy":
-            res[name] = _nan_pad(rms_energy(y, frame_length=frame_length, hop_length=hop_length, center=center), T)
+            res[name] = _nan_pad(rms_energy(y, frame_length=frame_length, hop_length=hop_length, center=center), cur)
         elif name == "zero_crossing_rate":
-            res[name] = _nan_pad(zero_crossing_rate(y, frame_length, hop_length, center), T)
+            res[name] = _nan_pad(zero_crossing_rate(y, frame_length, hop_length, center), cur)
         elif name in SPECTRUM_FEATURES:
+            S_mag = s_mag()
+            if name == "spectral_bandwidth" and "spectral_centroid" not in res:     # manager.py:296-301
+                res["spectral_centroid"] = np.array([spectral_centroid(S_mag[:, i], freqs) for i in range(S_mag.shape[1])],
+                                                    dtype=np.float64)
+                done.add("spectral_centroid")
             if per_frame_loop:
                 fn = {"spectral_centroid": spectral_centroid, "spectral_bandwidth": spectral_bandwidth,
                       "spectral_flatness": spectral_flatness, "spectral_rolloff": spectral_rolloff,
@@ -898,20 +923,23 @@ def extract_features(y, sr, features, frame_length=2048, hop_length=512, center=
                         p=feature_params.get("spectral_bandwidth", {}).get("p", 2))
                 res[name] = stats[name]
         elif name == "spectral_contrast":
+            S_mag = s_mag()
             C = spectral_contrast(S_mag, sr, freqs=freqs, **p)
             for i in range(C.shape[0] - 1):
                 res[f"contrast_band_{i}"] = C[i]
             res["contrast_delta"] = C[-1]
         elif name == "mfcc":
             mp = feature_params.get("mfcc", {})
-            M = melspectrogram(S_mag ** mp.get("power", 2.0), sr, frame_length, mp.get("n_mels", 128),
+            M = melspectrogram(s_mag() ** mp.get("power", 2.0), sr, frame_length, mp.get("n_mels", 128),
                                mp.get("fmin", 0.0), mp.get("fmax", sr / 2.0))
             Ldb = power_to_db(M, ref=np.max)
             C = mfcc(S=Ldb, sr=sr, n_mfcc=mp.get("n_mfcc", 13), dct_type=mp.get("dct_type", 2),
                      norm=mp.get("norm", "ortho"), lifter=mp.get("lifter", 0.0))
             for i in range(C.shape[0]):
                 res[f"mfcc_{i}"] = C[i]
-    return res
+        done.add(name)
+    final_T = len(res["time"])
+    return {k: v for k, v in res.items() if k == "time" or len(v) == final_T}     # manager.py:408-420
 
 
 # --------------------------------------------------------------------------

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsygnals_hip.so")
+# SYGNALS_AMD_LIB: development only (tools/ablate.sh, timeline builds) -- a library built somewhere else
+LIB_PATH = os.environ.get("SYGNALS_AMD_LIB") or os.path.join(_HERE, "lib", "libsygnals_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int
@@ -20,6 +21,7 @@ _d = C.c_double
 # name -> (restype, argtypes); must list every symbol declared in include/sygnals_hip.h
 SIGNATURES = {
     "syg_abi_version": (_i, []),
+    "syg_build_variant": (_i, []),
     "syg_last_error": (C.c_char_p, []),
     "syg_stft2048_mel_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p, _i, _p, _f, _f, _f, _i, _p, _p, _p, _p]),
     "syg_stft2048_c2c_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p]),
@@ -82,6 +84,10 @@ def lib() -> C.CDLL:
         ver = h.syg_abi_version()
         if ver != 1:
             raise SygnalsHipError(f"libsygnals_hip.so ABI version {ver} != 1")
+        var = h.syg_build_variant()
+        if var != 0 and os.environ.get("SYGNALS_AMD_ALLOW_VARIANT") != str(var):
+            raise SygnalsHipError(f"{LIB_PATH} is a development variant (SYG_ABL={var}: results wrong by design); "
+                                  "rebuild the product library with build_lib.sh")
         _lib = h
     return _lib
 

@@ -100,6 +100,9 @@ def compute_stft(y, n_fft: int = 2048, hop_length: Optional[int] = None, win_len
     return np.ascontiguousarray(_c128(X)[0].T).astype(np.complex128, copy=False)   # [F, T] like librosa
 
 
+_cqt_warned = False
+
+
 def compute_cqt(y, sr: int, hop_length: Optional[int] = 512, fmin: Optional[float] = None, n_bins: int = 84,
                 bins_per_octave: int = 12, **kwargs) -> np.ndarray:
     """Constant-Q transform, complex128 [n_bins, 1 + len(y)//hop_length] (dsp.py:231-289).
@@ -115,7 +118,19 @@ def compute_cqt(y, sr: int, hop_length: Optional[int] = 512, fmin: Optional[floa
     for k, v in fixed.items():
         if k in kwargs and kwargs.pop(k) != v:
             raise SygnalsHipError(f"compute_cqt: only {k}={v!r} runs on the device")
-    kwargs.pop("res_type", None)
+    # APPROXIMATE ROW: librosa decimates between octaves with its default res_type='soxr_hq'; the device
+    # (and this repository's oracle) use a 41-tap Kaiser half-band FIR (= scipy.signal.resample_poly(x, 1, 2)).  An
+    # explicit request for any other resampler cannot be honoured and is refused rather than silently dropped.
+    res_type = kwargs.pop("res_type", None)
+    if res_type not in (None, "kaiser_halfband"):
+        raise SygnalsHipError(f"compute_cqt: res_type={res_type!r} is not available on the device; the octave "
+                              "decimator is a fixed 41-tap Kaiser half-band FIR (res_type='kaiser_halfband')")
+    global _cqt_warned
+    if res_type is None and not _cqt_warned:
+        _cqt_warned = True
+        logger.warning("compute_cqt: the device path decimates with a 41-tap Kaiser half-band FIR, not librosa's "
+                       "default res_type='soxr_hq'; values differ from librosa.cqt at the resampler's accuracy "
+                       "(pass res_type='kaiser_halfband' to acknowledge)")
     tuning = kwargs.pop("tuning", 0.0)
     filter_scale = kwargs.pop("filter_scale", 1.0)
     sparsity = kwargs.pop("sparsity", 0.01)

@@ -59,6 +59,13 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     """Batched extract_features: y [B, L] (array or device tensor) -> {'time': [T], name: [B, T]}.
 
     With to_host=False the per-feature values stay on the device as float32 tensors.
+
+    The per-feature semantics are the reference's (manager.py:242-397): features are processed in the order given;
+    a failing feature is logged and skipped, the others still come out (:394-397); `spectral_bandwidth` requested
+    without `spectral_centroid` also emits the centroid it depends on (:296-301); when the STFT has fewer frames
+    than the frame-count rule (odd frame_length, :186-194) `time` is re-made from the STFT frame count and rows
+    of another length are dropped by the final length check (:408-420).  What is NOT per feature: a missing HIP
+    library or GPU raises before anything is computed (no CPU fallback).
     """
     feature_params = feature_params or {}
     if features == ["all"]:
@@ -66,9 +73,7 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     unknown = [f for f in features if f not in _ALL_KNOWN_FEATURES]
     if unknown:
         raise ValueError(f"Unknown feature(s) requested: {unknown}. Available: {sorted(_ALL_KNOWN_FEATURES)}")
-    host_only = [f for f in features if f in _REFERENCE_ONLY]
-    if host_only:
-        raise SygnalsHipError(f"feature(s) {host_only} are not offloaded to the device backend")
+    ops.require_gpu()
     yd = y if hasattr(y, "is_cuda") else ops.to_device_f32(np.asarray(y))
     if yd.dim() != 2:
         raise ValueError("Batched input 'y' must have shape [B, L].")
@@ -88,109 +93,160 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
     want_contrast = "spectral_contrast" in features
     want_mfcc = "mfcc" in features
     mp = feature_params.get("mfcc", {})
-    n_mels = mp.get("n_mels", 128)
-    fmin, fmax = mp.get("fmin", 0.0), mp.get("fmax", sr / 2.0)
-    power = mp.get("power", 2.0)
-    roll = feature_params.get("spectral_rolloff", {}).get("roll_percent", 0.85)
-    bw_p = float(feature_params.get("spectral_bandwidth", {}).get("p", 2))
-    if not 0.0 <= roll <= 1.0:
-        raise ValueError("roll_percent must be between 0.0 and 1.0.")
-    if bw_p <= 0:
-        raise ValueError("Order 'p' for spectral bandwidth must be positive.")
-    freqs = np.fft.rfftfreq(frame_length, 1.0 / sr)
-    cplan = None
     cp = feature_params.get("spectral_contrast", {})
-    if want_contrast:
-        cplan = T.contrast_plan(freqs, sr, cp.get("n_bands", 6), cp.get("fmin", 200.0), cp.get("quantile", 0.02))
+    freqs = np.fft.rfftfreq(frame_length, 1.0 / sr)
 
-    tstats = None
-    want_time = [f for f in features if f in _FRAME_BASED]
-    if want_time:
-        from .time_domain import time_features_frames
-        nb = int(feature_params.get("signal_entropy", {}).get("num_bins", 10))
-        tstats = time_features_frames(yd, frame_length, hop_length, center, nb, want_time)
-        # the reference frames the signal padded by frame_length // 2 on both sides (manager.py:268-271, librosa's
-        # rms / zcr likewise): with an ODD frame_length that is one sample short of the last frame whenever hop
-        # divides len(y), and the missing value is NaN-padded (manager.py:378-386).  Same observable result here.
-        if center:
-            t_ref = 1 + (L + 2 * (frame_length // 2) - frame_length) // hop_length
-            if t_ref < Tn:
-                for v in tstats.values():
-                    v[:, t_ref:] = float("nan")
-    need_stft = bool(want_stats or want_contrast or want_mfcc)
+    # ---- lazy device products, computed once and shared (the reference's _S_mag / _S_mel_log caches, :173-227)
+    cache: Dict[str, Any] = {}
 
-    mel = stats = cpv = None
-    t_stft = Tn
-    try:
-        if not need_stft:
-            pass
-        elif frame_length == 2048 and power == 2.0 and n_mels <= 16 * ops.fused_waves():
-            mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
-                                               fmin, fmax, want_stats, roll, bw_p, cplan)
-        else:
-            X = ops.stft_any(yd, frame_length, hop_length, center, window)
-            F = X.shape[2]
-            if X.shape[1] < Tn:
-                # odd frame_length: the centred STFT has one frame less than the manager's frame count whenever hop
-                # divides len(y); the reference NaN-pads rows that come out short (manager.py:378-386), as above
-                t_stft = X.shape[1]
-                X = torch.cat([X, torch.zeros((B, Tn - t_stft, F, 2), dtype=X.dtype, device=X.device)], dim=1)
-            if want_stats or want_contrast:
-                mag = ops.cabs_pow(X, 1).reshape(B * Tn, F)
-                if want_stats:
-                    stats = ops.spectral_stats(mag, ops.to_device_f32(freqs), roll, bw_p).reshape(8, B, Tn).permute(1, 0, 2)
-                if want_contrast:
-                    R = int(cplan[0])
-                    cpv = ops.contrast_pv(mag, cplan).reshape(2, R, B, Tn).permute(2, 0, 1, 3).contiguous()
-            if want_mfcc:
-                if power not in (1.0, 2.0):
-                    raise SygnalsHipError("mel power must be 1.0 or 2.0 on the device")
-                P = ops.cabs_pow(X, int(power))
-                mel = ops.mel_dense(P, ops.mel_config(sr, frame_length, n_mels, fmin, fmax).basis)
-    except SygnalsHipError:
-        raise
-    except Exception as e:  # mirrors manager.py:201-202, 225-226
-        raise FeatureExtractionError(f"Error calculating STFT: {e}")
+    def time_rows():
+        if "tstats" not in cache:
+            from .time_domain import time_features_frames
+            want_time = [f for f in features if f in _FRAME_BASED]
+            nb = int(feature_params.get("signal_entropy", {}).get("num_bins", 10))
+            tstats = time_features_frames(yd, frame_length, hop_length, center, nb, want_time)
+            # the reference frames the signal padded by frame_length // 2 on both sides (manager.py:268-271, librosa's
+            # rms / zcr likewise): with an ODD frame_length that is one sample short of the last frame whenever hop
+            # divides len(y); those rows come out one frame short and are NaN-padded (manager.py:378-386)
+            t_rows = Tn
+            if center:
+                t_rows = min(Tn, 1 + (L + 2 * (frame_length // 2) - frame_length) // hop_length)
+            cache["tstats"] = ({k: v[:, :t_rows] for k, v in tstats.items()}, t_rows)
+        return cache["tstats"]
+
+    def stft_products():
+        """(mel power | None, stats | None, contrast tail means | None, STFT frame count): ONE fused launch for
+        frame_length 2048; an STFT failure is remembered and re-raised for every feature that needs it."""
+        if "stft" in cache:
+            if isinstance(cache["stft"], Exception):
+                raise cache["stft"]
+            return cache["stft"]
+        try:
+            n_mels = mp.get("n_mels", 128)
+            fmin, fmax = mp.get("fmin", 0.0), mp.get("fmax", sr / 2.0)
+            power = mp.get("power", 2.0)
+            roll = feature_params.get("spectral_rolloff", {}).get("roll_percent", 0.85)
+            bw_p = float(feature_params.get("spectral_bandwidth", {}).get("p", 2))
+            if not 0.0 <= roll <= 1.0:
+                raise ValueError("roll_percent must be between 0.0 and 1.0.")
+            if bw_p <= 0:
+                raise ValueError("Order 'p' for spectral bandwidth must be positive.")
+            cplan = None
+            if want_contrast:
+                cplan = T.contrast_plan(freqs, sr, cp.get("n_bands", 6), cp.get("fmin", 200.0), cp.get("quantile", 0.02))
+            mel = stats = cpv = None
+            if frame_length == 2048 and power == 2.0 and n_mels <= 16 * ops.fused_waves():
+                mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
+                                                   fmin, fmax, want_stats, roll, bw_p, cplan)
+                t_stft = Tn
+            else:
+                X = ops.stft_any(yd, frame_length, hop_length, center, window)
+                t_stft, F = X.shape[1], X.shape[2]
+                if want_stats or want_contrast:
+                    mag = ops.cabs_pow(X, 1).reshape(B * t_stft, F)
+                    if want_stats:
+                        stats = ops.spectral_stats(mag, ops.to_device_f32(freqs), roll, bw_p).reshape(8, B, t_stft).permute(1, 0, 2)
+                    if want_contrast:
+                        R = int(cplan[0])
+                        cpv = ops.contrast_pv(mag, cplan).reshape(2, R, B, t_stft).permute(2, 0, 1, 3).contiguous()
+                if want_mfcc:
+                    if power not in (1.0, 2.0):
+                        raise SygnalsHipError("mel power must be 1.0 or 2.0 on the device")
+                    P = ops.cabs_pow(X, int(power))
+                    mel = ops.mel_dense(P, ops.mel_config(sr, frame_length, n_mels, fmin, fmax).basis)
+        except Exception as e:  # mirrors manager.py:201-202, 225-226 (raised inside the per-feature try there too)
+            cache["stft"] = FeatureExtractionError(f"Error calculating STFT: {e}")
+            raise cache["stft"]
+        if t_stft != len(res["time"]):
+            # manager.py:186-194: the STFT's own frame count wins and `time` is re-made from it
+            logger.warning(f"STFT frames ({t_stft}) mismatch calculated frame times ({len(res['time'])}). "
+                           f"Adjusting frame count and times to match STFT output.")
+            res["time"] = ((np.arange(t_stft) * hop_length + frame_length // 2) / float(sr)).astype(np.float64)
+        cache["stft"] = (mel, stats, cpv, t_stft)
+        return cache["stft"]
 
     def host(t):
         return t.cpu().numpy().astype(np.float64) if to_host else t
 
-    def short(v):                                   # STFT-based rows past the last frame the STFT has
-        if t_stft < Tn:
-            v = v.astype(np.float64) if isinstance(v, np.ndarray) else v.clone().float()
-            v[:, t_stft:] = float("nan")
-        return v
+    def fit(name, v, n):
+        """Pad with NaN / truncate a [B, len] row block to n frames (manager.py:376-387)."""
+        have = v.shape[1]
+        if have == n:
+            return v
+        logger.warning(f"Feature '{name}' array length ({have}) mismatch expected frames ({n}). Adjusting length "
+                       f"(padding with NaN or truncating).")
+        if have > n:
+            return v[:, :n]
+        if isinstance(v, np.ndarray):
+            out = np.full((v.shape[0], n), np.nan, dtype=np.float64)
+            out[:, :have] = v
+            return out
+        out = torch.full((v.shape[0], n), float("nan"), dtype=torch.float32, device=v.device)
+        out[:, :have] = v
+        return out
 
+    processed = set()
     for name in features:
-        if name in res:
+        if name in processed:
             continue
-        if name in _FRAME_BASED:
-            res[name] = host(tstats[name])
-        elif name in _SPECTRUM_BASED:
-            if name == "spectral_centroid":
-                res[name] = short(host(stats[:, 0]))
-            elif name == "spectral_bandwidth":
-                res[name] = short(host(stats[:, 1]))
-            elif name == "spectral_flatness":
-                res[name] = short(host(stats[:, 2]))
-            elif name == "spectral_rolloff":
-                idx = stats[:, 3].cpu().numpy().astype(np.int64)
-                res[name] = short(freqs[idx] if to_host else stats[:, 3] * float(sr / frame_length))
-            elif name == "dominant_frequency":
-                idx = stats[:, 4].cpu().numpy().astype(np.int64)
-                res[name] = short(freqs[idx] if to_host else stats[:, 4] * float(sr / frame_length))
-        elif name == "spectral_contrast":
-            cdb, host_c = ops.contrast_db(cpv, linear=bool(cp.get("linear", False))), host
-            R = cdb.shape[1]
-            for i in range(R - 1):
-                res[f"contrast_band_{i}"] = short(host_c(cdb[:, i]))
-            res["contrast_delta"] = short(host_c(cdb[:, R - 1]))
-        elif name == "mfcc":
-            _, mf = ops.logmel_dct(mel, mp.get("n_mfcc", 13), mp.get("dct_type", 2), mp.get("norm", "ortho"),
-                                   float(mp.get("lifter", 0.0)), ref="max")
-            for i in range(mf.shape[1]):
-                res[f"mfcc_{i}"] = short(host(mf[:, i]))
-    return res
+        try:
+            items = []
+            cur_T = len(res["time"])
+            if name in _REFERENCE_ONLY:
+                raise SygnalsHipError(f"feature '{name}' is not offloaded to the device backend")
+            if name in _FRAME_BASED:
+                rows, _ = time_rows()
+                items.append((name, host(rows[name])))
+            elif name in _SPECTRUM_BASED:
+                _, stats, _, cur_T = stft_products()
+                if name == "spectral_bandwidth" and "spectral_centroid" not in res:
+                    logger.warning("Feature 'spectral_bandwidth' requires 'spectral_centroid', calculating it first.")
+                    res["spectral_centroid"] = host(stats[:, 0])
+                    processed.add("spectral_centroid")
+                if name == "spectral_centroid":
+                    items.append((name, host(stats[:, 0])))
+                elif name == "spectral_bandwidth":
+                    items.append((name, host(stats[:, 1])))
+                elif name == "spectral_flatness":
+                    items.append((name, host(stats[:, 2])))
+                else:
+                    row = 3 if name == "spectral_rolloff" else 4
+                    if to_host:
+                        items.append((name, freqs[stats[:, row].cpu().numpy().astype(np.int64)]))
+                    else:
+                        items.append((name, stats[:, row] * float(sr / frame_length)))
+            elif name == "spectral_contrast":
+                _, _, cpv, cur_T = stft_products()
+                cdb = ops.contrast_db(cpv, linear=bool(cp.get("linear", False)))
+                R = cdb.shape[1]
+                for i in range(R - 1):
+                    items.append((f"contrast_band_{i}", host(cdb[:, i])))
+                items.append(("contrast_delta", host(cdb[:, R - 1])))
+            elif name == "mfcc":
+                mel, _, _, cur_T = stft_products()
+                _, mf = ops.logmel_dct(mel, mp.get("n_mfcc", 13), mp.get("dct_type", 2), mp.get("norm", "ortho"),
+                                       float(mp.get("lifter", 0.0)), ref="max", keep_mel=True)
+                for i in range(mf.shape[1]):
+                    items.append((f"mfcc_{i}", host(mf[:, i])))
+            for nm, arr in items:
+                res[nm] = fit(nm, arr, cur_T)
+                processed.add(nm)
+            processed.add(name)
+        except Exception as e:                       # manager.py:394-397: log and continue with the next feature
+            logger.error(f"Error extracting feature '{name}': {e}")
+
+    # manager.py:401-420: only rows whose length equals the final frame count survive
+    final_T = len(res["time"])
+    out: Dict[str, Any] = {"time": res["time"]}
+    for nm, arr in res.items():
+        if nm == "time":
+            continue
+        if arr.shape[1] == final_T:
+            out[nm] = arr
+        else:
+            logger.error(f"Internal Error: Final length mismatch for feature '{nm}' ({arr.shape[1]} vs {final_T}). "
+                         f"Skipping feature in output.")
+    return out
 
 
 def extract_features(y, sr: int, features: List[str], frame_length: int = 2048, hop_length: int = 512,
@@ -225,3 +281,40 @@ def extract_features(y, sr: int, features: List[str], frame_length: int = 2048, 
     df = pd.DataFrame(final, index=idx)
     df.index.name = "time"
     return df
+
+
+# ------------------------------------------------------------------ config C4: the packed per-clip feature block
+def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: int = 13, roll_percent: float = 0.85,
+                  n_bands: int = 6, fmin_contrast: float = 200.0, quantile: float = 0.02, out=None):
+    """BASELINE config C4 on the device: y [B, L] float32 device clips -> [B, n_mfcc + 2 + (n_bands + 1), T] float32,
+    rows = mfcc_0..mfcc_{n-1}, spectral_centroid (Hz), spectral_rolloff (Hz), contrast_band_0..{n_bands-1},
+    contrast_delta -- the columns `extract_features(["mfcc", "spectral_centroid", "spectral_rolloff",
+    "spectral_contrast"])` returns (manager.py:289-371), one dense block per rank for the gather to rank 0
+    ([B/W, 22, 94]).  frame_length 2048 (the fused kernel)."""
+    ops.require_gpu()
+    B, L = y.shape
+    Tn = ops.num_frames(L, 2048, hop_length, True)
+    freqs = np.fft.rfftfreq(2048, 1.0 / sr)
+    cplan = ops._cached(("cplan", float(sr), n_bands, float(fmin_contrast), float(quantile)),
+                        lambda: T.contrast_plan(freqs, sr, n_bands, fmin_contrast, quantile))
+    R = int(cplan[0])
+    rows = n_mfcc + 2 + R
+    if out is None:
+        out = torch.empty((B, rows, Tn), dtype=torch.float32, device=y.device)
+    mel, stats, cpv = ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8, roll_percent,
+                                       2.0, cplan)
+    _, mf = ops.logmel_dct(mel, n_mfcc)
+    out[:, :n_mfcc] = mf
+    out[:, n_mfcc] = stats[:, 0]
+    torch.mul(stats[:, 3], float(sr) / 2048.0, out=out[:, n_mfcc + 1])        # bin index -> Hz (exact in float32)
+    out[:, n_mfcc + 2:] = ops.contrast_db(cpv)
+    return out
+
+
+def feature_block_dominant(y, sr, hop_length, n_mels, n_mfcc):
+    """(name, callable, feature rows it carries) of the dominant kernel of feature_block (bench.py's roofline leg)."""
+    freqs = np.fft.rfftfreq(2048, 1.0 / sr)
+    cplan = T.contrast_plan(freqs, sr)
+    return ("stft2048_kernel<16,2,1> (16 waves, staged tiles, mel + centroid + rolloff + contrast tail means)",
+            lambda: ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8, 0.85, 2.0, cplan),
+            n_mels + 3 + 2 * int(cplan[0]))

@@ -12,5 +12,11 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace syg
 
+#ifndef SYG_ABL
+#define SYG_ABL 0
+#endif
 extern "C" int syg_abi_version(void) { return SYG_ABI_VERSION; }
+// 0 for the product build; the SYG_ABL number of a development build (ablation / timeline variants compute WRONG
+// results by design; build_lib.sh writes them to their own path and the Python binding refuses to load one)
+extern "C" int syg_build_variant(void) { return SYG_ABL; }
 extern "C" const char* syg_last_error(void) { return syg::g_err; }

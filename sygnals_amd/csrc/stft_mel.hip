@@ -995,14 +995,12 @@ constexpr size_t lds_bytes() {
 // receive workgroups while the previous batch is gathered -- either waits for a whole launch or makes this launch wait
 // for it (tools/queue_bench.py: 167 -> 256 us for every second launch).  With the CUs set aside both run side by side.
 void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  // the CU count of the CURRENT device, asked at every call (an attribute query, no device properties round trip):
+  // no process-wide cache that a second device or a second thread could read stale
+  int n_cu = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+    n_cu = 256;
   int use_cu = n_cu;
   if (const char* e = getenv("SYGNALS_AMD_RESERVE_CUS")) {
     const int r = atoi(e);
@@ -1015,14 +1013,10 @@ void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
   wgs = (int)((total_tiles + p - 1) / p);
 }
 
-// SYGNALS_AMD_LOAD = 0 | 1 | 2 forces the frame load path (development aid); default: staged tiles
+// SYGNALS_AMD_LOAD = 0 | 1 | 2 forces the frame load path (development aid, read at every call); default: staged tiles
 int load_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("SYGNALS_AMD_LOAD");
-    mode = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
-  }
-  return mode;
+  const char* e = getenv("SYGNALS_AMD_LOAD");
+  return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
 }
 
 int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
@@ -1071,15 +1065,15 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   const int dma_wide = (hop % 4 == 0) && (pad % 4 == 0) && (ldy % 4 == 0) && (L % 4 == 0) && (((uintptr_t)y) % 16 == 0);
   auto kern = load == 2 ? stft2048_kernel<WAVES, 2, MODE>
                         : load == 1 ? stft2048_kernel<WAVES, 1, MODE> : stft2048_kernel<WAVES, 0, MODE>;
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[load]) {
+  {
+    // set at every launch: the attribute belongs to the (function, device) pair, and a per-process "already set"
+    // flag would leave a second device without it
     const size_t cap = (MODE == 3) ? LDS_LIMIT : lds_bytes<WAVES>();
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
       return SYG_E_LAUNCH;
     }
-    attr_set[load] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(WAVES * 64), lds, st, y, L, ldy, hop, pad, T,
                      tiles, total_tiles, per, (const float2*)window, (const float2*)twiddle, wpacked, plan, n_mels,

@@ -746,9 +746,16 @@ def fft_any(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     rows, n, _ = x.shape
     if n == 1:
         return x.clone()
+    if rows > MAX_ROWS and n > MAX_LDS_FFT:
+        # the four-step passes put the rows on a grid axis of at most 65535: long transforms of very many rows go
+        # through in blocks (without this a Bluestein length above 8192 would recurse on the same row count)
+        out = torch.empty_like(x)
+        for r0 in range(0, rows, MAX_ROWS):
+            out[r0:r0 + MAX_ROWS] = fft_any(x[r0:r0 + MAX_ROWS], inverse)
+        return out
     if is_pow2(n):
         return fft_pow2_any(x, inverse)
-    if _is_smooth(n) and smooth_split(n) is not None and (n <= MAX_MIXED_FFT or rows <= MAX_ROWS):
+    if _is_smooth(n) and smooth_split(n) is not None:
         return fft_smooth(x, inverse)
     m, fwd, inv = _cached(("blue", n), lambda: _bluestein_tables(n))
     w_in, bf, w_out = inv if inverse else fwd

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 from oracle import cpu_ref as O
-from tests.gpu_util import assert_parity, peak_rel
+from tests.gpu_util import assert_contrast_parity, assert_parity, fft_floor, peak_rel
 
 TOL = 1e-5
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -127,7 +127,7 @@ def test_per_frame_feature_functions_vs_reference_golden():
         assert abs(fd.spectral_bandwidth(s, fr) - g["bandwidth"][i]) <= TOL * g["bandwidth"].max()
         assert abs(fd.spectral_bandwidth(s, fr, p=1) - g["bandwidth_p1"][i]) <= TOL * g["bandwidth_p1"].max()
         assert abs(fd.spectral_bandwidth(s, fr, centroid=np.float64(5000.0)) - g["bandwidth_c"][i]) <= 2 * TOL * g["bandwidth_c"].max()
-        assert abs(fd.spectral_flatness(s) - g["flatness"][i]) <= 2e-5
+        assert abs(fd.spectral_flatness(s) - g["flatness"][i]) <= TOL * g["flatness"].max()
         assert fd.spectral_rolloff(s, fr) == g["rolloff85"][i]
         assert fd.spectral_rolloff(s, fr, roll_percent=0.5) == g["rolloff50"][i]
         assert fd.dominant_frequency(s, fr) == g["dominant"][i]
@@ -181,8 +181,6 @@ def test_extract_features_like_reference_manager_tests():
         if k in ("spectral_rolloff", "dominant_frequency"):
             m = st["rolloff_margin" if k == "spectral_rolloff" else "dominant_margin"] > 1e-6
             assert np.array_equal(d[k][m], ref[k][m]), k
-        elif k == "spectral_flatness":
-            assert_parity(d[k], ref[k], 2e-5, k)
         else:
             assert_parity(d[k], ref[k], TOL, k)
     df = extract_features(y, sr, ["mfcc", "spectral_centroid"])
@@ -279,15 +277,34 @@ def test_c4_share_full_size_batch_consistency():
         if k == "time":
             continue
         assert np.array_equal(big[k].reshape(128, 16, -1), np.broadcast_to(small[k], (128, 16, small[k].shape[1]))), k
-    ref = O.extract_features(Y[3].astype(np.float64), 48000, feats, feature_params=fp)
-    for k in ref:
-        if k == "time":
-            continue
-        tol = 1e-4 if k.startswith("contrast") else TOL
-        if k == "spectral_rolloff":
-            assert np.mean(small[k][3] == ref[k]) > 0.99
-        else:
-            assert peak_rel(small[k][3], ref[k]) <= tol, k
+    # the oracle on a sample of clips, at the north-star tolerance: bin-valued rolloff identical wherever the float64
+    # decision margin exceeds 1e-6 (<= 1 bin elsewhere), contrast dB margin-qualified against the fp32 FFT floor of
+    # the frame (tests/gpu_util.assert_contrast_parity), everything else 1e-5 peak-relative
+    fr = O.fft_frequencies(48000, 2048)
+    bands = O.contrast_bands(fr, 48000)
+    unsure = cells = flips = 0
+    for i in (3, 8, 14):
+        ref = O.extract_features(Y[i].astype(np.float64), 48000, feats, feature_params=fp)
+        S = np.abs(O.stft(Y[i].astype(np.float64), 2048, 512))
+        st = O.spectral_stats_frames(S, fr)
+        for k in ref:
+            if k == "time" or k.startswith("contrast"):
+                continue
+            if k == "spectral_rolloff":
+                sure = st["rolloff_margin"] > 1e-6
+                assert np.array_equal(small[k][i][sure], ref[k][sure]), "rolloff outside the decision margin"
+                assert (np.abs(small[k][i] - ref[k]) <= 48000 / 2048 + 1e-9).all()
+                flips += int((small[k][i] != ref[k]).sum())
+            else:
+                assert_parity(small[k][i], ref[k], TOL, k)
+        names = [f"contrast_band_{j}" for j in range(6)] + ["contrast_delta"]
+        valley = np.stack([np.sort(S[bins], axis=0)[:kk].mean(axis=0) for bins, kk in bands])
+        u, n = assert_contrast_parity(np.stack([small[k][i] for k in names]), np.stack([ref[k] for k in names]), valley,
+                                      fft_floor(S), TOL, f"C4 contrast clip {i}")
+        unsure += u; cells += n
+    print(f"C4 sample: rolloff bins inside the 1e-6 margin that differ: {flips}; contrast cells below the decision "
+          f"margin: {unsure} of {cells}")
+    assert unsure <= 0.10 * cells
 
 
 def test_c5_full_size_stream_welch_and_cqt():
@@ -345,7 +362,82 @@ def test_c3_full_size_filter_then_mfcc():
     small = ops.mfcc_batch(apply_sos_filter_batch(sos, ops.to_device_f32(Y)), 48000, n_mels=40, fused=True).cpu().numpy()
     assert out.shape == (1024, 13, 94)
     assert np.array_equal(out.reshape(64, 16, 13, 94), np.broadcast_to(small, (64, 16, 13, 94)))
-    for i in (0, 9):
+    for i in (0, 5, 9, 13):
         yf = O.apply_sos_filter(sos, Y[i].astype(np.float64))
         ref = O.mfcc_manager(yf, 48000, n_mels=40)
-        assert peak_rel(small[i], ref) <= 2e-5, i      # two fp32 stages in series (filter output rounded to fp32)
+        assert_parity(small[i], ref, TOL, f"C3 clip {i}")
+
+
+# ---- a16: the manager's per-feature semantics (manager.py:242-420), mirrored and checked against the oracle's
+# in-order restatement
+def test_bandwidth_alone_also_emits_the_centroid_it_depends_on():
+    """manager.py:296-301: 'spectral_bandwidth' without 'spectral_centroid' stores the centroid as a column too."""
+    from sygnals_amd.core.features.manager import extract_features
+    y = O.synth_clips(1, 8192, 16000, seed=5)[0].astype(np.float64)
+    out = extract_features(y, 16000, ["spectral_bandwidth", "mean_amplitude"], output_format="dict_of_arrays")
+    ref = O.extract_features(y, 16000, ["spectral_bandwidth", "mean_amplitude"])
+    assert list(out) == list(ref) == ["time", "spectral_centroid", "spectral_bandwidth", "mean_amplitude"]
+    for k in ref:
+        assert_parity(out[k], ref[k], TOL, k)
+    df = extract_features(y, 16000, ["spectral_bandwidth"])
+    assert list(df.columns) == ["spectral_centroid", "spectral_bandwidth"]
+
+
+def test_a_failing_feature_leaves_the_others_in_the_output(monkeypatch, caplog):
+    """manager.py:394-397: a feature that raises is logged and skipped; the rest of the call still comes out."""
+    import logging
+    from sygnals_amd import ops
+    from sygnals_amd.core.features import manager as M
+    y = O.synth_clips(1, 8192, 16000, seed=6)[0].astype(np.float64)
+
+    def boom(*a, **k):
+        raise RuntimeError("injected failure")
+
+    monkeypatch.setattr(ops, "contrast_db", boom)
+    with caplog.at_level(logging.ERROR):
+        out = M.extract_features(y, 16000, ["spectral_centroid", "spectral_contrast", "mfcc", "hnr", "rms_energy"],
+                                 output_format="dict_of_arrays", feature_params={"mfcc": {"n_mels": 40}})
+    assert "contrast_band_0" not in out and "hnr" not in out
+    assert {"spectral_centroid", "mfcc_0", "mfcc_12", "rms_energy"} <= set(out)
+    assert "Error extracting feature 'spectral_contrast': injected failure" in caplog.text
+    assert "Error extracting feature 'hnr'" in caplog.text
+    ref = O.extract_features(y, 16000, ["spectral_centroid", "mfcc", "rms_energy"], feature_params={"mfcc": {"n_mels": 40}})
+    for k in ref:
+        assert_parity(out[k], ref[k], TOL, k)
+    # every STFT-based feature failing (here: an invalid parameter) still returns the time-domain ones
+    out2 = M.extract_features(y, 16000, ["spectral_rolloff", "rms_energy"], output_format="dict_of_arrays",
+                              feature_params={"spectral_rolloff": {"roll_percent": 1.5}})
+    assert list(out2) == ["time", "rms_energy"]
+
+
+def test_odd_frame_length_retimes_from_the_stft_like_the_reference():
+    """manager.py:186-194 + 408-420: with an odd frame_length and hop | len(y) the STFT has one frame less than the
+    frame-count rule; `time` is re-made from it, rows computed BEFORE with the longer count are dropped by the final
+    length check, rows computed AFTER are cut to the new count."""
+    from sygnals_amd.core.features.manager import extract_features
+    y = O.synth_clips(1, 4096, 16000, seed=2)[0].astype(np.float64)
+    feats = ["mean_amplitude", "spectral_centroid", "rms_energy", "mfcc"]
+    kw = dict(frame_length=1023, hop_length=256, feature_params={"mfcc": {"n_mels": 32}})
+    out = extract_features(y, 16000, feats, output_format="dict_of_arrays", **kw)
+    ref = O.extract_features(y, 16000, feats, **kw)
+    assert len(ref["time"]) == 16 and "mean_amplitude" not in ref and "rms_energy" in ref
+    assert list(out) == list(ref)
+    for k in ref:
+        assert out[k].shape == ref[k].shape and not np.isnan(out[k]).any()
+        assert_parity(out[k], ref[k], TOL, k)
+
+
+def test_c4_feature_block_equals_the_manager_columns():
+    """feature_block (the [B, 22, 94] block config C4 gathers) holds exactly the manager's columns, in order."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.features.manager import extract_features_batch, feature_block
+    Y = O.synth_clips(6, 48000, 48000, seed=41)
+    blk = feature_block(ops.to_device_f32(Y), 48000).cpu().numpy()
+    assert blk.shape == (6, 22, 94)
+    feats = ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]
+    d = extract_features_batch(Y, 48000, feats, feature_params={"mfcc": {"n_mels": 40}})
+    names = [k for k in d if k != "time"]
+    assert names == [f"mfcc_{i}" for i in range(13)] + ["spectral_centroid", "spectral_rolloff"] + \
+        [f"contrast_band_{i}" for i in range(6)] + ["contrast_delta"]
+    for r, k in enumerate(names):
+        assert np.array_equal(blk[:, r].astype(np.float64), d[k]), k

@@ -346,14 +346,14 @@ def test_extract_features_with_odd_frame_length():
     want = O.extract_features(y, sr, feats, frame_length=1000, hop_length=250)
     for k in ("mfcc_0", "mfcc_5", "mfcc_12", "spectral_centroid", "spectral_bandwidth", "rms_energy"):
         assert_parity(got[k], want[k], TOL, k)
-    # odd frame_length, hop dividing len(y): the centred STFT is one frame short of the manager's count; the missing
-    # value is NaN (the reference pads rows that come out short, manager.py:378-386)
+    # odd frame_length, hop dividing len(y): the centred STFT is one frame short of the manager's frame-count rule;
+    # the reference then re-makes `time` from the STFT's own frame count (manager.py:186-194) -- no NaN padding
     got = extract_features(y, sr, ["spectral_centroid", "mfcc"], frame_length=999, hop_length=250, output_format="dict_of_arrays")
     want = O.extract_features(y, sr, ["spectral_centroid", "mfcc"], frame_length=999, hop_length=250)
-    T = len(got["time"])
-    assert len(want["spectral_centroid"]) == T - 1 and np.isnan(got["spectral_centroid"][-1]) and np.isnan(got["mfcc_3"][-1])
-    assert_parity(got["spectral_centroid"][:-1], want["spectral_centroid"], TOL, "odd centroid")
-    assert_parity(got["mfcc_3"][:-1], want["mfcc_3"], TOL, "odd mfcc")
+    assert len(got["time"]) == len(want["time"]) == 24000 // 250 and np.array_equal(got["time"], want["time"])
+    assert list(got) == list(want)
+    assert_parity(got["spectral_centroid"], want["spectral_centroid"], TOL, "odd centroid")
+    assert_parity(got["mfcc_3"], want["mfcc_3"], TOL, "odd mfcc")
 
 
 @pytest.mark.parametrize("n", [2, 3, 5, 6, 7, 10, 12, 15, 21, 30, 35, 49, 100, 105, 240, 375, 441, 1000, 1500, 2401, 3000,

@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 from oracle import cpu_ref as O
-from tests.gpu_util import assert_parity, peak_rel
+from tests.gpu_util import assert_contrast_parity, assert_parity, fft_floor, peak_rel
 
 TOL = 1e-5  # fp32 parity tolerance stated by BASELINE.json north_star
 
@@ -70,8 +70,7 @@ def test_mfcc_degenerate_clips(ops):
     assert_parity(out[0], ref[0], TOL, "all-zero clip")   # amin/amin -> 0 dB everywhere
     assert_parity(out[1], ref[1], TOL, "impulse")
     assert_parity(out[2], ref[2], TOL, "dc")
-    # pure sine: bands far below the peak sit at the fp32 noise floor before the 80 dB clamp
-    assert_parity(out[3], ref[3], 5e-4, "sine (fp32 floor vs float64 floor under top_db)")
+    assert_parity(out[3], ref[3], TOL, "pure sine")
 
 
 @pytest.mark.parametrize("L,hop,center", [(100, 512, True), (2048, 512, False), (5000, 160, True),
@@ -156,6 +155,7 @@ def test_spectral_contrast_matches_oracle(ops, clips):
     _, _, _pv_dev = ops.stft2048_mel(y, 48000, n_mels=40, contrast=plan)
     pv = _pv_dev.cpu().numpy()
     cdb = ops.contrast_db(_pv_dev).cpu().numpy()
+    unsure = cells = 0
     for i in range(clips.shape[0]):
         S = np.abs(O.stft(clips[i].astype(np.float64), 2048, 512))
         bands = O.contrast_bands(fr, 48000)
@@ -166,11 +166,14 @@ def test_spectral_contrast_matches_oracle(ops, clips):
             srt = np.sort(S[bins], axis=0)
             assert np.abs(pv[i, 1, k] - srt[:kk].mean(axis=0)).max() <= atol, f"valley band {k}"
             assert np.abs(pv[i, 0, k] - srt[-kk:].mean(axis=0)).max() <= atol, f"peak band {k}"
-        # the dB contrast takes log10 of the valley = the SMALLEST bins of a band (k = 1 for the
-        # narrow bands): those sit ~3 orders of magnitude under the frame's tonal peaks, where the
-        # fp32 FFT's rounding (~1e-7 of the peak) is a 1e-5..1e-4 relative error that the log turns
-        # into ~1e-4 of the 20-35 dB contrast.  Stated tolerance for this feature: 1e-4 peak-relative.
-        assert_parity(cdb[i], O.spectral_contrast(S, 48000, freqs=fr), 1e-4, "contrast dB")
+        # the dB contrast: 1e-5 peak-relative on every cell whose float64 valley clears the fp32 FFT floor of its
+        # frame by the decision margin; one propagated floor on the rest (gpu_util.assert_contrast_parity)
+        valley = np.stack([np.sort(S[bins], axis=0)[:kk].mean(axis=0) for bins, kk in bands])
+        u, n = assert_contrast_parity(cdb[i], O.spectral_contrast(S, 48000, freqs=fr), valley, fft_floor(S), TOL,
+                                      f"contrast dB clip {i}")
+        unsure += u; cells += n
+    print(f"contrast cells below the decision margin: {unsure} of {cells}")
+    assert unsure <= 0.10 * cells           # (measured: 5 %; a gate that excluded most cells would prove nothing)
 
 
 def test_large_batch_consistency(ops):

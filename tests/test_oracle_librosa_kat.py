@@ -242,3 +242,18 @@ def test_zcr_known_answers():
     assert np.all(O.zero_crossing_rate(np.full(4096, 1e-11) * np.resize([1, -1], 4096), 1024, 256) == 0.0)  # under threshold
     alt = np.resize([1.0, -1.0], 1024)
     assert O.zero_crossing_rate(alt, 1024, 1024, False)[0] == 1023 / 1024  # first sample never counts
+
+
+def test_manager_order_semantics_of_the_oracle():
+    """The oracle's extract_features follows manager.py's in-order rules: dependency column for the bandwidth
+    (:296-301), re-timing from the STFT frame count (:186-194), final length check (:408-420)."""
+    y = O.synth_clips(1, 4096, 16000, seed=2)[0].astype(np.float64)
+    r = O.extract_features(y, 16000, ["spectral_bandwidth", "mean_amplitude"])
+    assert list(r) == ["time", "spectral_centroid", "spectral_bandwidth", "mean_amplitude"]
+    r = O.extract_features(y, 16000, ["spectral_centroid", "spectral_bandwidth"])
+    assert list(r) == ["time", "spectral_centroid", "spectral_bandwidth"]
+    r = O.extract_features(y, 16000, ["mean_amplitude", "spectral_centroid", "rms_energy"], frame_length=1023, hop_length=256)
+    assert list(r) == ["time", "spectral_centroid", "rms_energy"] and len(r["time"]) == 16
+    assert np.allclose(r["time"], (np.arange(16) * 256 + 511) / 16000.0)
+    r = O.extract_features(y, 16000, ["mean_amplitude", "rms_energy"], frame_length=1023, hop_length=256)
+    assert len(r["time"]) == 17 and np.isnan(r["rms_energy"][-1]) and np.isnan(r["mean_amplitude"][-1])
