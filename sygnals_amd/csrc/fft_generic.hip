@@ -350,12 +350,17 @@ int set_lds(const void* fn, size_t bytes, const char* what) {
   return SYG_OK;
 }
 
-// Partial-sum workgroups per stream: enough of them to fill the chip whatever the batch (a single one-hour stream
-// -- config C5 -- gets 1024, a batch of 1024 clips 16 each); block j sums the segments j, j + nblk, ...
+}  // namespace
+int welch_wave_launch(const float* x, int64_t B, int64_t ldx, int step, int64_t nseg, const float* window,
+                      const float* twiddle, int detrend, int nblk, float* work, hipStream_t st);   // welch_wave.hip
+namespace {
+// Partial sums per stream: enough of them to fill the chip whatever the batch (a single one-hour stream -- config C5 --
+// gets 2048: the eight waves per CU the wave-per-segment kernel's registers admit; a batch of 1024 clips 16 each); partial j sums the
+// segments j, j + nblk, ...
 __host__ int welch_nblk(int64_t B) {
-  int64_t n = 4096 / B;
+  int64_t n = (8192 / B) & ~(int64_t)3;       // (a multiple of 4: the wave-per-segment kernel runs 4 waves per workgroup)
   if (n < 16) n = 16;
-  if (n > 1024) n = 1024;
+  if (n > 2048) n = 2048;
   return (int)n;
 }
 
@@ -447,6 +452,17 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   int nblk = welch_nblk(B);
+  // nperseg = nfft = 4096 on 16-byte aligned segments (config C5): one wave per segment (welch_wave.hip); its partial
+  // sums carry a factor 4
+  if (nfft == 4096 && nperseg == 4096 && step % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) {
+    if ((int64_t)nblk > nseg) nblk = (int)((nseg + 3) & ~(int64_t)3);
+    rc = welch_wave_launch(x, B, ldx, step, nseg, window, twiddle, detrend, nblk, (float*)work, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(welch_final_kernel, dim3((F + 63) / 64, (unsigned)B), dim3(64 * WF_G), 0, st, (const float*)work,
+                       nblk, F, nseg, 0.25 * scale, 0, psd_out);
+    SYG_CHECK_LAUNCH("welch_final");
+    return SYG_OK;
+  }
   if ((int64_t)nblk > nseg) nblk = (int)nseg;
   hipLaunchKernelGGL(welch_partial_kernel, dim3(nblk, (unsigned)B), dim3(WELCH_NT), lds, st, x, L, ldx, nperseg,
                      step, nfft, nseg, window, (const float2*)twiddle, detrend, (float*)work);

@@ -831,6 +831,22 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     }
     SETPRIO(0);
     if (COMPLEX_OUT) continue;
+#if SYG_ABL == 10 || SYG_ABL == 11
+    // ablation (WRONG results): free-running waves -- no projection, no slab, no reduce, no workgroup barrier; the
+    // stage hand-over is unsynchronised.  Lower bound for a design whose waves never meet (10), or meet once per
+    // tile (11).
+    if (LOAD == 2) {
+      have = false;
+      if (tile + 1 < tile_end) fetch(tile + 1);
+#if SYG_ABL == 11
+      __syncthreads();
+#endif
+      if (tile + 2 < tile_end) dma(tile + 2);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    if (lane == 0 && mel_out != nullptr && t < T) mel_out[(b * n_mels) * T + t] = prow[5];
+    continue;
+#endif
 #if SYG_ABL == 9
     int tdep = lane;
     TICK(5, tdep);

@@ -52,9 +52,9 @@ def test_argument_errors_are_reported_without_device_work():
     assert rc == -1 and b"greater than padlen, which is 27" in h.syg_last_error()
     assert h.syg_sosfiltfilt_work_bytes(1024, 48000, 27, 4) > 0
     assert h.syg_sosfiltfilt_work_bytes(1, 100, 9, 9) == -1
-    # partial-sum workgroups per stream: clamp(4096 / B, 16, 1024)
-    assert h.syg_welch_work_bytes(8, 4096) == 8 * 512 * 2049 * 4
-    assert h.syg_welch_work_bytes(1, 4096) == 1 * 1024 * 2049 * 4
+    # partial sums per stream: clamp(8192 / B rounded down to a multiple of 4, 16, 2048)
+    assert h.syg_welch_work_bytes(8, 4096) == 8 * 1024 * 2049 * 4
+    assert h.syg_welch_work_bytes(1, 4096) == 1 * 2048 * 2049 * 4
     assert h.syg_welch_work_bytes(1024, 256) == 1024 * 16 * 129 * 4
     # the one-launch MFCC form: the library owns the LDS-fit rule
     assert h.syg_stft2048_mfcc_fits(40, 94, 13) == 1 and h.syg_stft2048_mfcc_fits(128, 313, 13) == 0
