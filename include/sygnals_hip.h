@@ -256,6 +256,13 @@ int syg_rms_from_spec_f32(const float* S, int64_t rows, int F, int frame_length,
  * ------------------------------------------------------------------------------- */
 int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const float* taps, int ntaps, float scale,
                       float* y, int64_t ldy, void* stream);
+ /* syg_cqt_octave_gemm_f32: the same octave as ONE framed matrix product on the matrix cores (n_fft 128 / 256 / 512):
+ *   out[f, t] = sum_n y[t hop - n_fft/2 + n] * g_f[n],  g_f[n] = sum_k basis[f, k] exp(-2 pi i k n / n_fft)
+ *   (the frequency-domain rows taken to the time domain by the caller, in float64 -- the same linear map).
+ *   gpacked float32 [row tile][n_fft/16][4][64]: A operands of v_mfma_f32_16x16x4_f32, row r = 2 f + (0: re, 1: im):
+ *   entry (mt, s, u, lane) = G[16 s + 4 (lane >> 4) + u][16 mt + (lane & 15)] (0 past 2 n_filt rows).  */
+int syg_cqt_octave_gemm_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
+                            const float* gpacked, int n_filt, float* out, int64_t out_bstride, int row0, void* stream);
 int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
                        const float* twiddle, const float* basis, int n_filt, const int32_t* hull_host,
                        float* out, int64_t out_bstride, int row0, void* stream);

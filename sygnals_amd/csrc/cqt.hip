@@ -17,7 +17,7 @@ constexpr int MAXFILT = 24;       // filters per octave (bins_per_octave <= 24 h
 // even and odd samples (E[m] = x[2m], O[m] = x[2m+1]: the stride-2 reads of the filter become contiguous,
 // conflict-free LDS reads; samples outside [0, L) are staged as zeros), the taps sit in LDS too, and every thread
 // accumulates DEC_OUTS outputs per tap read.  Taps are applied in index order (same sum order as a direct loop).
-constexpr int DEC_NT = 256, DEC_OUTS = 4, DEC_NBO = DEC_NT * DEC_OUTS;
+constexpr int DEC_NT = 256, DEC_OUTS = 8, DEC_NBO = DEC_NT * DEC_OUTS;
 
 __global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restrict__ x, int64_t L, int64_t ldx,
                                                            const float* __restrict__ taps, int ntaps, float scale,
@@ -31,16 +31,29 @@ __global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restri
   const int64_t b = blockIdx.y;
   const float* xb = x + b * ldx;
   const int tid = threadIdx.x;
+  const bool pair_ok = ((ldx & 1) == 0) && ((((uintptr_t)x) & 7) == 0);
   for (int j = tid; j < ntaps; j += DEC_NT) hs[j] = taps[j];
   for (int64_t n0 = (int64_t)blockIdx.x * DEC_NBO; n0 < Lout; n0 += (int64_t)gridDim.x * DEC_NBO) {
     // lowest input index used: 2 n0 + half - (ntaps - 1) = 2 n0 - half; mbase = floor(that / 2)
     const int64_t ilo = 2 * n0 - half;
     const int64_t mbase = (ilo >= 0) ? ilo / 2 : -((-ilo + 1) / 2);
     __syncthreads();                                  // the previous round's reads are done
-    for (int u = tid; u < nstage; u += DEC_NT) {
-      const int64_t i0 = 2 * (mbase + u);
-      E[u] = (i0 >= 0 && i0 < L) ? xb[i0] : 0.f;
-      O[u] = (i0 + 1 >= 0 && i0 + 1 < L) ? xb[i0 + 1] : 0.f;
+    // staging: sample pairs (x[2m], x[2m+1]) as one 8-byte load per lane where the whole run lies inside the signal
+    // and rows are 8-byte aligned (interior workgroups: no bounds checks); element-wise with zero fill otherwise
+    const bool fast = pair_ok && mbase >= 0 && 2 * (mbase + nstage) <= L;
+    if (fast) {
+      const float2* xp = reinterpret_cast<const float2*>(xb) + mbase;
+      for (int u = tid; u < nstage; u += DEC_NT) {
+        const float2 v = xp[u];
+        E[u] = v.x;
+        O[u] = v.y;
+      }
+    } else {
+      for (int u = tid; u < nstage; u += DEC_NT) {
+        const int64_t i0 = 2 * (mbase + u);
+        E[u] = (i0 >= 0 && i0 < L) ? xb[i0] : 0.f;
+        O[u] = (i0 + 1 >= 0 && i0 + 1 < L) ? xb[i0 + 1] : 0.f;
+      }
     }
     __syncthreads();
     float acc[DEC_OUTS];
@@ -61,6 +74,101 @@ __global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restri
     for (int o = 0; o < DEC_OUTS; ++o) {
       const int64_t n = n0 + tid + o * DEC_NT;
       if (n < Lout) y[b * ldy + n] = acc[o] * scale;
+    }
+  }
+}
+
+// The same filter for a fixed tap count (NT = 41: the CQT's decimator), two ADJACENT outputs per lane per round: the
+// windows E[n - H2 .. n + H2 + 1], O[n - H2 .. n + H2] the pair needs are read as 8-byte words (lane stride 8 B:
+// conflict-free) and kept in registers -- 12 to 22 LDS reads per two outputs instead of one read per tap and output.
+// A half-band filter (every tap at an even offset from the centre is zero, the centre excepted) needs only the odd
+// samples and the two centre ones: detected once per workgroup from the taps themselves.  Taps are applied in index order.
+template <int NT>
+__global__ __launch_bounds__(DEC_NT) void decimate2_fixed_kernel(const float* __restrict__ x, int64_t L, int64_t ldx,
+                                                                 const float* __restrict__ taps, float scale,
+                                                                 float* __restrict__ y, int64_t Lout, int64_t ldy) {
+  constexpr int HALF = (NT - 1) / 2;                 // 20: even
+  constexpr int H2 = HALF / 2;                       // 10
+  static_assert(HALF % 2 == 0, "specialised for an even half length");
+  constexpr int PAIRS = DEC_OUTS / 2;                // adjacent output pairs per thread
+  constexpr int NSTAGE = DEC_NBO + HALF + 2;
+  __shared__ __attribute__((aligned(16))) float hs[(NT + 3) & ~3];
+  __shared__ __attribute__((aligned(16))) float E[NSTAGE + 2];
+  __shared__ __attribute__((aligned(16))) float O[NSTAGE + 2];
+  __shared__ int hb_flag;
+  const int64_t b = blockIdx.y;
+  const float* xb = x + b * ldx;
+  const int tid = threadIdx.x;
+  const bool pair_ok = ((ldx & 1) == 0) && ((((uintptr_t)x) & 7) == 0);
+  for (int j = tid; j < NT; j += DEC_NT) hs[j] = taps[j];
+  __syncthreads();
+  if (tid == 0) {
+    int hb = 1;
+    for (int j = 0; j < NT; ++j)
+      if (((HALF - j) & 1) == 0 && j != HALF && hs[j] != 0.f) hb = 0;
+    hb_flag = hb;
+  }
+  __syncthreads();
+  const bool halfband = hb_flag != 0;
+  // the taps live in scalar registers for the whole kernel (wave-uniform values: one LDS read each, once)
+  float hreg[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) hreg[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hs[j])));
+  for (int64_t n0 = (int64_t)blockIdx.x * DEC_NBO; n0 < Lout; n0 += (int64_t)gridDim.x * DEC_NBO) {
+    const int64_t mbase = n0 - H2;                   // staged pair u holds (x[2 (mbase + u)], x[2 (mbase + u) + 1])
+    __syncthreads();
+    const bool fast = pair_ok && mbase >= 0 && 2 * (mbase + NSTAGE) <= L;
+    if (fast) {
+      const float2* xp = reinterpret_cast<const float2*>(xb) + mbase;
+      for (int u = tid; u < NSTAGE; u += DEC_NT) {
+        const float2 v = xp[u];
+        E[u] = v.x;
+        O[u] = v.y;
+      }
+    } else {
+      for (int u = tid; u < NSTAGE; u += DEC_NT) {
+        const int64_t i0 = 2 * (mbase + u);
+        E[u] = (i0 >= 0 && i0 < L) ? xb[i0] : 0.f;
+        O[u] = (i0 + 1 >= 0 && i0 + 1 < L) ? xb[i0 + 1] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      const int nl = 2 * tid + p * 2 * DEC_NT;       // local index of the pair's first output; its window starts at nl
+      // x[2 n + c], c = HALF - j:  c even -> E[n + c/2] (staged at nl + H2 + c/2),  c odd -> O[n + (c-1)/2]
+      float ow[2 * H2 + 2], ew[2 * H2 + 2];
+      const float2* o2 = reinterpret_cast<const float2*>(O + nl);
+      const float2* e2 = reinterpret_cast<const float2*>(E + nl);
+#pragma unroll
+      for (int k = 0; k <= H2; ++k) { const float2 v = o2[k]; ow[2 * k] = v.x; ow[2 * k + 1] = v.y; }
+      if (halfband) {
+        const float2 v = e2[H2 / 2 + 0];             // E[nl + H2], E[nl + H2 + 1]: the two centre samples
+        static_assert(H2 % 2 == 0, "centre pair must be 8-byte aligned");
+        ew[H2] = v.x; ew[H2 + 1] = v.y;
+      } else {
+#pragma unroll
+        for (int k = 0; k <= H2; ++k) { const float2 v = e2[k]; ew[2 * k] = v.x; ew[2 * k + 1] = v.y; }
+      }
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = HALF - j;
+        const float h = hreg[j];
+        if ((c & 1) == 0) {
+          if (halfband && j != HALF) continue;
+          const int q = H2 + c / 2;                  // window index of E[n + c/2]
+          a0 = fmaf(h, ew[q], a0);
+          a1 = fmaf(h, ew[q + 1], a1);
+        } else {
+          const int q = H2 + (c - 1) / 2;            // (c - 1) / 2 = floor(c / 2) for odd c of either sign
+          a0 = fmaf(h, ow[q], a0);
+          a1 = fmaf(h, ow[q + 1], a1);
+        }
+      }
+      const int64_t n = n0 + nl;
+      if (n < Lout) y[b * ldy + n] = a0 * scale;
+      if (n + 1 < Lout) y[b * ldy + n + 1] = a1 * scale;
     }
   }
 }
@@ -134,6 +242,104 @@ __global__ __launch_bounds__(FPW * 64) void cqt_octave_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One octave as a framed matrix product on the matrix cores.  The octave's response is linear in the frame:
+//   out[f, t] = sum_k basis[f, k] * rfft(frame_t)[k] = sum_n frame_t[n] * g_f[n],   g_f[n] = sum_k basis[f, k] W_N^(k n)
+// (g: the sparsified frequency-domain rows taken back to the time domain on the host, in float64), i.e.
+//   OUT [2 n_filt, T] = G^T [2 n_filt, n_fft] x FRAMES [n_fft, T],   FRAMES[n, t] = y[t hop - n_fft/2 + n]
+// with the real and imaginary parts of a filter as two rows.  v_mfma_f32_16x16x4_f32 (exact fp32): A = a 16-row tile
+// of G^T, held in registers for the whole launch (n_fft / 4 VGPRs); B = 16 frames, each lane loading 16 bytes of its
+// frame per four k-steps straight from global memory -- the k order inside a group of 16 samples is permuted so that a
+// lane's float4 feeds four consecutive steps (A is packed with the same permutation on the host); frames overlap, so
+// the re-reads hit L1 / L2.  No LDS, no barrier; a wave owns (row tile, frame tiles wave_id, wave_id + n_waves, ...),
+// and the loads of the next frame tile are issued as soon as the MFMAs that read a register have been issued.
+// RT row tiles per wave (n_rowtiles is a multiple of RT): with RT = 2 the two accumulator chains share every frame load
+// and cover each other's MFMA latency.
+template <int NFFT, int RT>
+__global__ __launch_bounds__(256) void cqt_gemm_kernel(const float* __restrict__ ysig, int64_t L, int64_t ldy, int hop,
+                                                       int64_t T, const float* __restrict__ gpacked, int n_rowtiles,
+                                                       int n_filt, float2* __restrict__ out, int64_t out_bstride,
+                                                       int row0, int waves_per_rowtile) {
+  constexpr int S = NFFT / 16;                 // groups of 16 samples = 4 MFMA steps each
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int ngroups = n_rowtiles / RT;
+  const int mt = (wid % ngroups) * RT, slot = wid / ngroups;
+  if (slot >= waves_per_rowtile) return;
+  const int64_t b = blockIdx.y;
+  const float* yb = ysig + b * ldy;
+  float a[RT][S * 4];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const float* gp = gpacked + ((int64_t)(mt + r) * S * 4) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < S * 4; ++i) a[r][i] = gp[i * 64];
+  }
+  const int n = lane & 15, kk = lane >> 4;
+  const int64_t ntiles = (T + 15) >> 4;
+  // first output row (filter) of this lane: rows 16 mt + 4 kk + {0, 1} are (re, im) of filter f0, + {2, 3} of f0 + 1
+  const int f0 = 8 * mt + 2 * kk;
+  // groups [s0, s1) of frame tile `tile` into q: plain 16-byte loads when every frame of the tile lies inside the signal
+  // (wave-uniform test), element-wise with zero fill otherwise (centre padding at both ends)
+  auto load_part = [&](int64_t tile, float4 (&q)[S], int s0, int s1) {
+    const int64_t t = tile * 16 + n;
+    const int64_t base = t * (int64_t)hop - NFFT / 2 + 4 * kk;
+    const int64_t lo = tile * 16 * (int64_t)hop - NFFT / 2, hi = (tile * 16 + 15) * (int64_t)hop + NFFT / 2;
+    if (lo >= 0 && hi <= L) {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        if (s >= s0 && s < s1) q[s] = *reinterpret_cast<const float4*>(yb + base + 16 * s);
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        if (s >= s0 && s < s1) {
+          const int64_t i0 = base + 16 * s;
+          q[s].x = (i0 >= 0 && i0 < L) ? yb[i0] : 0.f;
+          q[s].y = (i0 + 1 >= 0 && i0 + 1 < L) ? yb[i0 + 1] : 0.f;
+          q[s].z = (i0 + 2 >= 0 && i0 + 2 < L) ? yb[i0 + 2] : 0.f;
+          q[s].w = (i0 + 3 >= 0 && i0 + 3 < L) ? yb[i0 + 3] : 0.f;
+        }
+    }
+  };
+  float4 q[S];
+  int64_t tile = slot;
+  if (tile < ntiles) load_part(tile, q, 0, S);
+  for (; tile < ntiles; tile += waves_per_rowtile) {
+    v4f acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = v4f{0.f, 0.f, 0.f, 0.f};
+    const int64_t nxt = tile + waves_per_rowtile;
+    // two halves: as soon as the MFMAs of a half have been issued its registers are reloaded with the next tile's
+    // samples, which then travel while the other half is multiplied -- no second buffer
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int s = h * (S / 2); s < (h + 1) * (S / 2); ++s) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][4 * s + 0], q[s].x, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][4 * s + 1], q[s].y, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][4 * s + 2], q[s].z, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][4 * s + 3], q[s].w, acc[r], 0, 0, 0);
+      }
+      if (nxt < ntiles) load_part(nxt, q, h * (S / 2), (h + 1) * (S / 2));
+    }
+    const int64_t t = tile * 16 + n;
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int f = f0 + 8 * r;
+        float2* o = out + b * out_bstride + (int64_t)(row0 + f) * T + t;
+        if (f < n_filt) o[0] = make_float2(acc[r][0], acc[r][1]);
+        if (f + 1 < n_filt) o[T] = make_float2(acc[r][2], acc[r][3]);
+      }
+    }
+  }
+}
+
 bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
 
 }  // namespace
@@ -152,8 +358,12 @@ extern "C" int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t l
   if (blocks > 16384) blocks = 16384;
   const int half = (ntaps - 1) / 2;
   const size_t lds = (size_t)(((ntaps + 3) & ~3) + 2 * (DEC_NBO + half + 2)) * sizeof(float);
-  hipLaunchKernelGGL(decimate2_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(DEC_NT), lds, (hipStream_t)stream, x, L,
-                     ldx, taps, ntaps, scale, y, Lout, ldy);
+  if (ntaps == 41)
+    hipLaunchKernelGGL(decimate2_fixed_kernel<41>, dim3((unsigned)blocks, (unsigned)B), dim3(DEC_NT), 0, (hipStream_t)stream,
+                       x, L, ldx, taps, scale, y, Lout, ldy);
+  else
+    hipLaunchKernelGGL(decimate2_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(DEC_NT), lds, (hipStream_t)stream, x, L,
+                       ldx, taps, ntaps, scale, y, Lout, ldy);
   SYG_CHECK_LAUNCH("decimate2");
   return SYG_OK;
 }
@@ -193,5 +403,39 @@ extern "C" int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t 
                      ldy, n_fft, hop, T, (const float2*)twiddle, (const float2*)basis, n_filt, hull, (float2*)out,
                      out_bstride, row0);
   SYG_CHECK_LAUNCH("cqt_octave");
+  return SYG_OK;
+}
+
+
+extern "C" int syg_cqt_octave_gemm_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
+                                       const float* gpacked, int n_filt, float* out, int64_t out_bstride, int row0,
+                                       void* stream) {
+  SYG_REQUIRE(y && gpacked && out, "cqt_octave_gemm: null pointer argument");
+  SYG_REQUIRE(n_fft == 128 || n_fft == 256 || n_fft == 512, "cqt_octave_gemm: n_fft must be 128, 256 or 512 (got %d)", n_fft);
+  SYG_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && ldy >= L && hop >= 1, "cqt_octave_gemm: bad B/L/ldy/hop");
+  SYG_REQUIRE(T >= 1 && T <= 1 + L / hop, "cqt_octave_gemm: T=%lld exceeds the centred frame count %lld", (long long)T,
+              (long long)(1 + L / hop));
+  SYG_REQUIRE(n_filt >= 1 && n_filt <= 64, "cqt_octave_gemm: n_filt must be in [1, 64]");
+  SYG_REQUIRE(row0 >= 0 && out_bstride >= (int64_t)(row0 + n_filt) * T, "cqt_octave_gemm: output rows out of range");
+  const int n_rowtiles = (2 * n_filt + 15) / 16;
+  const int64_t ntiles = (T + 15) / 16;
+  // two row tiles per wave when they come in pairs and the operands fit the registers (n_fft <= 256: 128 + 64 VGPRs)
+  const int rt = (n_rowtiles % 2 == 0 && n_fft <= 256) ? 2 : 1;
+  const int ngroups = n_rowtiles / rt;
+  // persistent waves: about 8 (rt = 2) / 12 per CU over the batch, never more than there are frame tiles
+  int64_t wpr = (256 * (rt == 2 ? 8 : 12)) / ((int64_t)ngroups * B);
+  if (wpr < 4) wpr = 4;
+  if (wpr > ntiles) wpr = ntiles;
+  const int64_t waves = wpr * ngroups;
+  const dim3 grid((unsigned)((waves + 3) / 4), (unsigned)B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define SYG_CQT_GEMM(N, R)                                                                                           \
+  hipLaunchKernelGGL((cqt_gemm_kernel<N, R>), grid, block, 0, st, y, L, ldy, hop, T, gpacked, n_rowtiles, n_filt,    \
+                     (float2*)out, out_bstride, row0, (int)wpr)
+  if (n_fft == 128) { if (rt == 2) SYG_CQT_GEMM(128, 2); else SYG_CQT_GEMM(128, 1); }
+  else if (n_fft == 256) { if (rt == 2) SYG_CQT_GEMM(256, 2); else SYG_CQT_GEMM(256, 1); }
+  else SYG_CQT_GEMM(512, 1);
+#undef SYG_CQT_GEMM
+  SYG_CHECK_LAUNCH("cqt_octave_gemm");
   return SYG_OK;
 }

@@ -7,6 +7,7 @@ tensors with a leading batch axis; there is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import functools
 from typing import Optional
 
@@ -917,6 +918,30 @@ def periodogram(x: torch.Tensor, nfft: int, window_host: Optional[np.ndarray], d
 
 
 # ------------------------------------------------------------------ constant-Q transform
+def cqt_pack_gemm(basis: np.ndarray, n_fft: int) -> np.ndarray:
+    """A operands of syg_cqt_octave_gemm_f32 for one octave: the frequency-domain rows basis [n_filt, 1 + n_fft/2]
+    (complex) act on rfft(frame); the same linear map in the time domain is out[f] = sum_n frame[n] g_f[n] with
+    g_f[n] = sum_k basis[f, k] exp(-2 pi i k n / n_fft) (float64 here).  Rows 2f / 2f + 1 of G^T hold Re / Im of g_f;
+    packed [row tile][n_fft/16][4][64] float32 with entry (mt, s, u, lane) = G[16 s + 4 (lane >> 4) + u][16 mt + lane % 16]."""
+    basis = np.asarray(basis, dtype=np.complex128)
+    nf, F = basis.shape
+    k = np.arange(F)[:, None]
+    n = np.arange(n_fft)[None, :]
+    g = basis @ np.exp(-2j * np.pi * ((k * n) % n_fft) / n_fft)            # [nf, n_fft]
+    ntile = (2 * nf + 15) // 16
+    G = np.zeros((n_fft, 16 * ntile), dtype=np.float64)
+    G[:, 0:2 * nf:2] = g.real.T
+    G[:, 1:2 * nf:2] = g.imag.T
+    lane = np.arange(64)
+    S = n_fft // 16
+    out = np.empty((ntile, S, 4, 64), dtype=np.float32)
+    for mt in range(ntile):
+        for s in range(S):
+            for u in range(4):
+                out[mt, s, u] = G[16 * s + 4 * (lane >> 4) + u, 16 * mt + (lane & 15)]
+    return np.ascontiguousarray(out)
+
+
 def decimate2(x: torch.Tensor, taps: torch.Tensor, scale: float) -> torch.Tensor:
     """FIR decimation by two of x [B, L] -> [B, ceil(L/2)] (zero padded ends)."""
     require_gpu()
@@ -948,6 +973,7 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
             k0 = np.array([int(np.argmax(r)) if r.any() else 0 for r in nz], dtype=np.int32)
             k1 = np.array([int(len(r) - np.argmax(r[::-1])) if r.any() else 0 for r in nz], dtype=np.int32)
             o["hull"] = np.ascontiguousarray(np.concatenate([k0, k1 - k0]).astype(np.int32))
+            o["gpacked_dev"] = _dev(cqt_pack_gemm(b, o["n_fft"])) if o["n_fft"] in (128, 256, 512) and len(b) <= 64 else None
         p.taps_dev = _dev(decimation_taps().astype(np.float32))
         return p
     plan = _cached(key, build)
@@ -965,13 +991,19 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
         Tn = To if Tn is None else min(Tn, To)
         if o["decimate_after"]:
             Lc = (Lc + 1) // 2
-    out = torch.zeros((B, plan.n_bins, Tn, 2), dtype=torch.float32, device=y.device)
+    out = torch.empty((B, plan.n_bins, Tn, 2), dtype=torch.float32, device=y.device)      # every row is written
     cur = y
     s2 = float(np.sqrt(2.0))
     for _ in range(plan.early):
         cur = decimate2(cur, plan.taps_dev, s2)
+    use_gemm = os.environ.get("SYGNALS_AMD_CQT", "gemm") != "fft"
     for o in plan.octaves:
-        if o["n"] > 0:
+        if o["n"] > 0 and use_gemm and o.get("gpacked_dev") is not None:
+            rc = lib().syg_cqt_octave_gemm_f32(_ptr(cur), B, cur.shape[1], _ld(cur), o["n_fft"], o["hop"], Tn,
+                                               _ptr(o["gpacked_dev"]), o["n"], _ptr(out), plan.n_bins * Tn, o["row0"],
+                                               C.c_void_p(_stream_ptr()))
+            check(rc, "syg_cqt_octave_gemm_f32")
+        elif o["n"] > 0:
             rc = lib().syg_cqt_octave_f32(_ptr(cur), B, cur.shape[1], _ld(cur), o["n_fft"], o["hop"], Tn,
                                           _ptr(twiddle_rfft_dev(o["n_fft"])), _ptr(o["basis_dev"]), o["n"],
                                           o["hull"].ctypes.data_as(C.c_void_p), _ptr(out),

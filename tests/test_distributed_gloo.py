@@ -121,3 +121,62 @@ def test_root_gather_single_process_passthrough():
     x = torch.arange(8, dtype=torch.float32).reshape(4, 2)
     gat.start(x)
     assert gat.finish() is x and gat.finish() is None
+
+
+# ---- config C4's payload: every rank's [b_r, 22, T] feature block (13 MFCC + centroid + rolloff + 7 contrast rows)
+# gathered to rank 0 -- the per-rank compute is the float64 oracle here (CPU); on the GPU box bench.py --config c4 runs
+# sygnals_amd.core.features.manager.feature_block under the same RootGather
+C4_FEATS = ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]
+
+
+def _c4_block_oracle(Y, sr):
+    from oracle import cpu_ref as O
+    rows = []
+    for y in Y:
+        d = O.extract_features(y.astype(np.float64), sr, C4_FEATS, feature_params={"mfcc": {"n_mels": 40}})
+        rows.append(np.stack([d[k] for k in d if k != "time"]))
+    return np.stack(rows).astype(np.float32)
+
+
+def _c4_worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sygnals_amd.distributed import RootGather, shard_range
+    from sygnals_amd.synth import synth_clips
+    lo, hi = shard_range(n_total, rank, world)
+    allc = synth_clips(n_total, 8192, 48000, seed=9)
+    T = 1 + 8192 // 512
+    gat = RootGather(n_total, (hi - lo, 22, T), torch.float32, "cpu", dst=0)
+    gat.start(torch.from_numpy(_c4_block_oracle(allc[lo:hi], 48000)))
+    out = gat.finish()
+    q.put((rank, None if out is None else out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4, 5])
+def test_two_rank_c4_feature_block_gather(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    from sygnals_amd.synth import synth_clips
+    want = _c4_block_oracle(synth_clips(n_total, 8192, 48000, seed=9), 48000)
+    assert res[0].shape == (n_total, 22, 17) and np.array_equal(res[0], want)
+
+
+def test_synth_recipe_matches_the_oracles_statement():
+    """bench.py's inputs come from sygnals_amd.synth (no oracle import on the GPU leg); the oracle states the same
+    SURVEY 8(d) recipe: bit-identical clips."""
+    from oracle import cpu_ref as O
+    from sygnals_amd.synth import synth_clips
+    assert np.array_equal(synth_clips(3, 4800, 48000, seed=5), O.synth_clips(3, 4800, 48000, seed=5))
+    assert np.array_equal(synth_clips(2, 1600, 16000, seed=20250523), O.synth_clips(2, 1600, 16000, seed=20250523))

@@ -247,6 +247,24 @@ def test_compute_cqt_vs_oracle():
         compute_cqt(y2, 8000)
 
 
+@pytest.mark.parametrize("path", ["gemm", "fft"])
+def test_cqt_both_octave_kernels_vs_oracle(path, monkeypatch):
+    """The octave response as one framed matrix product on the matrix cores (default) and as rfft x sparse basis rows
+    (the fallback for other frame lengths) are the same linear map: both against the oracle."""
+    from sygnals_amd import ops
+    monkeypatch.setenv("SYGNALS_AMD_CQT", path)
+    rng = np.random.default_rng(11)
+    sr = 48000
+    n = sr * 3 + 77                                          # odd length: ragged decimated lengths, masked edge tiles
+    t = np.arange(n) / sr
+    x = (rng.normal(0, 0.05, n) + 0.4 * np.sin(2 * np.pi * 261.63 * t) + 0.2 * np.sin(2 * np.pi * 3135.96 * t)).astype(np.float32)
+    ref = O.cqt(x.astype(np.float64), sr)
+    got = ops.cqt(ops.to_device_f32(np.stack([x, -2 * x])), sr).cpu().numpy()
+    got = got[..., 0] + 1j * got[..., 1]
+    assert got.shape == (2,) + ref.shape
+    assert peak_rel(got[0], ref) <= TOL and peak_rel(got[1], -2 * ref) <= TOL
+
+
 def test_cqt_batch_long_stream_consistency():
     """C5-shaped use: a batch of long streams; size-independent property: linearity and time-shift by whole hops."""
     from sygnals_amd import ops
@@ -260,7 +278,8 @@ def test_cqt_batch_long_stream_consistency():
     assert peak_rel(S, X[0] + 2 * X[1]) <= TOL
     ref = O.cqt(x[0, :48000 * 2].astype(np.float64), 48000)
     got = X[0][:, :150]
-    assert peak_rel(got[:, :150], ref[:, :150]) <= 1e-3     # edge of the 2 s excerpt differs only through filter tails
+    assert peak_rel(got[:, :130], ref[:, :130]) <= TOL      # (frames clear of the 2 s excerpt's end: the lowest octave's
+                                                            #  filters are 0.34 s long on either side)
 
 
 def test_c4_share_full_size_batch_consistency():
@@ -347,7 +366,7 @@ def test_c5_full_size_stream_welch_and_cqt():
     ref = O.cqt(exc, sr)
     got = C[0, :, :300].cpu().numpy()
     got = got[..., 0] + 1j * got[..., 1]
-    assert peak_rel(got[:, :250], ref[:, :250]) <= 1e-3      # the excerpt's end differs only through filter tails
+    assert peak_rel(got[:, :300], ref[:, :300]) <= TOL       # frames clear of the excerpt's end
 
 
 def test_c3_full_size_filter_then_mfcc():

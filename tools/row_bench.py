@@ -24,7 +24,7 @@ def timeit(fn, n=20, warm=5):
 
 rows = []
 def want(name):
-    return not ONLY or any(a in name.lower() for a in ONLY)
+    return not ONLY or any(a in name.lower() for a in ONLY)        # (a substring of the row name, e.g. "c5", "cqt")
 def report(name, fn, samples, algo_bytes, note="", n=20, warm=5):
     if not want(name):
         return
@@ -47,7 +47,7 @@ report("a13 sosfiltfilt order-4 band-pass (C3 filter alone)", lambda: FL.apply_s
 report("C3 filtfilt + MFCC", lambda: ops.mfcc_batch(FL.apply_sos_filter_batch(sos, y), SR, n_mels=40), B * L, B * (4 * L + 4 * 13 * Tn),
        "filtered waveform is a non-algorithmic intermediate")
 # C4 per-GPU share: 2048 clips, MFCC + centroid + rolloff + contrast -> one [2048, 22, 94] block
-if want("C4"):
+if want("C4 share"):
     from sygnals_amd.core.features.manager import feature_block
     y4 = ops.to_device_f32(np.tile(Y, (2048 // 64, 1)))
     report("C4 share: MFCC + centroid + rolloff + contrast -> [2048, 22, 94] block", lambda: feature_block(y4, SR), 2048 * L, 2048 * (4 * L + 4 * 22 * Tn))
@@ -55,7 +55,7 @@ if want("C4"):
 report("a6-a9 all five spectral statistics + mel, 1024 clips", lambda: ops.stft2048_mel(y, SR, n_mels=40, want_stats=31), B * L, B * (4 * L + 4 * (40 + 5) * Tn))
 report("f-1 time-domain frame features (9 rows), 1024 clips", lambda: ops.frame_stats(y, 2048, 512, True), B * L, B * (4 * L + 4 * 9 * Tn))
 # a10: batched FFT
-if want("a10"):
+if want("a10 complex FFT"):
     xf = torch.randn((4096, 4096, 2), dtype=torch.float32, device=y.device)
     report("a10 complex FFT n=4096 x 4096 signals", lambda: ops.fft_pow2(xf), 4096 * 4096, 2 * 8 * 4096 * 4096)
     x48 = torch.randn((1024, 48000, 2), dtype=torch.float32, device=y.device)
@@ -64,7 +64,7 @@ if want("a10"):
     report("a10 complex FFT n=6000 (2^4 3 5^3) x 8192 signals", lambda: ops.fft_any(x6k), 8192 * 6000, 2 * 8 * 8192 * 6000, n=10, warm=3)
     del xf, x48, x6k
 # C5: ONE 1-hour stream (172.8 M samples), generated on the device: noise + a slow chirp + tones (tone phases in float64)
-if want("C5"):
+if want("C5 a14 Welch") or want("C5 a15 CQT"):
     Ls = 48000 * 3600
     g = torch.Generator(device="cuda").manual_seed(5)
     stream = torch.randn(Ls, device="cuda", generator=g, dtype=torch.float32) * 0.05
@@ -80,7 +80,7 @@ if want("C5"):
            "input read in its own pass (Welch separate)", n=3, warm=1)
     del stream
 # f-3: FFT-backed 1-D operations on the 1024-clip batch
-if want("f-3"):
+if want("f-3 convolution autocorrelation Hilbert periodogram"):
     kern = ops.to_device_f32((np.random.default_rng(0).normal(0, 1, 1023) / 32).astype(np.float32))
     report("f-3 convolution, 1023-tap shared kernel, mode=same, 1024 clips", lambda: D.convolve_batch(y, kern, "same"), B * L, B * 8 * L)
     report("f-3 autocorrelation (full), 1024 clips", lambda: D.convolve_batch(y, y, "full", correlate=True), B * L, B * (4 * L + 4 * (2 * L - 1)))
