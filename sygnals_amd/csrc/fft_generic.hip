@@ -83,21 +83,81 @@ __global__ void cabs_pow_kernel(const float2* __restrict__ x, int64_t n, int pow
   }
 }
 
-// mel[b, m, t] = sum_f basis[m, f] * P[b, t, f]; one workgroup per (b, t), one wave per mel row.
-__global__ void mel_dense_kernel(const float* __restrict__ P, int64_t T, int F, const float* __restrict__ basis,
-                                 int M, float* __restrict__ mel) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-  const int64_t b = blockIdx.x / T, t = blockIdx.x % T;
-  const float* row = P + (b * T + t) * (int64_t)F;
-  for (int f = tid; f < F; f += blockDim.x) lds[f] = row[f];
-  __syncthreads();
-  for (int m = w; m < M; m += nw) {
-    const float* br = basis + (int64_t)m * F;
-    float s = 0.f;
-    for (int f = lane; f < F; f += 64) s = fmaf(br[f], lds[f], s);
-    s = wave_sum(s);
-    if (lane == 0) mel[(b * M + m) * T + t] = s;
+// mel[b, m, t] = sum_f basis[m, f] * P[b, t, f] on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): the dense
+// mel filterbank of librosa.feature.melspectrogram (manager.py:219-222) for every frame length the fused kernel does not
+// take.  A wave owns 16 frames x up to MELT_PER_WAVE tiles of 16 mel rows; per group of 16 bins each lane loads 16
+// bytes of its frame's power row (B operand) and 16 bytes of each of its basis rows (A operands) and feeds four
+// consecutive k-steps from them (the k order inside a group is permuted the same way on both sides); the last,
+// partial group of a row (F = n_fft/2 + 1 is odd) is loaded element-wise with zero fill.
+constexpr int MELT_PER_WAVE = 4;
+typedef float mel_v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mel_dense_mfma_kernel(const float* __restrict__ P, int64_t B, int64_t T, int F,
+                                                             const float* __restrict__ basis, int M,
+                                                             float* __restrict__ mel, int64_t tiles_per_clip) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t b = wid / tiles_per_clip;
+  if (b >= B) return;
+  const int64_t t0 = (wid - b * tiles_per_clip) * 16;
+  const int mt0 = blockIdx.y * MELT_PER_WAVE;
+  const int n = lane & 15, kk = lane >> 4;
+  const int64_t t = t0 + n;
+  const bool tok = t < T;
+  const float* prow = P + (b * T + (tok ? t : T - 1)) * (int64_t)F + 4 * kk;
+  const float* arow[MELT_PER_WAVE];
+  bool aok[MELT_PER_WAVE];
+#pragma unroll
+  for (int r = 0; r < MELT_PER_WAVE; ++r) {
+    const int m = 16 * (mt0 + r) + n;
+    aok[r] = m < M;
+    arow[r] = basis + (int64_t)(aok[r] ? m : 0) * F + 4 * kk;
+  }
+  mel_v4f acc[MELT_PER_WAVE];
+#pragma unroll
+  for (int r = 0; r < MELT_PER_WAVE; ++r) acc[r] = mel_v4f{0.f, 0.f, 0.f, 0.f};
+  const int full = F >> 4;                       // groups of 16 bins that lie entirely inside a row
+  auto step = [&](const float (&pb)[4], const float (&pa)[MELT_PER_WAVE][4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < MELT_PER_WAVE; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r][u], pb[u], acc[r], 0, 0, 0);
+  };
+  for (int s = 0; s < full; ++s) {
+    float pb[4], pa[MELT_PER_WAVE][4];
+    {
+      // (4-byte aligned 16-byte loads: F is odd, rows are not 16-byte aligned)
+      const float* q = prow + 16 * s;
+      pb[0] = tok ? q[0] : 0.f; pb[1] = tok ? q[1] : 0.f; pb[2] = tok ? q[2] : 0.f; pb[3] = tok ? q[3] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < MELT_PER_WAVE; ++r) {
+      const float* q = arow[r] + 16 * s;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pa[r][u] = aok[r] ? q[u] : 0.f;
+    }
+    step(pb, pa);
+  }
+  if (full * 16 < F) {                           // the partial last group
+    float pb[4], pa[MELT_PER_WAVE][4];
+    const int f0 = full * 16 + 4 * kk;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pb[u] = (tok && f0 + u < F) ? prow[16 * full + u] : 0.f;
+#pragma unroll
+    for (int r = 0; r < MELT_PER_WAVE; ++r)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pa[r][u] = (aok[r] && f0 + u < F) ? arow[r][16 * full + u] : 0.f;
+    step(pb, pa);
+  }
+  // D[row = 4 kk + i][col = n]: mel row 16 (mt0 + r) + 4 kk + i of frame t0 + n
+  if (tok) {
+#pragma unroll
+    for (int r = 0; r < MELT_PER_WAVE; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * (mt0 + r) + 4 * kk + i;
+        if (m < M) mel[(b * M + m) * T + t] = acc[r][i];
+      }
   }
 }
 
@@ -420,12 +480,12 @@ extern "C" int syg_mel_dense_f32(const float* P, int64_t B, int64_t T, int F, co
                                  float* mel_out, void* stream) {
   SYG_REQUIRE(P && basis && mel_out, "mel_dense: null pointer argument");
   SYG_REQUIRE(B >= 1 && T >= 1 && F >= 1 && F <= 16385 && M >= 1, "mel_dense: bad shape");
-  SYG_REQUIRE(B * T < (int64_t)0x7fffffff, "mel_dense: grid too large");
-  const size_t lds = (size_t)F * sizeof(float);
-  int rc = set_lds((const void*)mel_dense_kernel, lds, "mel_dense");
-  if (rc) return rc;
-  hipLaunchKernelGGL(mel_dense_kernel, dim3((unsigned)(B * T)), dim3(256), lds, (hipStream_t)stream, P, T, F, basis,
-                     M, mel_out);
+  const int64_t tiles_per_clip = (T + 15) / 16;
+  const int64_t waves = B * tiles_per_clip;
+  SYG_REQUIRE((waves + 3) / 4 < (int64_t)0x7fffffff && M <= 16 * MELT_PER_WAVE * 65535, "mel_dense: grid too large");
+  const dim3 grid((unsigned)((waves + 3) / 4), (unsigned)((M + 16 * MELT_PER_WAVE - 1) / (16 * MELT_PER_WAVE)));
+  hipLaunchKernelGGL(mel_dense_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, B, T, F, basis, M, mel_out,
+                     tiles_per_clip);
   SYG_CHECK_LAUNCH("mel_dense");
   return SYG_OK;
 }

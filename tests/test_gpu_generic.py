@@ -174,3 +174,21 @@ def test_welch_vs_reference_golden(ops, tag, kw):
                   scale).cpu().numpy()
     assert_parity(p[0], g[f"welch_{tag}_p"], TOL, tag)
     assert_parity(p[1], 4 * g[f"welch_{tag}_p"], TOL, tag + " (x2 -> x4)")
+
+
+@pytest.mark.parametrize("n_fft,n_mels,L", [(256, 13, 4000), (1024, 128, 16000), (4096, 40, 30001), (500, 70, 5003)])
+def test_mel_dense_mfma_shapes(ops, n_fft, n_mels, L):
+    """The dense filterbank on the matrix cores (frame lengths the fused kernel does not take): row counts that do not
+    fill a 16-row tile, more than one group of four tiles (128 mels), F = n_fft/2 + 1 with and without a partial last
+    group of 16 bins, frame counts that are not multiples of 16 -- against the float64 product."""
+    from sygnals_amd import _tables as T
+    rng = np.random.default_rng(n_fft + n_mels)
+    F = n_fft // 2 + 1
+    Tn = 1 + L // (n_fft // 4)
+    P = (rng.random((3, Tn, F)) ** 4 * 100.0).astype(np.float32)          # wide dynamic range, non-negative
+    basis = T.mel_filterbank(16000, n_fft, n_mels)
+    mel = ops.mel_dense(torch.from_numpy(P).cuda(), torch.from_numpy(basis).cuda()).cpu().numpy()
+    want = np.einsum("mf,btf->bmt", basis.astype(np.float64), P.astype(np.float64))
+    assert mel.shape == (3, n_mels, Tn)
+    for b in range(3):
+        assert_parity(mel[b], want[b], TOL, f"dense mel n_fft={n_fft} n_mels={n_mels}")
