@@ -225,6 +225,20 @@ int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg
                   void* work, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * BASELINE config C4's per-clip feature block in one launch behind syg_stft2048_mel_f32 (mel + centroid + rolloff +
+ * contrast tail means): block_out [B, K + 2 + R, T] float32 with rows
+ *   0 .. K-1      MFCC = DCT rows x power_to_db(mel, ref = max of the clip, amin, top_db)   (manager.py:219-223,
+ *                 cepstral.py:106-115; the dB matrix stays in LDS: M * T * 4 bytes <= 150 KiB)
+ *   K, K + 1      spectral centroid (Hz), spectral rolloff (Hz = bin x binhz)              (manager.py:304-316)
+ *   K + 2 ..      spectral contrast dB rows from contrast_pv [B, 2, R, T] (peak, valley)    (frequency_domain.py:200-207)
+ * -- the columns extract_features(["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]) returns, in
+ * order: the [B/W, 22, 94] block a rank contributes to config C4's gather.  stats: [B, SYG_NSTAT, T].
+ * ------------------------------------------------------------------------------- */
+int syg_feature_block_f32(const float* mel, int64_t B, int M, int64_t T, const float* dct, int K, float amin,
+                          float top_db, const float* stats, float binhz, const float* contrast_pv, int R,
+                          float c_amin, float c_top_db, float* block_out, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Time-domain frame features, one value per frame:
  *   rows 0..6: mean |x|, population std, skewness (scipy.stats.skew bias=False), excess kurtosis
  *              (scipy.stats.kurtosis fisher, bias=False), max |x|, crest factor, Shannon entropy of

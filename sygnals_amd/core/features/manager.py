@@ -303,11 +303,13 @@ def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: i
         out = torch.empty((B, rows, Tn), dtype=torch.float32, device=y.device)
     mel, stats, cpv = ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8, roll_percent,
                                        2.0, cplan)
-    _, mf = ops.logmel_dct(mel, n_mfcc)
-    out[:, :n_mfcc] = mf
-    out[:, n_mfcc] = stats[:, 0]
-    torch.mul(stats[:, 3], float(sr) / 2048.0, out=out[:, n_mfcc + 1])        # bin index -> Hz (exact in float32)
-    out[:, n_mfcc + 2:] = ops.contrast_db(cpv)
+    dct = ops._cached(("dct", n_mfcc, n_mels, 2, "ortho"), lambda: ops._dev(T.dct_matrix(n_mfcc, n_mels, 2, "ortho")))
+    import ctypes as C
+    from ..._lib import check, lib
+    rc = lib().syg_feature_block_f32(ops._ptr(mel), B, n_mels, Tn, ops._ptr(dct), n_mfcc, 1e-10, 80.0, ops._ptr(stats),
+                                     float(sr) / 2048.0, ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out),
+                                     C.c_void_p(ops._stream_ptr()))
+    check(rc, "syg_feature_block_f32")
     return out
 
 

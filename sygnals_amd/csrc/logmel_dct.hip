@@ -85,10 +85,103 @@ dct_stage:
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Config C4's per-clip block in one launch behind the fused STFT kernel: from the clip's mel power [M, T], the
+// statistics rows and the contrast tail means, write [K + 2 + R, T]:
+//   rows 0 .. K-1        MFCC: power_to_db(ref = max, amin, top_db) -> DCT rows on the matrix cores (the dB matrix only
+//                        ever exists in LDS)
+//   row  K, K + 1        spectral centroid (Hz) and rolloff (bin index x bin width = the bin's frequency)
+//   rows K + 2 .. +R-1   spectral contrast: power_to_db(peak) - power_to_db(valley), each clamped top_db below the
+//                        maximum of its own [R, T] matrix (librosa.feature.spectral_contrast)
+// -- the columns extract_features(["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]) returns
+// (manager.py:289-371).  One workgroup per clip.
+__global__ __launch_bounds__(NT) void feature_block_kernel(const float* __restrict__ mel, int M, int64_t T,
+                                                           const float* __restrict__ dct, int K, float amin,
+                                                           float top_db, const float* __restrict__ stats, float binhz,
+                                                           const float* __restrict__ pv, int R, float c_amin,
+                                                           float c_top_db, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float db[];     // [M][T]
+  __shared__ float red[3][NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t b = blockIdx.x;
+  const int rows = K + 2 + R;
+  const float* src = mel + b * (int64_t)M * T;
+  const float* pk = pv + (b * 2 + 0) * (int64_t)R * T;
+  const float* vl = pv + (b * 2 + 1) * (int64_t)R * T;
+  float* ob = out + b * (int64_t)rows * T;
+  const int64_t n = (int64_t)M * T, nc = (int64_t)R * T;
+  float mx = 0.f, m0 = 0.f, m1 = 0.f;       // powers and magnitudes are non-negative
+  for (int64_t i = tid; i < n; i += NT) mx = fmaxf(mx, src[i]);
+  for (int64_t i = tid; i < nc; i += NT) { m0 = fmaxf(m0, pk[i]); m1 = fmaxf(m1, vl[i]); }
+  mx = wave_max(mx); m0 = wave_max(m0); m1 = wave_max(m1);
+  if (lane == 0) { red[0][w] = mx; red[1][w] = m0; red[2][w] = m1; }
+  __syncthreads();
+  mx = red[0][0]; m0 = red[1][0]; m1 = red[2][0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) { mx = fmaxf(mx, red[0][i]); m0 = fmaxf(m0, red[1][i]); m1 = fmaxf(m1, red[2][i]); }
+  // (the same expressions as logmel_dct_kernel / contrast_db_kernel: the two forms give identical values)
+  const float reflog = log10f(fmaxf(amin, mx));
+  const float flo = (top_db >= 0.f) ? 10.f * (log10f(fmaxf(amin, mx)) - reflog) - top_db : -3.4e38f;
+  for (int64_t i = tid; i < n; i += NT) db[i] = fmaxf(10.f * (log10f(fmaxf(amin, src[i])) - reflog), flo);
+  const float f0 = (c_top_db >= 0.f) ? 10.f * log10f(fmaxf(c_amin, m0)) - c_top_db : -3.4e38f;
+  const float f1 = (c_top_db >= 0.f) ? 10.f * log10f(fmaxf(c_amin, m1)) - c_top_db : -3.4e38f;
+  for (int64_t i = tid; i < nc; i += NT) {
+    const float a = fmaxf(10.f * log10f(fmaxf(c_amin, pk[i])), f0);
+    const float c = fmaxf(10.f * log10f(fmaxf(c_amin, vl[i])), f1);
+    ob[(int64_t)(K + 2) * T + i] = a - c;
+  }
+  const float* st = stats + b * (int64_t)SYG_NSTAT * T;
+  for (int64_t t = tid; t < T; t += NT) {
+    ob[(int64_t)K * T + t] = st[SYG_STAT_CENTROID * T + t];
+    ob[(int64_t)(K + 1) * T + t] = st[SYG_STAT_ROLLOFF_BIN * T + t] * binhz;
+  }
+  __syncthreads();
+  const int ktiles = (K + 15) / 16, ttiles = (int)((T + 15) / 16);
+  const int f = lane & 15, g = lane >> 4;
+  for (int tile = w; tile < ktiles * ttiles; tile += NT / 64) {
+    const int kt = tile / ttiles, tt = tile % ttiles;
+    const int krow = kt * 16 + f;
+    const int64_t tcol = (int64_t)tt * 16 + f;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int m0i = 0; m0i < M; m0i += 4) {
+      const int m = m0i + g;
+      const float a = (krow < K && m < M) ? dct[krow * M + m] : 0.f;
+      const float bv = (tcol < T && m < M) ? db[(int64_t)m * T + tcol] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + 4 * g + r;
+      if (k < K && tcol < T) ob[(int64_t)k * T + tcol] = acc[r];
+    }
+  }
+}
+
 }  // namespace
 }  // namespace syg
 
 using namespace syg;
+
+extern "C" int syg_feature_block_f32(const float* mel, int64_t B, int M, int64_t T, const float* dct, int K, float amin,
+                                     float top_db, const float* stats, float binhz, const float* contrast_pv, int R,
+                                     float c_amin, float c_top_db, float* block_out, void* stream) {
+  SYG_REQUIRE(mel && dct && stats && contrast_pv && block_out, "feature_block: null pointer argument");
+  SYG_REQUIRE(B >= 1 && B < (int64_t)0x7fffffff && M >= 1 && T >= 1 && K >= 1 && K <= M && R >= 1,
+              "feature_block: bad shape (B=%lld M=%d T=%lld K=%d R=%d)", (long long)B, M, (long long)T, K, R);
+  SYG_REQUIRE(amin > 0.f && c_amin > 0.f, "feature_block: amin must be strictly positive");
+  const size_t lds = (size_t)M * (size_t)T * sizeof(float);
+  SYG_REQUIRE(lds <= 150 * 1024, "feature_block: the clip's dB matrix (%d x %lld) does not fit LDS; use "
+              "syg_logmel_dct_f32 + syg_contrast_db_f32", M, (long long)T);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)feature_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) { set_error("feature_block: cannot reserve %zu B of LDS", lds); return SYG_E_LAUNCH; }
+  }
+  hipLaunchKernelGGL(feature_block_kernel, dim3((unsigned)B), dim3(NT), lds, (hipStream_t)stream, mel, M, T, dct, K, amin,
+                     top_db, stats, binhz, contrast_pv, R, c_amin, c_top_db, block_out);
+  SYG_CHECK_LAUNCH("feature_block");
+  return SYG_OK;
+}
 
 extern "C" int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const float* dct, int K,
                                   const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,

@@ -81,6 +81,7 @@ struct MelPlan {
 
 struct ContrastPlan {
   int n_rows;
+  int ascending;     // 1: lo[] and hi[] are non-decreasing (a band never starts below an earlier band's start)
   int lo[SYG_MAX_BANDS];
   int hi[SYG_MAX_BANDS];
   int k[SYG_MAX_BANDS];
@@ -532,12 +533,63 @@ __device__ __forceinline__ void contrast_extract(lds_row prow, int lane, int lo,
   }
 }
 
+// Wide bands (R = 12 registers per lane: 449..768 bins, config C4's 751-bin top band with k = 15).  The register form
+// above pays 2 R selects per extraction to shift two sorted lists; here a lane sorts its values ONCE into one
+// ascending list, parks it transposed in a dead part of its own row -- words [0, 64 R) of the row: the bands below
+// this one are finished and this band's values are in registers (the caller guarantees ascending band order and
+// 64 R <= ppos(hi)) -- and an extraction moves a head index and re-reads one word: the largest values are consumed
+// from the top of the list, the smallest from the bottom, independently (as two sorted copies would be).
+template <int R>
+__device__ __forceinline__ void contrast_extract_lds(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
+  typedef __attribute__((address_space(3))) float* lds_wrow;
+  lds_wrow wrow = (lds_wrow)prow;
+  float v[R];
+  int nv = 0;                                     // valid values of this lane
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = r * 64 + lane;
+    const float p = prow[ppos(lo + (i < n ? i : 0))];
+    v[r] = (i < n) ? p : 3.4e38f;                 // pads sort to the top of the list and are never a head
+    nv += (i < n) ? 1 : 0;
+  }
+#pragma unroll
+  for (int c = 0; c < SortNet<R>::N; ++c) {
+    constexpr auto& P = SortNet<R>::P;
+    const int i = P[c][0], j = P[c][1];
+    const float a = v[i], b = v[j];
+    v[i] = fminf(a, b); v[j] = fmaxf(a, b);
+  }
+  wave_lds_sync();                                // every lane has read its band values: the row may be overwritten
+#pragma unroll
+  for (int r = 0; r < R; ++r) wrow[r * 64 + lane] = v[r];
+  wave_lds_sync();
+  int ht = nv - 1, hb = 0;                        // head indices: next largest / next smallest of this lane
+  float MHl = (nv > 0) ? wrow[(nv > 0 ? ht : 0) * 64 + lane] : -1.f, MLl = (nv > 0) ? v[0] : 3.4e38f;
+  spk = 0.f; svl = 0.f;
+  for (int it = 0; it < k; ++it) {
+    float MH = MHl, ML = MLl;
+    wave_maxmin(MH, ML);
+    const int fh = __ffsll((long long)__ballot(MHl == MH)) - 1;
+    const int fl = __ffsll((long long)__ballot(MLl == ML)) - 1;
+    ht -= (lane == fh) ? 1 : 0;
+    hb += (lane == fl) ? 1 : 0;
+    // (a lane re-reads its heads every round: the address only moves in the two winning lanes)
+    const float nh = wrow[(ht >= 0 ? ht : 0) * 64 + lane], nl = wrow[(hb < nv ? hb : 0) * 64 + lane];
+    MHl = (ht >= 0) ? nh : -1.f;
+    MLl = (hb < nv) ? nl : 3.4e38f;
+    spk += fsqrt(MH);
+    svl += fsqrt(ML);
+  }
+}
+
 // mean of the k smallest and k largest MAGNITUDES of bins [lo, hi) of one LDS power row (identical to sorting,
 // as librosa does: values are non-negative, selection on power == selection on magnitude).
 //   bands of <= 768 bins with k <= 16 : register extraction, specialised by registers per lane;
 //   otherwise                         : radix select of the k-th order statistic + tail sum closed with the
 //                                       tie count.
-__device__ __noinline__ float2 row_contrast(lds_row prow, int lane, int lo, int hi, int k) {   // (peak, valley)
+// may_park: the bands come in ascending order and the row's statistics are done, so a wide band may park its sorted
+// lists in the part of the row below its own end (contrast_extract_lds)
+__device__ __noinline__ float2 row_contrast(lds_row prow, int lane, int lo, int hi, int k, int may_park) {   // (peak, valley)
   const int n = hi - lo;
   if (n <= 768 && k <= 16) {
     float spk, svl;
@@ -545,6 +597,7 @@ __device__ __noinline__ float2 row_contrast(lds_row prow, int lane, int lo, int 
     else if (n <= 128) contrast_extract<2>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 256) contrast_extract<4>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 448) contrast_extract<7>(prow, lane, lo, n, k, spk, svl);
+    else if (may_park && ppos(hi - 1) >= 64 * 12) contrast_extract_lds<12>(prow, lane, lo, n, k, spk, svl);
     else contrast_extract<12>(prow, lane, lo, n, k, spk, svl);
     const float rk = frcp((float)k);
     return make_float2(spk * rk, svl * rk);
@@ -965,7 +1018,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
                     (gptr)(stats_out + (b * SYG_NSTAT) * T + t), (int)T);
         if (contrast_out != nullptr) {
           for (int r = 0; r < cplan.n_rows; ++r) {
-            const float2 pv = row_contrast((lds_row)prow, lane, cpl[r], cpl[SYG_MAX_BANDS + r], cpl[2 * SYG_MAX_BANDS + r]);
+            const float2 pv = row_contrast((lds_row)prow, lane, cpl[r], cpl[SYG_MAX_BANDS + r], cpl[2 * SYG_MAX_BANDS + r],
+                                           cplan.ascending);
             if (lane == 0) {
               contrast_out[((b * 2 + 0) * cplan.n_rows + r) * T + t] = pv.x;
               contrast_out[((b * 2 + 1) * cplan.n_rows + r) * T + t] = pv.y;
@@ -1157,6 +1211,9 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
                       cp.k[r] <= cp.hi[r] - cp.lo[r],
                   "stft2048_mel: contrast band %d invalid (lo=%d hi=%d k=%d)", r, cp.lo[r], cp.hi[r], cp.k[r]);
     }
+    cp.ascending = 1;
+    for (int r = 1; r < cp.n_rows; ++r)
+      if (cp.lo[r] < cp.hi[r - 1] - 1 || cp.hi[r] < cp.hi[r - 1]) cp.ascending = 0;   // (a band may include the bin below it)
   }
   if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f &&
                                  stats_mask > 0 && stats_mask < 32 && T < ((int64_t)1 << 27),
