@@ -49,10 +49,13 @@ const char* syg_last_error(void);
  *   y          [B, L] float32, row stride ldy            (clips)
  *   window     [2048] float32  periodic analysis window (already centre-padded)
  *   twiddle    [2048] complex  W_2048^k = exp(-2*pi*i*k/2048)
- *   wpacked    packed block-sparse mel weights, [group of 4 k-steps][lane][4] (see sygnals_amd/_tables.py);
- *              the table must end with >= 20 all-zero rows (5 groups) after the last segment: every wave
- *              pre-loads 5 groups from its woff unconditionally
- *   plan_host  HOST int32[2 + 4*16]: {n_tiles, n_waves (8 or 16), tile[16], k0[16], nsteps[16], woff[16]}
+ *   wpacked    packed block-sparse mel weights for v_mfma_f32_4x4x1_16b_f32 (sygnals_amd/_tables.py: pack_mel_plan):
+ *              [wave][steps / 4][64 lanes][4] A operands (lane l of step i: basis[4 g + (l & 3)][k0 + i] of its slot
+ *              l >> 4), then >= 6 groups of zero rows (every wave pre-loads 6 groups unconditionally), then four
+ *              int32 tables of 64 entries at float offset table_off: first bin of slot (wave * 4 + s), mel group of the
+ *              slot, first slot of group g, slot count of group g (slots of a group are consecutive, ascending bins)
+ *   plan_host  HOST int32[5]: {2 (layout), n_waves (8 or 16), steps (multiple of 4), n_groups = ceil(n_mels / 4) <= 64,
+ *              table_off}
  *   mel_out    [B, n_mels, T] float32 mel POWER spectrogram
  *   stats_out  optional [B, SYG_NSTAT, T] float32 per-frame spectral statistics
  *              (NULL to skip), rows in SYG_STAT_* order; only the rows selected by stats_mask

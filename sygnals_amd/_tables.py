@@ -76,57 +76,83 @@ def mel_filterbank(sr: float, n_fft: int, n_mels: int = 128, fmin: float = 0.0, 
     return (tri.astype(np.float64) * enorm[:, None]).astype(np.float32)
 
 
-def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
-    """Block-sparse packing of a [M, F] filterbank for v_mfma_f32_16x16x4_f32.
+MEL_MIN_STEPS = 28      # the kernel issues 7 groups of 4 MFMA steps unconditionally
 
-    Rows are grouped in tiles of 16; for each tile only its non-zero column range is kept.
-    The tiles' 4-bin k-steps are split over `waves` contiguous segments (one per wave,
-    balanced greedily).  Returns (wpacked float32 [steps, 64], plan int32 [2 + 4*16] =
-    {n_tiles, n_waves, tile[16], k0[16], nsteps[16], woff[16]})
-    where A[m = l & 15][k = l >> 4] of step i = basis[16*tile + m][k0 + 4*i + k]; rows of `wpacked` are
-    stored four steps at a time as [group][lane][4] so that a lane fetches four steps with one 16-byte load.
+
+def row_pos(k):
+    """Word position of bin k inside a skewed LDS power row of the fused kernel: one pad word after every 16 bins."""
+    return k + (k >> 4)
+
+
+def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
+    """Block-sparse packing of a [M, F] filterbank for v_mfma_f32_4x4x1_16b_f32 (sixteen 4 x 4 blocks per instruction).
+
+    The rows are taken in groups of four; only the non-zero column range of a group is kept and cut into chunks; chunk c
+    is slot c: wave c // 4 runs its four slots side by side, one ROW POSITION per slot and MFMA step.  A slot walks
+    consecutive words of the kernel's skewed power rows (row_pos: a pad word after every 16 bins, which gets a zero
+    weight), so the kernel addresses its B operands with one base and immediate offsets.  `steps` (positions per slot)
+    is the smallest multiple of 4 >= 28 for which the chunks fit the 4 * waves slots.  Returns (wpacked float32, plan
+    int32):
+
+      wpacked  [waves][steps / 4][64 lanes][4]  A operands, four steps per 16-byte load: lane l of step i carries
+               basis[4 g + (l & 3)][bin at position p0 + i] of its slot s = l >> 4 (the four frame groups (l >> 2) & 3
+               see the same weight), zero at pad positions, past the chunk and past the last mel row; then 8 groups of
+               zero rows; then the int32 tables (bit patterns) [slot p0 | slot group | group first slot | group slot
+               count], 64 entries each
+      plan     {2, waves, steps, n_groups, table_off (in floats)}
     """
     basis = np.asarray(basis, dtype=np.float32)
     M, F = basis.shape
-    nt = (M + 15) // 16
     if waves not in (8, 16):
         raise ValueError("waves must be 8 or 16")
-    if nt > waves:
-        raise ValueError(f"n_mels={M} needs {nt} tiles > {waves} waves (max n_mels {16 * waves})")
-    lo = np.zeros(nt, int); hi = np.zeros(nt, int)
-    for t in range(nt):
-        cols = np.flatnonzero(np.any(basis[16 * t:16 * t + 16] != 0, axis=0))
-        if cols.size:
-            lo[t], hi[t] = (cols[0] // 16) * 16, cols[-1] + 1    # segment starts are multiples of 16 bins (row skew)
-    steps = (hi - lo + 3) // 4
-    nw = np.ones(nt, int)
-    for _ in range(waves - nt):
-        nw[int(np.argmax(steps / nw))] += 1
-    tile = -np.ones(MAXW, np.int32); k0 = np.zeros(MAXW, np.int32)
-    ns = np.zeros(MAXW, np.int32); woff = np.zeros(MAXW, np.int32)
-    blocks = []
-    w = 0
-    off = 0
+    ng = (M + 3) // 4
+    if ng > 64:
+        raise ValueError(f"n_mels={M} needs {ng} groups of four rows (max 64: n_mels <= 256)")
+    nslots = 4 * waves
+    rng = []
+    for g in range(ng):
+        cols = np.flatnonzero(np.any(basis[4 * g:4 * g + 4] != 0, axis=0))
+        rng.append((int(cols[0]), int(cols[-1]) + 1) if cols.size else (0, 0))
+
+    def chunks_of(a, b, steps):
+        """Chunks of the position range [row_pos(a), row_pos(b - 1)] in pieces of `steps` positions."""
+        if b <= a:
+            return []
+        p, pe = row_pos(a), row_pos(b - 1) + 1
+        return [(q, min(q + steps, pe)) for q in range(p, pe, steps)]
+
+    steps = MEL_MIN_STEPS
+    while sum(len(chunks_of(a, b, steps)) for a, b in rng) > nslots:
+        steps += 4
+    slot_p0 = np.zeros(64, np.int32); slot_g = -np.ones(64, np.int32)
+    g_first = np.zeros(64, np.int32); g_cnt = np.zeros(64, np.int32)
+    wts = np.zeros((nslots, steps, 4), np.float32)             # [slot][step][row]
+    c = 0
+    for g, (a, b) in enumerate(rng):
+        g_first[g] = c
+        for (p0, p1) in chunks_of(a, b, steps):                 # ascending positions = ascending bins
+            slot_p0[c] = p0; slot_g[c] = g
+            for i in range(p1 - p0):
+                p = p0 + i
+                if p % 17 == 16:                                # pad word of the skewed row
+                    continue
+                k = p - p // 17
+                if a <= k < b:
+                    rows = basis[4 * g:min(4 * g + 4, M), k]
+                    wts[c, i, :rows.shape[0]] = rows
+            c += 1
+        g_cnt[g] = c - g_first[g]
+    assert c <= nslots
     lane = np.arange(64)
-    for t in range(nt):
-        per = -(-steps[t] // nw[t]) if steps[t] else 0
-        per = -(-per // 4) * 4                              # whole groups of 4 steps = 16 bins
-        for j in range(nw[t]):
-            s0 = min(j * per, steps[t]); s1 = min((j + 1) * per, steps[t])
-            n4 = -(-(s1 - s0) // 4) * 4                     # padded with zero-weight steps to a multiple of 4
-            tile[w] = t; k0[w] = (lo[t] + 4 * s0) if s1 > s0 else 0; ns[w] = n4; woff[w] = off
-            if s1 > s0:
-                rows = 16 * t + (lane & 15)[None, :]
-                cols = (lo[t] + 4 * np.arange(s0, s0 + n4))[:, None] + (lane >> 4)[None, :]
-                ok = (rows < M) & (cols < F) & (np.arange(s0, s0 + n4) < s1)[:, None]
-                blk = np.where(ok, basis[np.minimum(rows, M - 1), np.minimum(cols, F - 1)], 0.0).astype(np.float32)
-                # device layout: [group of 4 steps][lane][step in group] -> one float4 per lane per group
-                blocks.append(blk.reshape(n4 // 4, 4, 64).transpose(0, 2, 1).reshape(n4, 64))
-                off += n4
-            w += 1
-    blocks.append(np.zeros((32, 64), np.float32))      # tail: the kernel pre-loads 5 groups unconditionally
-    wpacked = np.concatenate(blocks, axis=0)
-    plan = np.concatenate([[nt, waves], tile, k0, ns, woff]).astype(np.int32)
+    # [wave][step][lane] = wts[wave * 4 + (lane >> 4)][step][lane & 3]
+    A = wts.reshape(waves, 4, steps, 4)[:, lane >> 4, :, lane & 3]          # -> [64 lanes, waves, steps]
+    A = np.transpose(A, (1, 2, 0))                                          # [waves][steps][64]
+    # device layout: [wave][group of 4 steps][lane][step in group]
+    A = A.reshape(waves, steps // 4, 4, 64).transpose(0, 1, 3, 2).reshape(-1)
+    tail = np.zeros(8 * 64 * 4, np.float32)
+    table = np.concatenate([slot_p0, slot_g, g_first, g_cnt]).astype(np.int32)
+    wpacked = np.concatenate([A.astype(np.float32), tail, table.view(np.float32)])
+    plan = np.array([2, waves, steps, ng, A.size + tail.size], dtype=np.int32)
     return np.ascontiguousarray(wpacked), plan
 
 

@@ -71,13 +71,18 @@ constexpr int TW2_STRIDE = 18;   // complex entries per lane class (16 + 2 pad: 
 constexpr int TW2_FLOATS = 4 * TW2_STRIDE * 2;
 constexpr int TW1_FLOATS = 15 * 64 * 2;
 
+// Block-sparse filterbank plan for v_mfma_f32_4x4x1_16b_f32 (sygnals_amd/_tables.py: pack_mel_plan): the mel rows are
+// taken in groups of four; the non-zero bin range of a group is cut into chunks of at most `steps` bins, one chunk per
+// (wave, slot) -- a wave runs four slots side by side, one bin per slot and step.  The tables sit behind the packed
+// weights in the same device buffer (int32, 4 x 64 entries from `table_off`, in floats):
+//   [0, 64) first row POSITION ppos(bin) of slot (wave * 4 + s)   [64, 128) mel group of the slot (-1: unused)
+//   [128, 192) first slot of mel group g          [192, 256) number of slots of group g
 struct MelPlan {
-  int n_tiles;
-  int tile[MAXW];
-  int k0[MAXW];
-  int nsteps[MAXW];
-  int woff[MAXW];
+  int steps;        // row positions per slot = MFMA steps per wave and tile (a multiple of 4, at least 28)
+  int n_groups;     // mel groups of four rows
+  int table_off;    // offset (in floats) of the tables inside wpacked
 };
+constexpr int MTAB_INTS = 256;
 
 struct ContrastPlan {
   int n_rows;
@@ -722,7 +727,7 @@ struct Lds {
   static constexpr int TILE_T = WAVES;
   static constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
   static constexpr int SLAB_FLOATS = WAVES * 16 * TILE_T;
-  static constexpr int CPL_FLOATS = 3 * SYG_MAX_BANDS;
+  static constexpr int CPL_FLOATS = 3 * SYG_MAX_BANDS + MTAB_INTS;   // contrast plan + the mel plan's slot / group tables
   static constexpr int STAGE_FLOATS = (WAVES - 1) * 512 + NFFT;
   static constexpr int O_SLAB = P_FLOATS;
   static constexpr int O_TW2 = O_SLAB + SLAB_FLOATS;
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     if (mf.lifter != nullptr && tid < mf.n_mfcc) dctl[mf.n_mfcc * n_mels + tid] = mf.lifter[tid];
   }
 
-  int ns = 0, woff = 0, k0 = 0;
+  int* mtab = cpl + 3 * SYG_MAX_BANDS;              // [4][64]: slot first bin, slot group, group first slot, group slots
   if (!COMPLEX_OUT) {
     // pad words of the skewed rows, the row tails and the slack are read against zero weights: they must
     // hold finite values, so the whole buffer (and the slab behind it) is cleared once
@@ -799,9 +804,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #pragma unroll
     for (int r = 0; r < SYG_MAX_BANDS; ++r)
       if (tid == r) { cpl[r] = cplan.lo[r]; cpl[SYG_MAX_BANDS + r] = cplan.hi[r]; cpl[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
-#pragma unroll
-    for (int ww = 0; ww < WAVES; ++ww)
-      if (w == ww) { ns = plan.nsteps[ww]; woff = plan.woff[ww]; k0 = plan.k0[ww]; }
+    for (int i = tid; i < MTAB_INTS; i += NTHREADS) mtab[i] = reinterpret_cast<const int*>(wpacked)[plan.table_off + i];
   }
   if (LOAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -904,18 +907,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     int tdep = lane;
     TICK(5, tdep);
 #endif
-    // The filterbank operands of this wave's segment are the same for every tile but cannot stay resident
-    // (the FFT phase needs all 128 VGPRs): the first NPRE groups are re-fetched here, where the registers are
-    // free again, so that their L2 latency overlaps the wait at barrier A.
-    constexpr int NPRE = 5;            // unconditional: the packed table ends with NPRE groups of zero rows
+    // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT
+    // phase needs all 128 VGPRs): the first NPRE groups of four steps are re-fetched here, where the registers are free
+    // again, so that their L2 latency overlaps the wait at barrier A.
+    constexpr int NPRE = 7;            // unconditional: every wave's segment holds >= NPRE groups (zero padded)
     int la = lane;                     // laundered: keeps the (tile-invariant) loads inside the loop, and
     asm volatile("" : "+v"(la)::"memory");   // behind the row stores (the FFT results are dead by now)
-    const int f = la & 15, g = la >> 4;
-    const float4* wp4 = reinterpret_cast<const float4*>(wpacked) + (int64_t)(woff >> 2) * 64 + la;
-    const int ng = ns >> 2;
+    const int ng = plan.steps >> 2;
+    const float4* wp4 = reinterpret_cast<const float4*>(wpacked) + (int64_t)w * ng * 64 + la;
     float4 apre[NPRE];
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) apre[q] = wp4[q * 64];
+    const int pslot = mtab[w * 4 + (la >> 4)];          // row POSITION (skewed, see ppos()) of this lane's slot
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (staged mode: the next tile's samples have landed too)
     __syncthreads();                                    // barrier A: rows complete
     TICK(6, tdep);
@@ -926,36 +929,41 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       TICK(10, tdep);
     }
 
-    // ---- phase 2: block-sparse mel projection on the matrix cores
+    // ---- phase 2: block-sparse mel projection on the matrix cores, v_mfma_f32_4x4x1_16b_f32: sixteen independent
+    // 4 x 4 outer-product blocks per instruction.  Block b = lane >> 2 = (slot s = b >> 2, frame group h = b & 3):
+    // A = four mel rows of the slot's group at the slot's current row position (lane & 3 = row), B = the power at that
+    // position in the four frames 4 h + (lane & 3), D[row][frame] accumulates in four registers.  A slot walks
+    // CONSECUTIVE WORDS of the skewed power rows -- the pad word after every 16 bins carries a zero weight -- so every
+    // B read is one base register plus an immediate offset, all of them are in flight together, and the MFMAs then
+    // issue back to back.  Only the non-zero ranges of the 4-row groups are multiplied (1221 bin-steps per tile at
+    // 40 mels against 4544 for 16-row tiles).
     {
-      // k0 is a multiple of 16, so ppos(k0 + 4i) = ppos(k0) + 4i + (i >> 2): one base register and
-      // compile-time offsets.  The A operands are packed four steps per lane (one 16-byte load feeds
-      // four MFMAs); the step count of a segment is a multiple of 4 (zero-weight padding).
-      const float* pq = Pbuf + (f & (TILE_T - 1)) * P_STRIDE + g + ppos(k0);
+      const int fr = (4 * ((la >> 2) & 3) + (la & 3)) & (TILE_T - 1);       // frame of this lane's block column
+      const float* pq = Pbuf + fr * P_STRIDE + pslot;
+      float bq[4 * NPRE];
+#pragma unroll
+      for (int i = 0; i < 4 * NPRE; ++i) bq[i] = pq[i];
       v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NPRE; ++q) {
-        if (q < ng) {
-          const float* pb = pq + 17 * q;          // 16 bins + 1 pad word per group of four steps
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].x, pb[0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].y, pb[4], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].z, pb[8], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[q].w, pb[12], acc, 0, 0, 0);
-        }
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].x, bq[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].y, bq[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].z, bq[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].w, bq[4 * q + 3], acc, 0, 0, 0);
       }
-#pragma unroll 2
-      for (int q = NPRE; q < ng; ++q) {
+      for (int q = NPRE; q < ng; ++q) {       // (filterbanks whose chunks are longer than 28 row positions)
         const float4 a4 = wp4[q * 64];
-        const float* pb = pq + 17 * q;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, pb[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, pb[4], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, pb[8], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, pb[12], acc, 0, 0, 0);
+        const float* pb = pq + 4 * q;
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, pb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, pb[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, pb[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, pb[3], acc, 0, 0, 0);
       }
-      if (f < TILE_T) {
-        float* sl = slab + w * (16 * TILE_T);
+      // partial sums of (slot, mel row r, frame): slab[wave][slot][r][frame]
+      if (4 * ((la >> 2) & 3) + (la & 3) < TILE_T) {
+        float* sl = slab + (w * 4 + (la >> 4)) * (4 * TILE_T) + fr;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sl[(4 * g + r) * TILE_T + f] = acc[r];
+        for (int r = 0; r < 4; ++r) sl[r * TILE_T] = acc[r];
       }
       TICK(7, acc[0]);
     }
@@ -972,27 +980,34 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const bool clip_done = (MODE == 3) && (t0 + TILE_T >= T);
     if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
 
-    // ---- reduce the per-wave partial tiles in a fixed order; a wave handles 64 consecutive outputs of one
-    // mel tile, so the segment test is wave-uniform
+    // ---- combine the slots of each mel group in a fixed order (ascending bins): one wave per group of four mel rows,
+    // lane = (row, frame); the slots of a group are consecutive
     {
-      constexpr int WPT = TILE_T / 4;             // waves per 16 x TILE_T mel tile
-      for (int e = w; e < plan.n_tiles * WPT; e += WAVES) {
-        const int mt = e / WPT;
-        const int idx = (e - mt * WPT) * 64 + lane;
-        const int m = idx / TILE_T, tt = idx & (TILE_T - 1);
-        float sum = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww)
-          if (plan.tile[ww] == mt) sum += slab[ww * (16 * TILE_T) + idx];
-        const int mel = mt * 16 + m;
-        if (MODE == 3) {
-          if (mel < n_mels) {
-            clipmel[mel * mf.tp + (int)t0 + tt] = sum;     // frames >= T hold 0 (rows were cleared)
-            cmax = fmaxf(cmax, sum);                        // power is non-negative
+      constexpr int GL = 4 * TILE_T;               // outputs per group and tile (64 at 16 frames)
+      for (int g = w; g < plan.n_groups; g += WAVES) {
+        const int first = __builtin_amdgcn_readfirstlane(mtab[128 + g]);
+        const int cnt = __builtin_amdgcn_readfirstlane(mtab[192 + g]);
+        if (GL == 64 || lane < GL) {
+          const int m = lane / TILE_T, tt = lane & (TILE_T - 1);
+          const float* sp = slab + first * GL + lane;
+          float sum = 0.f;
+          int q = 0;
+          for (; q + 4 <= cnt; q += 4) {
+            const float a0 = sp[0], a1 = sp[GL], a2 = sp[2 * GL], a3 = sp[3 * GL];
+            sum += a0; sum += a1; sum += a2; sum += a3;
+            sp += 4 * GL;
           }
-          if (SYG_ABL != 9 && mel_out != nullptr && mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
-        } else {
-          if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+          for (; q < cnt; ++q) { sum += sp[0]; sp += GL; }
+          const int mel = g * 4 + m;
+          if (MODE == 3) {
+            if (mel < n_mels) {
+              clipmel[mel * mf.tp + (int)t0 + tt] = sum;     // frames >= T hold 0 (rows were cleared)
+              cmax = fmaxf(cmax, sum);                        // power is non-negative
+            }
+            if (SYG_ABL != 9 && mel_out != nullptr && mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+          } else {
+            if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+          }
         }
       }
     }
@@ -1160,24 +1175,19 @@ using namespace syg;
 namespace syg {
 namespace {
 int parse_mel_plan(const char* who, const int32_t* plan_host, int n_mels, MelPlan& plan) {
+  // plan_host: {2 (layout version), waves, steps, n_groups, table_off}
+  SYG_REQUIRE(plan_host[0] == 2, "%s: mel plan layout %d, this library needs layout 2 (sygnals_amd._tables.pack_mel_plan)",
+              who, plan_host[0]);
   const int waves = plan_host[1];
   SYG_REQUIRE(waves == 8 || waves == 16, "%s: plan must be built for 8 or 16 waves (got %d)", who, waves);
-  SYG_REQUIRE(n_mels >= 1 && n_mels <= 16 * waves, "%s: n_mels must be in [1, %d] (got %d)", who, 16 * waves, n_mels);
-  memset(&plan, 0, sizeof(plan));
-  plan.n_tiles = plan_host[0];
-  SYG_REQUIRE(plan.n_tiles == (n_mels + 15) / 16, "%s: plan has %d tiles, n_mels=%d needs %d", who, plan.n_tiles,
-              n_mels, (n_mels + 15) / 16);
-  for (int w = 0; w < MAXW; ++w) {
-    plan.tile[w] = plan_host[2 + w];
-    plan.k0[w] = plan_host[2 + MAXW + w];
-    plan.nsteps[w] = plan_host[2 + 2 * MAXW + w];
-    plan.woff[w] = plan_host[2 + 3 * MAXW + w];
-    if (w >= waves) { plan.tile[w] = -1; plan.nsteps[w] = 0; plan.k0[w] = 0; plan.woff[w] = 0; }
-    SYG_REQUIRE(plan.tile[w] >= -1 && plan.tile[w] < plan.n_tiles, "%s: bad tile in plan", who);
-    SYG_REQUIRE(plan.nsteps[w] >= 0 && plan.k0[w] >= 0 && plan.k0[w] + 4 * plan.nsteps[w] <= NBIN + 15 &&
-                    plan.woff[w] >= 0 && plan.k0[w] % 16 == 0 && plan.nsteps[w] % 4 == 0 && plan.woff[w] % 4 == 0,
-                "%s: plan segment %d out of range (k0=%d nsteps=%d)", who, w, plan.k0[w], plan.nsteps[w]);
-  }
+  plan.steps = plan_host[2];
+  plan.n_groups = plan_host[3];
+  plan.table_off = plan_host[4];
+  SYG_REQUIRE(n_mels >= 1 && plan.n_groups == (n_mels + 3) / 4 && plan.n_groups <= 64,
+              "%s: plan has %d groups of four mel rows, n_mels=%d needs %d (at most 64)", who, plan.n_groups, n_mels,
+              (n_mels + 3) / 4);
+  SYG_REQUIRE(plan.steps >= 28 && plan.steps % 4 == 0 && plan.steps <= P_STRIDE, "%s: bad step count %d", who, plan.steps);
+  SYG_REQUIRE(plan.table_off >= waves * plan.steps * 64 && plan.table_off % 4 == 0, "%s: bad table offset", who);
   return SYG_OK;
 }
 }  // namespace

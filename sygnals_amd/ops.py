@@ -104,7 +104,7 @@ class MelConfig:
         self.basis_host = basis
         self.n_mels = n_mels
         waves = fused_waves() if waves is None else waves
-        if n_fft == 2048 and n_mels <= 16 * waves:
+        if n_fft == 2048 and n_mels <= 256:
             wp, plan = T.pack_mel_plan(basis, waves)
             self.wpacked = _dev(wp)
             self.plan = np.ascontiguousarray(plan, dtype=np.int32)
@@ -140,7 +140,7 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
         raise ValueError("signal too short for one frame")
     cfg = mel_config(sr, 2048, n_mels, fmin, fmax)
     if cfg.wpacked is None:
-        raise SygnalsHipError(f"fused path supports n_mels <= {16 * fused_waves()}")
+        raise SygnalsHipError("fused path supports n_mels <= 256")
     win = window_dev(window, win_length, 2048)
     tw = twiddle_dev(2048)
     mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
@@ -299,7 +299,7 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
     fused=None picks the one-launch clip-resident form when the clip's mel matrix fits in LDS and there are
     enough clips to fill the chip (a workgroup owns whole clips); True / False force either form.
     """
-    if n_fft != 2048 or n_mels > 16 * fused_waves():
+    if n_fft != 2048 or n_mels > 256:
         # no fused kernel for this shape: complex STFT (any frame length) -> |X|^2 -> dense mel -> dB + DCT
         if fused:
             raise SygnalsHipError(f"mfcc_batch: no fused kernel for n_fft={n_fft}, n_mels={n_mels}")

@@ -24,34 +24,47 @@ def test_mel_filterbank_bit_identical_to_oracle(sr, n_fft, n_mels):
 
 
 @pytest.mark.parametrize("waves", [8, 16])
-@pytest.mark.parametrize("n_mels", [1, 13, 16, 40, 64, 100, 128])
+@pytest.mark.parametrize("n_mels", [1, 13, 16, 40, 64, 100, 128, 256])
 def test_mel_plan_reconstructs_dense_basis(n_mels, waves):
+    """The block-sparse packing for v_mfma_f32_4x4x1_16b_f32: replaying the kernel's addressing (slot = lane >> 4, row =
+    lane & 3, step i at row position p0 + i of the skewed power row) over every (wave, step, lane) rebuilds the dense
+    filterbank exactly; pad positions and everything past a chunk carry zero weights."""
+    if n_mels == 256 and waves == 8:
+        pytest.skip("64 groups of four rows need at least 64 slots = 16 waves")
     W = T.mel_filterbank(48000, 2048, n_mels)
     wp, plan = T.pack_mel_plan(W, waves)
-    assert plan[1] == waves and plan.shape == (66,)
-    nt = plan[0]; tile = plan[2:18]; k0 = plan[18:34]; ns = plan[34:50]; wo = plan[50:66]
-    assert (tile[waves:] == -1).all() and (ns[waves:] == 0).all()
-    assert nt == (n_mels + 15) // 16 and wp.dtype == np.float32 and wp.shape[1] == 64
-    R = np.zeros((16 * nt, 1032), np.float64)
-    lane = np.arange(64)
-    for w in range(waves):
-        assert k0[w] + 4 * ns[w] <= 1025 + 15
-        assert ns[w] % 4 == 0 and wo[w] % 4 == 0 and k0[w] % 16 == 0
-        seg = wp[wo[w]:wo[w] + ns[w]].reshape(-1, 64, 4).transpose(0, 2, 1).reshape(-1, 64)   # undo [group][lane][4]
-        for i in range(ns[w]):
-            cols = k0[w] + 4 * i + (lane >> 4)
-            ok = cols < 1032
-            R[tile[w] * 16 + (lane & 15)[ok], cols[ok]] += seg[i][ok]
-    assert_array_equal(R[:n_mels, :1025], W.astype(np.float64))
-    assert not R[n_mels:].any() and not R[:, 1025:].any()
-    # every tile is covered by consecutive, non-overlapping wave segments
-    assert sorted(set(tile[tile >= 0])) == list(range(nt))
+    assert plan.tolist()[:2] == [2, waves] and plan.shape == (5,) and wp.dtype == np.float32
+    steps, ng, toff = int(plan[2]), int(plan[3]), int(plan[4])
+    assert steps % 4 == 0 and steps >= T.MEL_MIN_STEPS and ng == (n_mels + 3) // 4
+    assert toff == waves * steps * 64 + 8 * 64 * 4 and wp.size == toff + 256
+    assert not wp[waves * steps * 64:toff].any()                       # the zero groups the kernel may pre-load
+    tab = wp[toff:].view(np.int32)
+    p0, sg, gf, gc = tab[:64], tab[64:128], tab[128:192], tab[192:256]
+    A = wp[:waves * steps * 64].reshape(waves, steps // 4, 64, 4)       # [wave][group][lane][step in group]
+    R = np.zeros((4 * ng, 1025), np.float64)
+    for slot in range(4 * waves):
+        w, s = divmod(slot, 4)
+        for i in range(steps):
+            for h in range(4):                                          # the four frame groups see the same weights
+                a = A[w, i // 4, 16 * s + 4 * h: 16 * s + 4 * h + 4, i % 4]
+                assert_array_equal(a, A[w, i // 4, 16 * s: 16 * s + 4, i % 4])
+            a = A[w, i // 4, 16 * s: 16 * s + 4, i % 4].astype(np.float64)
+            p = int(p0[slot]) + i
+            if sg[slot] < 0 or p % 17 == 16 or p - p // 17 > 1024:
+                assert not a.any()                                      # unused slot / pad word / past the last bin
+                continue
+            R[4 * sg[slot]: 4 * sg[slot] + 4, p - p // 17] += a
+    assert_array_equal(R[:n_mels], W.astype(np.float64))
+    assert not R[n_mels:].any()
+    # the slots of a group are consecutive and in ascending position order
+    for g in range(ng):
+        sl = np.arange(gf[g], gf[g] + gc[g])
+        assert (sg[sl] == g).all() and (np.diff(p0[sl]) == steps).all()
+    assert gc[:ng].sum() == (sg >= 0).sum() <= 4 * waves
 
 
 def test_mel_plan_rejects_too_many_mels():
-    with pytest.raises(ValueError, match="max n_mels 128"):
-        T.pack_mel_plan(np.ones((129, 1025), np.float32), 8)
-    with pytest.raises(ValueError, match="max n_mels 256"):
+    with pytest.raises(ValueError, match="max 64"):
         T.pack_mel_plan(np.ones((257, 1025), np.float32), 16)
     with pytest.raises(ValueError, match="waves must be 8 or 16"):
         T.pack_mel_plan(np.ones((16, 1025), np.float32), 4)

@@ -3,9 +3,9 @@ import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from sygnals_amd import ops
-from oracle import cpu_ref as O
+from sygnals_amd.synth import synth_clips
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-Y = O.synth_clips(32, 48000, 48000, seed=1)
+Y = synth_clips(32, 48000, 48000, seed=1)
 y = ops.to_device_f32(np.tile(Y, (B // 32, 1)))
 from sygnals_amd import _tables as TT
 CPLAN = TT.contrast_plan(np.fft.rfftfreq(2048, 1/48000), 48000)
@@ -24,21 +24,6 @@ for name, fn in (("mfcc", lambda: ops.mfcc_batch(y, 48000, n_mels=40)),
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print(f"{name}: {ms*1e3:.1f} us/step  {B*48000/ms/1e3:.0f} Msamples/s  roofline {B*196888/ms/1e-3/8e12*100:.2f}%")
-
-# --- experiment: FFT phase only (mel plan with zero steps) ---
-cfg = ops.mel_config(48000, 2048, 40)
-saved = cfg.plan.copy()
-cfg.plan[34:50] = 0
-def fftonly():
-    ops.stft2048_mel(y, 48000, n_mels=40)
-for _ in range(3): fftonly()
-torch.cuda.synchronize()
-e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20): fftonly()
-e1.record(); torch.cuda.synchronize()
-print(f"fft-only (no MFMA steps): {e0.elapsed_time(e1)/20*1e3:.1f} us/step")
-cfg.plan[:] = saved
 
 # --- raw C-ABI call loop of the one-launch MFCC (no Python wrapper work per step) ---
 import ctypes as C
