@@ -118,7 +118,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
         """Chunks of the position range [row_pos(a), row_pos(b - 1)] in pieces of `steps` positions."""
         if b <= a:
             return []
-        p, pe = row_pos(a), row_pos(b - 1) + 1
+        p, pe = row_pos(a) & ~1, row_pos(b - 1) + 1          # even start: the kernel reads two positions per LDS word pair
         return [(q, min(q + steps, pe)) for q in range(p, pe, steps)]
 
     steps = MEL_MIN_STEPS
@@ -137,7 +137,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
                 if p % 17 == 16:                                # pad word of the skewed row
                     continue
                 k = p - p // 17
-                if a <= k < b:
+                if a <= k < b:                                  # (a chunk may start one position below its range)
                     rows = basis[4 * g:min(4 * g + 4, M), k]
                     wts[c, i, :rows.shape[0]] = rows
             c += 1

@@ -939,10 +939,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // 40 mels against 4544 for 16-row tiles).
     {
       const int fr = (4 * ((la >> 2) & 3) + (la & 3)) & (TILE_T - 1);       // frame of this lane's block column
-      const float* pq = Pbuf + fr * P_STRIDE + pslot;
+      const float* pq = Pbuf + fr * P_STRIDE + pslot;     // 8-byte aligned: P_STRIDE and the slot positions are even
       float bq[4 * NPRE];
 #pragma unroll
-      for (int i = 0; i < 4 * NPRE; ++i) bq[i] = pq[i];
+      for (int i = 0; i < 2 * NPRE; ++i) {                 // two positions per LDS read (half the LDS cycles of b32 reads)
+        const float2 v2 = reinterpret_cast<const float2*>(pq)[i];
+        bq[2 * i] = v2.x; bq[2 * i + 1] = v2.y;
+      }
       v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NPRE; ++q) {
@@ -968,9 +971,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       TICK(7, acc[0]);
     }
     // ---- staged mode: the next tile's frame (LDS -> registers); once every wave holds its frame (barrier B)
-    // the stage is refilled with the tile after next.  With statistics the fetch waits until after them
-    // (the registers are needed there) and the refill starts behind the closing barrier instead.
-    constexpr bool FETCH_EARLY = (LOAD == 2) && (MODE == 0 || MODE == 3);
+    // the stage is refilled with the tile after next.  The statistics of MODE 1 run behind barrier B with the fetched
+    // frame live in callee-saved registers (the out-of-line row functions stay inside the caller-saved ones), so that
+    // mode needs no barrier of its own.
+    constexpr bool FETCH_EARLY = (LOAD == 2);
     if (FETCH_EARLY) {
       have = false;
       if (tile + 1 < tile_end) fetch(tile + 1);
@@ -1042,18 +1046,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           }
         }
       }
-      if (LOAD == 2) {
-        have = false;
-        if (tile + 1 < tile_end) fetch(tile + 1);
-      }
-      __syncthreads();   // the rows are overwritten by the next tile's FFT phase
-      if (LOAD == 2 && tile + 2 < tile_end) dma(tile + 2);
-    } else if (LOAD == 2 && MODE == 1) {
-      // (MODE 1 launched without statistics outputs does not happen; keep the pipeline correct anyway)
-      have = false;
-      if (tile + 1 < tile_end) fetch(tile + 1);
-      __syncthreads();
-      if (tile + 2 < tile_end) dma(tile + 2);
+      // (a wave only reads and -- parking sorted lists -- overwrites ITS OWN row here; every projection that read the
+      // row finished before barrier B, and the row is next written by this wave's own FFT: no barrier needed)
     }
   }
   if (MODE == 3 && pend_b >= 0) {
@@ -1188,6 +1182,7 @@ int parse_mel_plan(const char* who, const int32_t* plan_host, int n_mels, MelPla
               (n_mels + 3) / 4);
   SYG_REQUIRE(plan.steps >= 28 && plan.steps % 4 == 0 && plan.steps <= P_STRIDE, "%s: bad step count %d", who, plan.steps);
   SYG_REQUIRE(plan.table_off >= waves * plan.steps * 64 && plan.table_off % 4 == 0, "%s: bad table offset", who);
+  static_assert(P_STRIDE % 2 == 0, "slot reads are 8-byte words");
   return SYG_OK;
 }
 }  // namespace
