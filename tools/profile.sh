@@ -1,14 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel-trace stats + PMC counters for the headline bench.
 # Each PMC set is its own run (gpurun refuses --pmc combined with the trace domains).
+#   tools/profile.sh [outdir]
 set -u
 cd "$(dirname "$0")/.."
-OUT=${1:-gpurun_out/prof}
+OUT=${1:-gpurun_out/prof_r02}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 20 --warmup 200 --no-cpu-baseline"
-# the trace pass runs the default step counts (200 warm-up + 500 timed + 100 for the roofline block): its per-dispatch
-# average is then dominated by steady-clock launches, like the figure bench.py prints
+CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+# the trace pass runs the default step counts (300 pre-warm + 50 warm-up + 500 timed + 100 for the roofline block): its
+# per-dispatch average is then dominated by steady-clock launches, like the figure bench.py prints
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc1" -- $CMD > "$OUT/pmc1.log" 2>&1
@@ -19,8 +20,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc3" -- $CMD > "$OUT/pm
 echo "pmc3 rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc4" -- $CMD > "$OUT/pmc4.log" 2>&1
 echo "pmc4 rc=$?"
-rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc5" -- $CMD > "$OUT/pmc5.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$OUT/pmc5" -- $CMD > "$OUT/pmc5.log" 2>&1
 echo "pmc5 rc=$?"
-find "$OUT" -name "*.csv" | head -40
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

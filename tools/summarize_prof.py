@@ -27,6 +27,9 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5"):
         for name, ctrs in acc.items():
             if "stft2048" not in name and "logmel" not in name:
                 continue
+            if d == "pmc2" and "SQ_INSTS_MFMA" in ctrs:
+                n = sum(ctrs["SQ_INSTS_MFMA"]) / len(ctrs["SQ_INSTS_MFMA"])
+                print(f"    (MFMA instructions per launch {n:.4g}: 4x4x1_16b blocks = 512 flop each -> {n * 512 / 1e9:.3f} GFLOP per launch)")
             print(d, name)
             for c, v in ctrs.items():
                 print(f"    {c:28s} mean {sum(v)/len(v):.4g}  (n={len(v)})")
