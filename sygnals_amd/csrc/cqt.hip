@@ -82,9 +82,10 @@ __global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restri
 // windows E[n - H2 .. n + H2 + 1], O[n - H2 .. n + H2] the pair needs are read as 8-byte words (lane stride 8 B:
 // conflict-free) and kept in registers -- 12 to 22 LDS reads per two outputs instead of one read per tap and output.
 // A half-band filter (every tap at an even offset from the centre is zero, the centre excepted) needs only the odd
-// samples and the two centre ones: detected once per workgroup from the taps themselves.  Taps are applied in index order.
+// samples and the two centre ones: detected once per workgroup from the taps themselves.  The odd-offset taps are
+// applied first (ascending index), then the even-offset ones.
 template <int NT>
-__global__ __launch_bounds__(DEC_NT) void decimate2_fixed_kernel(const float* __restrict__ x, int64_t L, int64_t ldx,
+__global__ __launch_bounds__(DEC_NT, 8) void decimate2_fixed_kernel(const float* __restrict__ x, int64_t L, int64_t ldx,
                                                                  const float* __restrict__ taps, float scale,
                                                                  float* __restrict__ y, int64_t Lout, int64_t ldy) {
   constexpr int HALF = (NT - 1) / 2;                 // 20: even
@@ -137,33 +138,39 @@ __global__ __launch_bounds__(DEC_NT) void decimate2_fixed_kernel(const float* __
     for (int p = 0; p < PAIRS; ++p) {
       const int nl = 2 * tid + p * 2 * DEC_NT;       // local index of the pair's first output; its window starts at nl
       // x[2 n + c], c = HALF - j:  c even -> E[n + c/2] (staged at nl + H2 + c/2),  c odd -> O[n + (c-1)/2]
-      float ow[2 * H2 + 2], ew[2 * H2 + 2];
+      // one register window serves both parities in turn (the odd samples first, then the even ones): the kernel then
+      // fits 64 VGPRs and can share a CU with the octave products running beside it on another stream
+      float wv[2 * H2 + 2];
       const float2* o2 = reinterpret_cast<const float2*>(O + nl);
       const float2* e2 = reinterpret_cast<const float2*>(E + nl);
 #pragma unroll
-      for (int k = 0; k <= H2; ++k) { const float2 v = o2[k]; ow[2 * k] = v.x; ow[2 * k + 1] = v.y; }
-      if (halfband) {
-        const float2 v = e2[H2 / 2 + 0];             // E[nl + H2], E[nl + H2 + 1]: the two centre samples
-        static_assert(H2 % 2 == 0, "centre pair must be 8-byte aligned");
-        ew[H2] = v.x; ew[H2 + 1] = v.y;
-      } else {
-#pragma unroll
-        for (int k = 0; k <= H2; ++k) { const float2 v = e2[k]; ew[2 * k] = v.x; ew[2 * k + 1] = v.y; }
-      }
+      for (int k = 0; k <= H2; ++k) { const float2 v = o2[k]; wv[2 * k] = v.x; wv[2 * k + 1] = v.y; }
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = HALF - j;
-        const float h = hreg[j];
-        if ((c & 1) == 0) {
-          if (halfband && j != HALF) continue;
-          const int q = H2 + c / 2;                  // window index of E[n + c/2]
-          a0 = fmaf(h, ew[q], a0);
-          a1 = fmaf(h, ew[q + 1], a1);
-        } else {
+        if ((c & 1) != 0) {
           const int q = H2 + (c - 1) / 2;            // (c - 1) / 2 = floor(c / 2) for odd c of either sign
-          a0 = fmaf(h, ow[q], a0);
-          a1 = fmaf(h, ow[q + 1], a1);
+          a0 = fmaf(hreg[j], wv[q], a0);
+          a1 = fmaf(hreg[j], wv[q + 1], a1);
+        }
+      }
+      if (halfband) {
+        static_assert(H2 % 2 == 0, "centre pair must be 8-byte aligned");
+        const float2 v = e2[H2 / 2];                 // E[nl + H2], E[nl + H2 + 1]: the two centre samples
+        a0 = fmaf(hreg[HALF], v.x, a0);
+        a1 = fmaf(hreg[HALF], v.y, a1);
+      } else {
+#pragma unroll
+        for (int k = 0; k <= H2; ++k) { const float2 v = e2[k]; wv[2 * k] = v.x; wv[2 * k + 1] = v.y; }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int c = HALF - j;
+          if ((c & 1) == 0) {
+            const int q = H2 + c / 2;                // window index of E[n + c/2]
+            a0 = fmaf(hreg[j], wv[q], a0);
+            a1 = fmaf(hreg[j], wv[q + 1], a1);
+          }
         }
       }
       const int64_t n = n0 + nl;

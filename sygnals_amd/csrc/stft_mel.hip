@@ -150,9 +150,14 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
 // 1024-point complex forward FFT of the windowed frame + real split.  v[a] holds z[64a + lane] on entry.
 // On exit pair (j, d) holds X[k] in xs[j][d] and X[1024 - k] in xm[j][d] (k = kb_j + 256 d; lane 0 / unit 0:
 // k = 0, 256, 128, 384); lane 0 also returns X[512].
+// NPF > 0: the first NPF 16-byte groups of the wave's filterbank operands (pf_src, 64 float4 apart) are requested
+// behind pass 3 -- the transform's register peak is over there -- so that their L2 latency hides behind the real split
+// and the row stores instead of standing in front of barrier A.
+template <int NPF>
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
                                              const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
-                                             int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512 TARGS) {
+                                             int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512,
+                                             const float4* __restrict__ pf_src, float4* __restrict__ pf TARGS) {
   const int cl = lane >> 2, bp = lane & 3;
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
   dft16(v);
@@ -244,6 +249,12 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   }
   TICK(4, G[0][0].x);
   SETPRIO(1);
+  if (NPF > 0) {
+    int lp = lane;                     // laundered: the loads may not be hoisted above this point (register peak)
+    asm volatile("" : "+v"(lp));
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) pf[q] = pf_src[(int64_t)q * 64 + lp];
+  }
   // ---- real split on mirror pairs
   x512 = make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
 #pragma unroll
@@ -841,6 +852,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const int64_t t = t0 + w;
     if (LOAD != 2) fetch(tile);
     SETPRIO(3);
+    // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT needs
+    // all 128 VGPRs): the first NPRE groups of four steps are re-fetched every tile, behind pass 3 of the transform.
+    constexpr int NPRE = 7;            // unconditional: every wave's segment holds >= NPRE groups (zero padded)
+#ifndef SYG_NEARLY
+#define SYG_NEARLY 0
+#endif
+    constexpr int NEARLY = SYG_NEARLY; // ... of which this many may be requested behind pass 3 already (up to 5 fit the registers;
+                                       // measured: no gain -- barrier A's wait covers the latency either way -- so 0)
+    const int ng = plan.steps >> 2;
+    const float4* wp4w = reinterpret_cast<const float4*>(wpacked) + (int64_t)w * ng * 64;
+    float4 apre[NPRE];
     if (have) {
       // the lane id is laundered through an empty asm each iteration: the LDS / global addresses derived
       // from it are then recomputed per frame (a few integer ops) instead of being hoisted out of the tile
@@ -858,7 +880,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
       TICK(0, v[0].x);
       float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512 TPASS);
+      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre TPASS);
       if (COMPLEX_OUT) {
         float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll
@@ -884,6 +906,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       }
     } else if (!COMPLEX_OUT) {
       for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NEARLY; ++q) apre[q] = wp4w[q * 64 + lane];
     }
     SETPRIO(0);
     if (COMPLEX_OUT) continue;
@@ -907,17 +931,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     int tdep = lane;
     TICK(5, tdep);
 #endif
-    // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT
-    // phase needs all 128 VGPRs): the first NPRE groups of four steps are re-fetched here, where the registers are free
-    // again, so that their L2 latency overlaps the wait at barrier A.
-    constexpr int NPRE = 7;            // unconditional: every wave's segment holds >= NPRE groups (zero padded)
-    int la = lane;                     // laundered: keeps the (tile-invariant) loads inside the loop, and
-    asm volatile("" : "+v"(la)::"memory");   // behind the row stores (the FFT results are dead by now)
-    const int ng = plan.steps >> 2;
-    const float4* wp4 = reinterpret_cast<const float4*>(wpacked) + (int64_t)w * ng * 64 + la;
-    float4 apre[NPRE];
+    int la = lane;                     // laundered: per-lane addresses are recomputed here, not kept across the FFT
+    asm volatile("" : "+v"(la)::"memory");
+    const float4* wp4 = wp4w + la;
 #pragma unroll
-    for (int q = 0; q < NPRE; ++q) apre[q] = wp4[q * 64];
+    for (int q = NEARLY; q < NPRE; ++q) apre[q] = wp4[q * 64];
     const int pslot = mtab[w * 4 + (la >> 4)];          // row POSITION (skewed, see ppos()) of this lane's slot
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (staged mode: the next tile's samples have landed too)
     __syncthreads();                                    // barrier A: rows complete
