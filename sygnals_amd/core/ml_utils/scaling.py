@@ -131,6 +131,30 @@ def scale_features_device(xd, scaler_type: str = "standard", scaler_params: Opti
     return out, scaler
 
 
+def _pivot(features: np.ndarray) -> np.ndarray:
+    """A value near every column's data (median of up to the first 64 finite entries), float64: subtracted on the host
+    BEFORE the float32 cast so that a column with a large offset relative to its spread (mean 1e6, std 1) keeps its
+    precision on the device; the fitted attributes are shifted back afterwards."""
+    head = np.asarray(features[:64], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        piv = np.nanmedian(np.where(np.isfinite(head), head, np.nan), axis=0)
+    return np.where(np.isfinite(piv), piv, 0.0)
+
+
+def _shift_fitted(scaler, piv: np.ndarray) -> None:
+    """Attributes of a scaler fitted on (X - piv) -> the scaler of X (scale-type attributes are shift-invariant)."""
+    if isinstance(scaler, StandardScaler):
+        if scaler.mean_ is not None:
+            scaler.mean_ = scaler.mean_ + piv
+    elif isinstance(scaler, MinMaxScaler):
+        scaler.data_min_ = scaler.data_min_ + piv
+        scaler.data_max_ = scaler.data_max_ + piv
+        scaler.min_ = scaler.feature_range[0] - scaler.data_min_ * scaler.scale_
+    elif isinstance(scaler, RobustScaler):
+        if scaler.center_ is not None:
+            scaler.center_ = scaler.center_ + piv
+
+
 def apply_scaling(features, scaler_type: str = "standard", scaler_params: Optional[Dict[str, Any]] = None,
                   fit: bool = True, scaler_instance=None) -> Tuple[np.ndarray, Any]:
     features = np.asarray(features)
@@ -139,6 +163,34 @@ def apply_scaling(features, scaler_type: str = "standard", scaler_params: Option
             features = features.reshape(-1, 1)
         else:
             raise ValueError(f"Input features must be 1D or 2D (samples/frames x features), got shape {features.shape}")
+    if fit and features.shape[0] > 0:
+        piv = _pivot(features)
+        out, scaler = scale_features_device(ops.to_device_f32(features.astype(np.float64) - piv), scaler_type,
+                                            scaler_params, True, scaler_instance)
+        _shift_fitted(scaler, piv)
+        res = out.cpu().numpy().astype(np.float64)
+        # a scaler that does not centre (with_mean / with_centering off) scales x itself, not x - piv: put piv / scale back
+        uncentred = (isinstance(scaler, StandardScaler) and not scaler.with_mean) or \
+                    (isinstance(scaler, RobustScaler) and not scaler.with_centering)
+        if uncentred:
+            sc = getattr(scaler, "scale_", None)
+            res += piv / sc if sc is not None else piv
+        return res, scaler
+    if not fit and scaler_instance is not None and features.shape[0] > 0:
+        if not _SKLEARN_AVAILABLE:
+            raise ImportError("scikit-learn package is required for feature scaling. Please install it (`pip install scikit-learn`).")
+        # transform with a given scaler: its own centre is the pivot (float64, on the host), the device scales
+        sub, mul, add = _affine_of(scaler_instance, features.shape[1])
+        if isinstance(scaler_instance, MinMaxScaler):      # x scale_ + min_ = (x - data_min_) scale_ + range minimum
+            sub, add = scaler_instance.data_min_, np.full(features.shape[1], float(scaler_instance.feature_range[0]))
+        if len(np.atleast_1d(mul)) != features.shape[1]:
+            raise ValueError(f"X has {features.shape[1]} features, but {type(scaler_instance).__name__} is expecting "
+                             f"{len(np.atleast_1d(mul))} features as input.")
+        xd = ops.to_device_f32(features.astype(np.float64) - np.asarray(sub, dtype=np.float64))
+        out = ops.affine_cols(xd, np.zeros(features.shape[1]), mul, add)
+        if isinstance(scaler_instance, MinMaxScaler) and getattr(scaler_instance, "clip", False):
+            out = out.clamp(scaler_instance.feature_range[0], scaler_instance.feature_range[1])
+        return out.cpu().numpy().astype(np.float64), scaler_instance
     out, scaler = scale_features_device(ops.to_device_f32(features), scaler_type, scaler_params, fit, scaler_instance)
     return out.cpu().numpy().astype(np.float64), scaler
 

@@ -244,3 +244,24 @@ def test_segment_vectors_vs_reference_golden_and_cases(gm):
         format_feature_vectors_per_segment(rf, rsegs, aggregation={"rms": "bad"})
     with pytest.raises(ValueError, match="Length of segment_labels must match"):
         format_feature_vectors_per_segment(rf, rsegs, segment_labels=["a", "b"])
+
+
+@pytest.mark.parametrize("kind", ["standard", "minmax", "robust"])
+def test_scaling_keeps_precision_of_columns_with_a_large_offset(kind):
+    """A column with mean 1e6 and spread 1 would lose ~6e-2 to the float32 cast; apply_scaling subtracts a per-column
+    pivot on the host in float64 first and shifts the fitted attributes back: values and attributes match scikit-learn
+    (what the reference calls, scaling.py:49-143), and the returned scaler inverts and re-applies like the reference's."""
+    from sklearn.preprocessing import MinMaxScaler, RobustScaler, StandardScaler
+    from sygnals_amd.core.ml_utils.scaling import apply_scaling
+    rng = np.random.default_rng(3)
+    X = np.stack([1e6 + rng.normal(0, 1.0, 500), -4e4 + rng.normal(0, 0.01, 500), rng.normal(0, 5.0, 500)], axis=1)
+    ref = {"standard": StandardScaler, "minmax": MinMaxScaler, "robust": RobustScaler}[kind]()
+    want = ref.fit_transform(X)
+    out, sc = apply_scaling(X, kind)
+    assert np.abs(out - want).max() <= 1e-5 * np.abs(want).max()
+    for attr in ("mean_", "data_min_", "data_max_", "min_", "center_", "scale_"):
+        if hasattr(ref, attr) and getattr(ref, attr) is not None:
+            np.testing.assert_allclose(getattr(sc, attr), getattr(ref, attr), rtol=1e-6, atol=1e-9, err_msg=attr)
+    np.testing.assert_allclose(sc.inverse_transform(out), X, rtol=1e-9, atol=1e-4)
+    again, _ = apply_scaling(X[:50], kind, fit=False, scaler_instance=sc)
+    assert np.abs(again - ref.transform(X[:50])).max() <= 1e-5 * np.abs(want).max()
