@@ -5,6 +5,7 @@
 //                      products with the frequency-domain constant-Q basis -> out[b, row0 + f, t]
 // One 64-lane wave per frame, FRAMES_PER_WG frames per workgroup (their outputs are adjacent in t).
 #include "common.h"
+#include <stdlib.h>
 
 namespace syg {
 namespace {
@@ -427,7 +428,8 @@ extern "C" int syg_cqt_octave_gemm_f32(const float* y, int64_t B, int64_t L, int
   const int n_rowtiles = (2 * n_filt + 15) / 16;
   const int64_t ntiles = (T + 15) / 16;
   // two row tiles per wave when they come in pairs and the operands fit the registers (n_fft <= 256: 128 + 64 VGPRs)
-  const int rt = (n_rowtiles % 2 == 0 && n_fft <= 256) ? 2 : 1;
+  const char* rte = getenv("SYGNALS_AMD_CQT_RT");          // development aid: 1 forces one row tile per wave
+  const int rt = (n_rowtiles % 2 == 0 && n_fft <= 256 && !(rte && rte[0] == '1')) ? 2 : 1;
   const int ngroups = n_rowtiles / rt;
   // persistent waves: about 8 (rt = 2) / 12 per CU over the batch, never more than there are frame tiles
   int64_t wpr = (256 * (rt == 2 ? 8 : 12)) / ((int64_t)ngroups * B);

@@ -53,6 +53,25 @@ def test_mel_power_matches_oracle(ops, clips):
         assert_parity(mel[i], ref, TOL, f"mel clip {i}")
 
 
+@pytest.mark.parametrize("waves", [16, 8])
+@pytest.mark.parametrize("n_mels,sr,fmin,fmax", [(1, 48000, 0.0, None), (3, 48000, 0.0, None), (40, 16000, 100.0, 6000.0),
+                                                 (128, 22050, 0.0, None), (200, 48000, 0.0, None), (256, 48000, 20.0, 20000.0)])
+def test_mel_projection_plans(ops, clips, monkeypatch, waves, n_mels, sr, fmin, fmax):
+    """The block-sparse projection (v_mfma_f32_4x4x1_16b_f32, four-row mel groups) over the plan shapes it can meet:
+    a single row, a partial group, band limits, 128 / 200 / 256 rows (more than 28 positions per slot: the kernel's
+    extra-step loop), both workgroup shapes -- mel power against the float64 product with the same float32 basis."""
+    if n_mels > 128 and waves == 8:
+        pytest.skip("more than 32 groups of four rows need the 16-wave plan")
+    monkeypatch.setenv("SYGNALS_AMD_WAVES", str(waves))
+    y = ops.to_device_f32(clips[:3])
+    mel, _, _ = ops.stft2048_mel(y, sr, n_mels=n_mels, fmin=fmin, fmax=fmax)
+    mel = mel.cpu().numpy()
+    assert mel.shape == (3, n_mels, 94)
+    for i in range(3):
+        S = np.abs(O.stft(clips[i].astype(np.float64), 2048, 512)) ** 2
+        assert_parity(mel[i], O.melspectrogram(S, sr, 2048, n_mels, fmin, fmax), TOL, f"mel n_mels={n_mels} clip {i}")
+
+
 @pytest.mark.parametrize("n_mels,n_mfcc", [(40, 13), (128, 13), (64, 20), (24, 24)])
 def test_mfcc_c2_matches_oracle(ops, clips, n_mels, n_mfcc):
     y = ops.to_device_f32(clips)
