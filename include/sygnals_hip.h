@@ -280,6 +280,13 @@ int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const f
  *   entry (mt, s, u, lane) = G[16 s + 4 (lane >> 4) + u][16 mt + (lane & 15)] (0 past 2 n_filt rows).  */
 int syg_cqt_octave_gemm_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
                             const float* gpacked, int n_filt, float* out, int64_t out_bstride, int row0, void* stream);
+ /* syg_cqt_octave_bf16x3_f32: the same product with both operands split into three bfloat16 terms and the six products
+ *   above 2^-24 accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (fp32-equivalent: error <= 3 x 2^-24 |a b| per product,
+ *   parity tests at 1e-5 like the fp32 form; 3/8 of its matrix-pipe time).  n_fft 128 / 256, n_filt <= 16.
+ *   gsplit: bfloat16 [3 terms hi, mid, lo][row tile][n_fft/32][64 lanes][8]: entry (p, mt, s, lane, j) = term p of
+ *   float32(G[32 s + 8 (lane >> 4) + j][16 mt + (lane & 15)]); 16-byte aligned.  */
+int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
+                              const void* gsplit, int n_filt, float* out, int64_t out_bstride, int row0, void* stream);
 int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
                        const float* twiddle, const float* basis, int n_filt, const int32_t* hull_host,
                        float* out, int64_t out_bstride, int row0, void* stream);

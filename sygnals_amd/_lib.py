@@ -43,6 +43,7 @@ SIGNATURES = {
     "syg_contrast_db_f32": (_i, [_p, _l, _i, _l, _f, _f, _p, _p]),
     "syg_decimate2_f32": (_i, [_p, _l, _l, _l, _p, _i, _f, _p, _l, _p]),
     "syg_cqt_octave_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _i, _p, _p, _l, _i, _p]),
+    "syg_cqt_octave_bf16x3_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _i, _p, _l, _i, _p]),
     "syg_cqt_octave_gemm_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _i, _p, _l, _i, _p]),
     "syg_sosfiltfilt_work_bytes": (_l, [_l, _l, _i, _i]),
     "syg_sosfiltfilt_f32": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _p, _l, _p, _p]),

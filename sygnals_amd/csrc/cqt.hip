@@ -348,6 +348,119 @@ __global__ __launch_bounds__(256) void cqt_gemm_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same framed product with both operands split into three bfloat16 terms (x = hi + mid + lo, 3 x 8 mantissa bits
+// = the 24 of a float32) and the six products that carry more than 2^-24 of the result accumulated in fp32 on
+// v_mfma_f32_16x16x32_bf16: a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_lo b_hi + a_mid b_mid (the dropped
+// terms are <= 3 x 2^-24 |a b|, the size of the fp32 rounding the single-instruction form makes).  Why: the fp32-input
+// MFMA runs at 1/16 of the bf16 rate and, dense, holds the chip at ~1.5 GHz; six bf16 instructions of depth 32 do the
+// work of sixteen fp32 instructions of depth 4 in 3/8 of the matrix-pipe time, and the splitting of the frame samples
+// (11 vector instructions per two samples) runs on the otherwise idle vector pipe.  G^T is split on the host and sits
+// in LDS (3 x RT x n_fft/32 x 64 lanes x 16 B = 48 KiB at n_fft 256), frames come straight from global memory as
+// before; lane l of a step holds the 8 consecutive k = 8 (l >> 4) .. + 7 of its row / frame.
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float cq_v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], v8bf& hi, v8bf& mid, v8bf& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r = x[j] - (float)h;              // exact: h keeps the leading 8 bits of x
+    const __bf16 m = (__bf16)r;
+    hi[j] = h; mid[j] = m; lo[j] = (__bf16)(r - (float)m);
+  }
+}
+
+template <int NFFT, int RT>
+__global__ __launch_bounds__(256) void cqt_bf16x3_kernel(const float* __restrict__ ysig, int64_t L, int64_t ldy, int hop,
+                                                         int64_t T, const uint4* __restrict__ gsplit, int n_filt,
+                                                         float2* __restrict__ out, int64_t out_bstride, int row0,
+                                                         int n_waves) {
+  constexpr int S = NFFT / 32;                 // MFMA k-steps of 32 samples
+  __shared__ uint4 atab[3 * RT * S * 64];       // [term][row tile][step][lane]: 8 bf16 each
+  for (int i = threadIdx.x; i < 3 * RT * S * 64; i += 256) atab[i] = gsplit[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int64_t b = blockIdx.y;
+  const float* yb = ysig + b * ldy;
+  const int n = lane & 15, kk = lane >> 4;
+  const int64_t ntiles = (T + 15) >> 4;
+  const int f0 = 2 * kk;                         // rows 4 kk + {0, 1}: (re, im) of filter f0, + {2, 3}: of f0 + 1
+  auto load_part = [&](int64_t tile, float4 (&q)[2 * S], int s0, int s1) {
+    const int64_t t = tile * 16 + n;
+    const int64_t base = t * (int64_t)hop - NFFT / 2 + 8 * kk;
+    const int64_t lo = tile * 16 * (int64_t)hop - NFFT / 2, hi = (tile * 16 + 15) * (int64_t)hop + NFFT / 2;
+    if (lo >= 0 && hi <= L) {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        if (s >= s0 && s < s1) {
+          q[2 * s] = *reinterpret_cast<const float4*>(yb + base + 32 * s);
+          q[2 * s + 1] = *reinterpret_cast<const float4*>(yb + base + 32 * s + 4);
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        if (s >= s0 && s < s1) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int64_t i0 = base + 32 * s + j;
+            v[j] = (i0 >= 0 && i0 < L) ? yb[i0] : 0.f;
+          }
+          q[2 * s] = make_float4(v[0], v[1], v[2], v[3]);
+          q[2 * s + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+  };
+  float4 q[2 * S];
+  int64_t tile = wid;
+  if (tile < ntiles) load_part(tile, q, 0, S);
+  for (; tile < ntiles; tile += n_waves) {
+    cq_v4f acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = cq_v4f{0.f, 0.f, 0.f, 0.f};
+    const int64_t nxt = tile + n_waves;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int s = h * (S / 2); s < (h + 1) * (S / 2); ++s) {
+        const float x[8] = {q[2 * s].x, q[2 * s].y, q[2 * s].z, q[2 * s].w, q[2 * s + 1].x, q[2 * s + 1].y, q[2 * s + 1].z,
+                            q[2 * s + 1].w};
+        v8bf bh, bm, bl;
+        split3_bf16(x, bh, bm, bl);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const v8bf ah = *reinterpret_cast<const v8bf*>(&atab[((0 * RT + r) * S + s) * 64 + lane]);
+          const v8bf am = *reinterpret_cast<const v8bf*>(&atab[((1 * RT + r) * S + s) * 64 + lane]);
+          const v8bf al = *reinterpret_cast<const v8bf*>(&atab[((2 * RT + r) * S + s) * 64 + lane]);
+          // small terms first
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[r], 0, 0, 0);
+        }
+        // one k-step at a time: without this fence the scheduler hoists the operand reads and splits of all eight
+        // steps to the top (308 VGPRs); with it a step's temporaries die before the next step's are born
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nxt < ntiles) load_part(nxt, q, h * (S / 2), (h + 1) * (S / 2));
+    }
+    const int64_t t = tile * 16 + n;
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int f = f0 + 8 * r;
+        float2* o = out + b * out_bstride + (int64_t)(row0 + f) * T + t;
+        if (f < n_filt) o[0] = make_float2(acc[r][0], acc[r][1]);
+        if (f + 1 < n_filt) o[T] = make_float2(acc[r][2], acc[r][3]);
+      }
+    }
+  }
+}
+
 bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
 
 }  // namespace
@@ -446,5 +559,35 @@ extern "C" int syg_cqt_octave_gemm_f32(const float* y, int64_t B, int64_t L, int
   else SYG_CQT_GEMM(512, 1);
 #undef SYG_CQT_GEMM
   SYG_CHECK_LAUNCH("cqt_octave_gemm");
+  return SYG_OK;
+}
+
+
+extern "C" int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
+                                         const void* gsplit, int n_filt, float* out, int64_t out_bstride, int row0,
+                                         void* stream) {
+  SYG_REQUIRE(y && gsplit && out, "cqt_octave_bf16x3: null pointer argument");
+  SYG_REQUIRE(n_fft == 128 || n_fft == 256, "cqt_octave_bf16x3: n_fft must be 128 or 256 (got %d)", n_fft);
+  SYG_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && ldy >= L && hop >= 1, "cqt_octave_bf16x3: bad B/L/ldy/hop");
+  SYG_REQUIRE(T >= 1 && T <= 1 + L / hop, "cqt_octave_bf16x3: T=%lld exceeds the centred frame count %lld", (long long)T,
+              (long long)(1 + L / hop));
+  SYG_REQUIRE(n_filt >= 1 && n_filt <= 16, "cqt_octave_bf16x3: n_filt must be in [1, 16] (two 16-row tiles)");
+  SYG_REQUIRE(row0 >= 0 && out_bstride >= (int64_t)(row0 + n_filt) * T, "cqt_octave_bf16x3: output rows out of range");
+  SYG_REQUIRE(((uintptr_t)gsplit) % 16 == 0, "cqt_octave_bf16x3: operand table must be 16-byte aligned");
+  const int rt = (2 * n_filt + 15) / 16;
+  const int64_t ntiles = (T + 15) / 16;
+  int64_t waves = (256 * 12) / B;                  // three workgroups of four waves per CU (48 KiB of LDS each)
+  if (waves < 4) waves = 4;
+  if (waves > ntiles) waves = (ntiles + 3) & ~(int64_t)3;
+  waves &= ~(int64_t)3;
+  const dim3 grid((unsigned)(waves / 4), (unsigned)B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define SYG_CQT_B3(N, R)                                                                                             \
+  hipLaunchKernelGGL((cqt_bf16x3_kernel<N, R>), grid, block, 0, st, y, L, ldy, hop, T, (const uint4*)gsplit, n_filt,  \
+                     (float2*)out, out_bstride, row0, (int)waves)
+  if (n_fft == 128) { if (rt == 2) SYG_CQT_B3(128, 2); else SYG_CQT_B3(128, 1); }
+  else { if (rt == 2) SYG_CQT_B3(256, 2); else SYG_CQT_B3(256, 1); }
+#undef SYG_CQT_B3
+  SYG_CHECK_LAUNCH("cqt_octave_bf16x3");
   return SYG_OK;
 }

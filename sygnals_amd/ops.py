@@ -955,6 +955,44 @@ def cqt_pack_gemm(basis: np.ndarray, n_fft: int) -> np.ndarray:
     return np.ascontiguousarray(out)
 
 
+def _bf16_rne(x32: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(x32, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def cqt_pack_bf16x3(basis: np.ndarray, n_fft: int) -> np.ndarray:
+    """Operand table of syg_cqt_octave_bf16x3_f32: float32(G) (cqt_pack_gemm's matrix) split into three bfloat16 terms
+    hi + mid + lo (hi = bf16(g), mid = bf16(g - hi), lo = bf16(g - hi - mid); the two differences are exact in
+    float32), packed uint16 [3][row tile][n_fft / 32][64 lanes][8]: entry (p, mt, s, lane, j) = term p of
+    G[32 s + 8 (lane >> 4) + j][16 mt + (lane & 15)]."""
+    basis = np.asarray(basis, dtype=np.complex128)
+    nf, F = basis.shape
+    k = np.arange(F)[:, None]
+    n = np.arange(n_fft)[None, :]
+    g = basis @ np.exp(-2j * np.pi * ((k * n) % n_fft) / n_fft)
+    ntile = (2 * nf + 15) // 16
+    G = np.zeros((n_fft, 16 * ntile), dtype=np.float32)
+    G[:, 0:2 * nf:2] = g.real.T
+    G[:, 1:2 * nf:2] = g.imag.T
+
+    def f32_of(b16):
+        return (b16.astype(np.uint32) << 16).view(np.float32)
+    hi = _bf16_rne(G)
+    r1 = G - f32_of(hi)
+    mid = _bf16_rne(r1)
+    lo = _bf16_rne(r1 - f32_of(mid))
+    lane = np.arange(64)
+    S = n_fft // 32
+    out = np.empty((3, ntile, S, 64, 8), dtype=np.uint16)
+    for p, term in enumerate((hi, mid, lo)):
+        for mt in range(ntile):
+            for s_ in range(S):
+                for j in range(8):
+                    out[p, mt, s_, :, j] = term[32 * s_ + 8 * (lane >> 4) + j, 16 * mt + (lane & 15)]
+    return np.ascontiguousarray(out)
+
+
 def decimate2(x: torch.Tensor, taps: torch.Tensor, scale: float) -> torch.Tensor:
     """FIR decimation by two of x [B, L] -> [B, ceil(L/2)] (zero padded ends)."""
     require_gpu()
@@ -987,6 +1025,8 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
             k1 = np.array([int(len(r) - np.argmax(r[::-1])) if r.any() else 0 for r in nz], dtype=np.int32)
             o["hull"] = np.ascontiguousarray(np.concatenate([k0, k1 - k0]).astype(np.int32))
             o["gpacked_dev"] = _dev(cqt_pack_gemm(b, o["n_fft"])) if o["n_fft"] in (128, 256, 512) and len(b) <= 64 else None
+            o["gsplit_dev"] = (torch.from_numpy(cqt_pack_bf16x3(b, o["n_fft"]).view(np.int16)).to(require_gpu())
+                               if o["n_fft"] in (128, 256) and len(b) <= 16 else None)
         p.taps_dev = _dev(decimation_taps().astype(np.float32))
         return p
     plan = _cached(key, build)
@@ -1006,7 +1046,10 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
             Lc = (Lc + 1) // 2
     out = torch.empty((B, plan.n_bins, Tn, 2), dtype=torch.float32, device=y.device)      # every row is written
     s2 = float(np.sqrt(2.0))
-    use_gemm = os.environ.get("SYGNALS_AMD_CQT", "gemm") != "fft"
+    # octave kernel: "bf16x3" (default: the framed product with bfloat16-split operands, fp32-equivalent), "gemm" (the
+    # single-instruction fp32 MFMA form), "fft" (rfft x sparse rows; also what other frame lengths take)
+    mode = os.environ.get("SYGNALS_AMD_CQT", "bf16x3")
+    use_gemm = mode != "fft"
     # SYGNALS_AMD_CQT_STREAMS=2: the decimation chain (memory-bound) on the caller's stream, the octave products
     # (matrix-core bound, no LDS) on a side stream, so that octave i runs beside the decimation towards octave i + 1.
     # Measured on one 1-hour stream: 1.03 ms against 1.05 ms on one stream -- the two kernels slow each other down by
@@ -1027,7 +1070,11 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
                 side.wait_event(ev)
                 cur.record_stream(side)
             sp = C.c_void_p(side.cuda_stream)
-            if use_gemm and o.get("gpacked_dev") is not None:
+            if mode == "bf16x3" and o.get("gsplit_dev") is not None:
+                rc = lib().syg_cqt_octave_bf16x3_f32(_ptr(cur), B, cur.shape[1], _ld(cur), o["n_fft"], o["hop"], Tn,
+                                                     _ptr(o["gsplit_dev"]), o["n"], _ptr(out), plan.n_bins * Tn, o["row0"], sp)
+                check(rc, "syg_cqt_octave_bf16x3_f32")
+            elif use_gemm and o.get("gpacked_dev") is not None:
                 rc = lib().syg_cqt_octave_gemm_f32(_ptr(cur), B, cur.shape[1], _ld(cur), o["n_fft"], o["hop"], Tn,
                                                    _ptr(o["gpacked_dev"]), o["n"], _ptr(out), plan.n_bins * Tn, o["row0"], sp)
                 check(rc, "syg_cqt_octave_gemm_f32")

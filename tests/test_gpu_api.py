@@ -247,10 +247,11 @@ def test_compute_cqt_vs_oracle():
         compute_cqt(y2, 8000)
 
 
-@pytest.mark.parametrize("path", ["gemm", "fft"])
+@pytest.mark.parametrize("path", ["bf16x3", "gemm", "fft"])
 def test_cqt_both_octave_kernels_vs_oracle(path, monkeypatch):
-    """The octave response as one framed matrix product on the matrix cores (default) and as rfft x sparse basis rows
-    (the fallback for other frame lengths) are the same linear map: both against the oracle."""
+    """The octave response as one framed matrix product on the matrix cores -- with bfloat16-split operands (default,
+    fp32-equivalent) or as single fp32 MFMA instructions -- and as rfft x sparse basis rows (the fallback for other
+    frame lengths) are the same linear map: all three against the oracle at 1e-5."""
     from sygnals_amd import ops
     monkeypatch.setenv("SYGNALS_AMD_CQT", path)
     rng = np.random.default_rng(11)
