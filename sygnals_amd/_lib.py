@@ -42,6 +42,7 @@ SIGNATURES = {
     "syg_contrast_pv_f32": (_i, [_p, _l, _i, _p, _p, _p]),
     "syg_contrast_db_f32": (_i, [_p, _l, _i, _l, _f, _f, _p, _p]),
     "syg_decimate2_f32": (_i, [_p, _l, _l, _l, _p, _i, _f, _p, _l, _p]),
+    "syg_decimate2_chain_f32": (_i, [_p, _l, _l, _l, _p, _i, _f, _i, _p, _p, _p]),
     "syg_cqt_octave_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _i, _p, _p, _l, _i, _p]),
     "syg_cqt_octave_bf16x3_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _i, _p, _l, _i, _p]),
     "syg_cqt_octave_gemm_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _i, _p, _l, _i, _p]),

@@ -181,6 +181,185 @@ __global__ __launch_bounds__(DEC_NT, 8) void decimate2_fixed_kernel(const float*
   }
 }
 
+// Two or three decimations in one pass (the CQT walks down an octave per decimation and needs every level): the chain
+// x -> y1 -> y2 -> y3 moves 2 x the bytes of its largest member when every level is a launch of its own, because each
+// level is written and read back; here a workgroup carries a tile through all levels in LDS and writes each level once.
+// A tile owns NF outputs of the last level and the 2 NF / 4 NF outputs of the levels above; what the next level's
+// filter needs beyond them (20 samples per side and level) is recomputed from a wider input run (+7 % reads at NF = 478,
+// three levels).  Every value is produced by the same instructions in the same order as by decimate2_fixed_kernel and
+// passes to the next level as the float it would have been stored as; positions outside [0, L_level) are zero, as the
+// zero padding of a level-by-level chain makes them: identical bits.
+// Level s (s = 1 .. NL) computes CNT_s outputs from the level below, which sits in LDS split into even / odd samples
+// (pair u = samples 2 (a_s - 10 + u), + 1; a_s = first output index of the tile at level s, always even):
+//   CNT_NL = NF,   CNT_{s-1} = 2 CNT_s + 44  (the 8-byte window reads of the last pair touch two pairs more than the taps)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {          // a wave-uniform value back into scalar registers
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffff)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+template <int NL>
+struct DecChain {
+  static constexpr int NF = (NL == 3) ? 478 : 990;            // CNT_1 / 2 = 1022 / 1012 pairs: four rounds of 256 lanes
+  static constexpr int cnt(int s) { return s == NL ? NF : 2 * cnt(s + 1) + 44; }
+  static constexpr int lds_floats() { int t = 0; for (int s = 0; s < NL; ++s) t += cnt(s) + 4; return t; }
+};
+
+struct DecOut {
+  float* y[3];
+  int64_t ld[3];
+  int64_t len[4];                                // len[0] = L (input), len[s] = length of level s
+};
+
+template <int NT, int NL>
+__global__ __launch_bounds__(DEC_NT, 5) void decimate2_chain_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ taps, float scale, DecOut o,
+                                                                int64_t ntiles) {
+  constexpr int HALF = (NT - 1) / 2, H2 = HALF / 2;
+  static_assert(HALF % 4 == 0, "specialised for a half length that is a multiple of four");
+  using DC = DecChain<NL>;
+  __shared__ __attribute__((aligned(16))) float hs[(NT + 3) & ~3];
+  __shared__ __attribute__((aligned(16))) float buf[DC::lds_floats()];
+  __shared__ int hb_flag;
+  __shared__ DecOut ol;                          // the per-level arguments, fetched where a level starts (they would
+                                                 // otherwise sit in ~20 scalar registers for the whole kernel and spill)
+  const int64_t b = blockIdx.y;
+  const float* xb = x + b * ldx;
+  const int tid = threadIdx.x;
+  const bool pair_ok = ((ldx & 1) == 0) && ((((uintptr_t)x) & 7) == 0);
+  for (int j = tid; j < NT; j += DEC_NT) hs[j] = taps[j];
+  if (tid == 0) ol = o;
+  __syncthreads();
+  if (tid == 0) {
+    int hb = 1;
+    for (int j = 0; j < NT; ++j)
+      if (((HALF - j) & 1) == 0 && j != HALF && hs[j] != 0.f) hb = 0;
+    hb_flag = hb;
+  }
+  __syncthreads();
+  const bool halfband = hb_flag != 0;
+  const int64_t len0 = o.len[0];
+  // the taps at odd offsets from the centre, and the centre, live in scalar registers (all a half-band filter has);
+  // the other even-offset taps of a general filter are read from LDS where they are used
+  float hodd[HALF];
+#pragma unroll
+  for (int m = 0; m < HALF; ++m) hodd[m] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hs[2 * m + 1])));
+  const float hcen = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hs[HALF])));
+
+  // consecutive tiles go to the same XCD (workgroup i runs on XCD i % 8) at about the same time: the input samples two
+  // neighbours both need then come from that XCD's L2 the second time
+  const int64_t per_x = (ntiles + 7) / 8;
+  constexpr int NP0 = DC::cnt(0) / 2;
+  constexpr int NR0 = (NP0 + DEC_NT - 1) / DEC_NT;
+  constexpr int A0OFF = HALF * ((1 << NL) - 1);  // a[0] = 2^NL a[NL] - HALF (2^NL - 1)
+  auto tile_of = [&](int64_t wg) { return (wg & 7) * per_x + (wg >> 3); };
+  auto is_fast = [&](int64_t tile) {
+    const int64_t a0 = tile * ((int64_t)DC::NF << NL) - A0OFF;
+    return pair_ok && a0 >= 0 && a0 + 2 * NP0 <= len0;
+  };
+  // the input run of the NEXT tile is requested before the levels of the current one are computed (a workgroup
+  // without loads in flight for three levels' worth of arithmetic leaves the memory system idle)
+  float2 v[NR0];
+  auto request = [&](int64_t tile) {
+    const float2* xp = reinterpret_cast<const float2*>(xb + (tile * ((int64_t)DC::NF << NL) - A0OFF));
+#pragma unroll
+    for (int r = 0; r < NR0; ++r) {
+      const int u = tid + r * DEC_NT;
+      if (r + 1 < NR0 || u < NP0) v[r] = xp[u];
+    }
+  };
+  int64_t wg = blockIdx.x;
+  while (wg < per_x * 8 && tile_of(wg) >= ntiles) wg += gridDim.x;
+  if (wg < per_x * 8 && is_fast(tile_of(wg))) request(tile_of(wg));
+  while (wg < per_x * 8) {
+    const int64_t tile = tile_of(wg);
+    // first output index of this tile at every level
+    int64_t a[NL + 1];
+    a[NL] = tile * DC::NF;
+#pragma unroll
+    for (int s = NL; s >= 1; --s) a[s - 1] = 2 * a[s] - HALF;
+    __syncthreads();                             // the previous tile's readers are done
+    {   // level 0: CNT_0 samples from a[0] as pairs
+      float* E = buf;
+      float* O = buf + NP0 + 2;
+      if (is_fast(tile)) {
+#pragma unroll
+        for (int r = 0; r < NR0; ++r) {
+          const int u = tid + r * DEC_NT;
+          if (r + 1 < NR0 || u < NP0) { E[u] = v[r].x; O[u] = v[r].y; }
+        }
+      } else {                                     // a tile at either end of the signal
+#pragma unroll 1
+        for (int u = tid; u < NP0; u += DEC_NT) {
+          const int64_t i0 = a[0] + 2 * u;
+          E[u] = (i0 >= 0 && i0 < len0) ? xb[i0] : 0.f;
+          O[u] = (i0 + 1 >= 0 && i0 + 1 < len0) ? xb[i0 + 1] : 0.f;
+        }
+      }
+    }
+    wg += gridDim.x;
+    while (wg < per_x * 8 && tile_of(wg) >= ntiles) wg += gridDim.x;
+    if (wg < per_x * 8 && is_fast(tile_of(wg))) request(tile_of(wg));
+    int off = 0;
+#pragma unroll
+    for (int s = 1; s <= NL; ++s) {
+      __syncthreads();
+      const int npin = DC::cnt(s - 1) / 2;         // staged pairs of the level below
+      const float* E = buf + off;
+      const float* O = buf + off + npin + 2;
+      off += DC::cnt(s - 1) + 4;
+      const int npout = DC::cnt(s) / 2;            // output pairs of this level
+      float* En = buf + off;                       // next level's even / odd arrays (unused at the last level)
+      float* On = buf + off + npout + 2;
+      // everything about this tile and level as wave-uniform 32-bit numbers relative to a[s]
+      const int64_t Ls = uniform64(ol.len[s]);
+      const int64_t own0 = tile * ((int64_t)DC::NF << (NL - s));
+      const int span = DC::NF << (NL - s);
+      const int64_t lo64 = -a[s], hi64 = Ls - a[s];           // outputs with local index in [vlo, vhi) exist
+      const int vlo = lo64 > 0 ? (int)(lo64 < 2 * npout ? lo64 : 2 * npout) : 0;
+      const int vhi = hi64 < 0 ? 0 : (int)(hi64 < 2 * npout ? hi64 : 2 * npout);
+      const int w0 = (int)(own0 - a[s]);           // owned (written) local range [w0, w0 + span), cut to [vlo, vhi)
+      const int wlo = w0 > vlo ? w0 : vlo, whi = w0 + span < vhi ? w0 + span : vhi;
+      float* ybase = reinterpret_cast<float*>(uniform64((int64_t)(uintptr_t)ol.y[s - 1]));
+      float* yo = ybase ? ybase + b * uniform64(ol.ld[s - 1]) + a[s] : nullptr;   // (only owned, existing indices are touched)
+#pragma unroll 1
+      for (int pr = tid; pr < npout; pr += DEC_NT) {
+        const int nl = 2 * pr;                     // local index of the pair's first output (window starts at pair nl)
+        float wv[2 * H2 + 2];
+        const float2* o2 = reinterpret_cast<const float2*>(O + nl);
+#pragma unroll
+        for (int k = 0; k <= H2; ++k) { const float2 v = o2[k]; wv[2 * k] = v.x; wv[2 * k + 1] = v.y; }
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < HALF; ++m) {           // taps j = 2 m + 1 (odd offset c = HALF - j from the centre), ascending
+          const int q = H2 + (HALF - (2 * m + 1) - 1) / 2;
+          a0 = fmaf(hodd[m], wv[q], a0);
+          a1 = fmaf(hodd[m], wv[q + 1], a1);
+        }
+        if (halfband) {
+          const float2 v = *reinterpret_cast<const float2*>(E + nl + H2);
+          a0 = fmaf(hcen, v.x, a0);
+          a1 = fmaf(hcen, v.y, a1);
+        } else {                                   // a general filter: the even-offset taps, ascending, from LDS
+#pragma unroll 1
+          for (int j = 0; j < NT; j += 2) {
+            const int q = nl + H2 + (HALF - j) / 2;
+            const float h = hs[j];
+            a0 = fmaf(h, E[q], a0);
+            a1 = fmaf(h, E[q + 1], a1);
+          }
+        }
+        const float v0 = (nl >= vlo && nl < vhi) ? a0 * scale : 0.f;
+        const float v1 = (nl + 1 >= vlo && nl + 1 < vhi) ? a1 * scale : 0.f;
+        if (s < NL) { En[pr] = v0; On[pr] = v1; }
+        if (yo) {
+          if (nl >= wlo && nl < whi) yo[nl] = v0;
+          if (nl + 1 >= wlo && nl + 1 < whi) yo[nl + 1] = v1;
+        }
+      }
+    }
+  }
+}
+
 // Non-zero column range of every filter's frequency-domain row: librosa sparsifies the basis (entries below
 // the 1 % magnitude quantile are set to zero), so each constant-Q filter keeps a run of a few dozen bins.
 struct FiltHull {
@@ -461,6 +640,135 @@ __global__ __launch_bounds__(256) void cqt_bf16x3_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Overlapping frames (hop <= n_fft / 2, the lower octaves: hop halves with every decimation while the filters keep
+// their length, so a sample sits in 2 .. 32 frames): the kernel above splits a sample once per frame that holds it,
+// and that splitting is most of its time.  Here a workgroup of eight waves takes 128 consecutive frames, splits their
+// contiguous sample run ((128 - 1) hop + n_fft samples) ONCE into three bfloat16 planes in LDS, and every wave reads
+// its frames' B operands from the planes with ds_read_b128 (8 consecutive samples = 16 B; hop % 8 == 4 keeps a second
+// copy of the planes shifted by four samples, so that every frame start is 16-byte aligned in one of the two).  The
+// 16-byte chunk i of the run sits at slot i + (i >> sh): lane (n, kk) of step s reads chunk n hop/8 + kk + 4 s, and the
+// skew (sh = log2(hop / 8) - 1 for hop >= 32) spreads the 16 lanes of every ds_read_b128 lane group over the 16 bank
+// groups (checked by enumeration for hop / 8 in {1, 2, 4, 8, 16, 32}; other hops work with 2-way conflicts).
+// The next run's samples are requested from global memory before the products of the current one and split after
+// them.  Same operands, same MFMA order as cqt_bf16x3_kernel: the two produce identical bits.
+constexpr int CQS_NW = 8;                      // waves per workgroup
+constexpr int CQS_FB = 16 * CQS_NW;            // frames per run
+constexpr int CQS_MAXC = 5;                    // 16-byte chunks per thread and run: (127 * 128 + 256) / 8 = 2064 <= 5 * 512
+
+template <int NFFT, int RT>
+__global__ __launch_bounds__(CQS_NW * 64) void cqt_bf16x3_staged_kernel(const float* __restrict__ ysig, int64_t L,
+                                                                        int64_t ldy, int hop, int64_t T,
+                                                                        const uint4* __restrict__ gsplit, int n_filt,
+                                                                        float2* __restrict__ out, int64_t out_bstride,
+                                                                        int row0, int nchunks, int cplane, int ncopy,
+                                                                        int sh) {
+  constexpr int S = NFFT / 32;
+  constexpr int NA = 3 * RT * S * 64;
+  constexpr int NT = CQS_NW * 64;
+  extern __shared__ __attribute__((aligned(16))) uint4 cqs_lds[];
+  uint4* atab = cqs_lds;                         // [term][row tile][step][lane]
+  uint4* stage = cqs_lds + NA;                   // [term][slot]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NA; i += NT) atab[i] = gsplit[i];
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.y;
+  const float* yb = ysig + b * ldy;
+  const int n = lane & 15, kk = lane >> 4;
+  const int plane = cplane * ncopy;
+  const int ntot = nchunks * ncopy;
+  const int64_t nruns = (T + CQS_FB - 1) / CQS_FB;
+  const int f0 = 2 * kk;
+
+  float4 pre[2 * CQS_MAXC];
+  auto fetch = [&](int64_t run) {
+    const int64_t s0 = run * CQS_FB * (int64_t)hop - NFFT / 2;
+#pragma unroll
+    for (int c = 0; c < CQS_MAXC; ++c) {
+      const int idx = tid + NT * c;
+      if (idx < ntot) {
+        const int cp = idx >= nchunks ? 1 : 0, i = idx - cp * nchunks;
+        const int64_t g = s0 + 4 * cp + 8 * (int64_t)i;
+        if (g >= 0 && g + 8 <= L) {
+          pre[2 * c] = *reinterpret_cast<const float4*>(yb + g);
+          pre[2 * c + 1] = *reinterpret_cast<const float4*>(yb + g + 4);
+        } else {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (g + j >= 0 && g + j < L) ? yb[g + j] : 0.f;
+          pre[2 * c] = make_float4(v[0], v[1], v[2], v[3]);
+          pre[2 * c + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int c = 0; c < CQS_MAXC; ++c) {
+      const int idx = tid + NT * c;
+      if (idx < ntot) {
+        const int cp = idx >= nchunks ? 1 : 0, i = idx - cp * nchunks;
+        const float x[8] = {pre[2 * c].x, pre[2 * c].y, pre[2 * c].z, pre[2 * c].w,
+                            pre[2 * c + 1].x, pre[2 * c + 1].y, pre[2 * c + 1].z, pre[2 * c + 1].w};
+        v8bf bh, bm, bl;
+        split3_bf16(x, bh, bm, bl);
+        const int slot = i + (i >> sh) + cp * cplane;
+        *reinterpret_cast<v8bf*>(&stage[slot]) = bh;
+        *reinterpret_cast<v8bf*>(&stage[plane + slot]) = bm;
+        *reinterpret_cast<v8bf*>(&stage[2 * plane + slot]) = bl;
+      }
+    }
+  };
+
+  int64_t run = blockIdx.x;
+  if (run < nruns) fetch(run);
+  for (; run < nruns; run += gridDim.x) {
+    park();
+    __syncthreads();                             // (the first pass also orders the operand table)
+    const int64_t nxt = run + gridDim.x;
+    if (nxt < nruns) fetch(nxt);
+    cq_v4f acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = cq_v4f{0.f, 0.f, 0.f, 0.f};
+    const int fo = (w * 16 + n) * hop;            // the frame's first sample inside the run
+    const int cp = ncopy == 2 ? (fo >> 2) & 1 : 0;
+    const int i0 = ((fo - 4 * cp) >> 3) + kk;
+    const int coff = cp * cplane;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int i = i0 + 4 * s;
+      const int slot = i + (i >> sh) + coff;
+      const v8bf bh = *reinterpret_cast<const v8bf*>(&stage[slot]);
+      const v8bf bm = *reinterpret_cast<const v8bf*>(&stage[plane + slot]);
+      const v8bf bl = *reinterpret_cast<const v8bf*>(&stage[2 * plane + slot]);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const v8bf ah = *reinterpret_cast<const v8bf*>(&atab[((0 * RT + r) * S + s) * 64 + lane]);
+        const v8bf am = *reinterpret_cast<const v8bf*>(&atab[((1 * RT + r) * S + s) * 64 + lane]);
+        const v8bf al = *reinterpret_cast<const v8bf*>(&atab[((2 * RT + r) * S + s) * 64 + lane]);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[r], 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[r], 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[r], 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[r], 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[r], 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[r], 0, 0, 0);
+      }
+    }
+    const int64_t t = run * CQS_FB + w * 16 + n;
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int f = f0 + 8 * r;
+        float2* o = out + b * out_bstride + (int64_t)(row0 + f) * T + t;
+        if (f < n_filt) o[0] = make_float2(acc[r][0], acc[r][1]);
+        if (f + 1 < n_filt) o[T] = make_float2(acc[r][2], acc[r][3]);
+      }
+    }
+    __syncthreads();                             // every wave has read the planes before the next run overwrites them
+  }
+}
+
 bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
 
 }  // namespace
@@ -486,6 +794,54 @@ extern "C" int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t l
     hipLaunchKernelGGL(decimate2_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(DEC_NT), lds, (hipStream_t)stream, x, L,
                        ldx, taps, ntaps, scale, y, Lout, ldy);
   SYG_CHECK_LAUNCH("decimate2");
+  return SYG_OK;
+}
+
+extern "C" int syg_decimate2_chain_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const float* taps, int ntaps,
+                                       float scale, int levels, float* const* y, const int64_t* ldy, void* stream) {
+  SYG_REQUIRE(x && taps && y && ldy, "decimate2_chain: null pointer argument");
+  SYG_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && ldx >= L, "decimate2_chain: bad B/L/ldx");
+  SYG_REQUIRE(levels >= 1 && levels <= 3, "decimate2_chain: levels must be 1, 2 or 3 (got %d)", levels);
+  SYG_REQUIRE(ntaps >= 1 && (ntaps & 1) == 1 && ntaps <= 1025, "decimate2_chain: ntaps must be odd and <= 1025");
+  SYG_REQUIRE(y[levels - 1], "decimate2_chain: the last level needs an output buffer");
+  DecOut o;
+  o.len[0] = L;
+  for (int s = 0; s < 3; ++s) { o.y[s] = nullptr; o.ld[s] = 0; o.len[s + 1] = 0; }
+  for (int s = 0; s < levels; ++s) {
+    o.len[s + 1] = (o.len[s] + 1) / 2;
+    o.y[s] = y[s];
+    o.ld[s] = ldy[s];
+    SYG_REQUIRE(!y[s] || ldy[s] >= o.len[s + 1], "decimate2_chain: ldy[%d] too small", s);
+  }
+  if (ntaps != 41 || levels == 1) {               // level by level (every level then needs its buffer)
+    const float* src = x;
+    int64_t ls = ldx;
+    for (int s = 0; s < levels; ++s) {
+      SYG_REQUIRE(y[s], "decimate2_chain: with %d taps every level needs an output buffer", ntaps);
+      const int rc = syg_decimate2_f32(src, B, o.len[s], ls, taps, ntaps, scale, y[s], ldy[s], stream);
+      if (rc != SYG_OK) return rc;
+      src = y[s];
+      ls = ldy[s];
+    }
+    return SYG_OK;
+  }
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
+    set_error("decimate2_chain: cannot query the device");
+    return SYG_E_LAUNCH;
+  }
+  const int nf = levels == 3 ? DecChain<3>::NF : DecChain<2>::NF;
+  const int64_t ntiles = (o.len[levels] + nf - 1) / nf;
+  int64_t blocks = ((ntiles + 7) / 8) * 8;                      // a multiple of 8: a workgroup keeps its XCD
+  const int64_t cap = (((int64_t)n_cu * 5 + B - 1) / B + 7) / 8 * 8;
+  if (blocks > cap) blocks = cap;
+  const dim3 grid((unsigned)blocks, (unsigned)B), block(DEC_NT);
+  if (levels == 3)
+    hipLaunchKernelGGL((decimate2_chain_kernel<41, 3>), grid, block, 0, (hipStream_t)stream, x, ldx, taps, scale, o, ntiles);
+  else
+    hipLaunchKernelGGL((decimate2_chain_kernel<41, 2>), grid, block, 0, (hipStream_t)stream, x, ldx, taps, scale, o, ntiles);
+  SYG_CHECK_LAUNCH("decimate2_chain");
   return SYG_OK;
 }
 
@@ -576,12 +932,53 @@ extern "C" int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, i
   SYG_REQUIRE(((uintptr_t)gsplit) % 16 == 0, "cqt_octave_bf16x3: operand table must be 16-byte aligned");
   const int rt = (2 * n_filt + 15) / 16;
   const int64_t ntiles = (T + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  // overlapping frames: split each sample once per 128-frame run (cqt_bf16x3_staged_kernel)
+  {
+    const char* e = getenv("SYGNALS_AMD_CQT_STAGED");
+    const bool off = e && e[0] == '0';
+    const bool shape_ok = hop % 4 == 0 && hop <= n_fft / 2;
+    const int ncopy = hop % 8 == 0 ? 1 : 2;
+    const int nchunks = shape_ok ? ((CQS_FB - 1) * hop + n_fft) / 8 : 0;
+    int sh = 31;                                   // slot skew: floor(log2(hop / 8)) - 1 for hop >= 32, none below
+    if (hop >= 32) { const int h8 = hop >> 3; int lg = 0; while ((2 << lg) <= h8) ++lg; sh = lg - 1; }
+    int cplane = sh < 31 ? nchunks + (nchunks >> sh) + 1 : nchunks;
+    if (ncopy == 2) cplane = ((cplane + 7) & ~15) + 8;          // the second copy starts 8 bank groups over
+    const size_t lds = (size_t)(3 * rt * (n_fft / 32) * 64 + 3 * ncopy * cplane) * 16;
+    if (!off && shape_ok && ((uintptr_t)y) % 16 == 0 && (B == 1 || ldy % 4 == 0) &&
+        ncopy * nchunks <= CQS_MAXC * CQS_NW * 64 && lds <= 160 * 1024 - 512) {
+      int dev = 0, n_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
+        set_error("cqt_octave_bf16x3: cannot query the device");
+        return SYG_E_LAUNCH;
+      }
+      const int64_t nruns = (T + CQS_FB - 1) / CQS_FB;
+      const int per_cu = lds <= 80 * 1024 - 256 ? 2 : 1;
+      int64_t gx = ((int64_t)n_cu * per_cu + B - 1) / B;
+      if (gx > nruns) gx = nruns;
+      if (gx < 1) gx = 1;
+      const dim3 grid((unsigned)gx, (unsigned)B), block(CQS_NW * 64);
+#define SYG_CQT_ST(N, R)                                                                                             \
+  do {                                                                                                               \
+    hipError_t e2 = hipFuncSetAttribute((const void*)cqt_bf16x3_staged_kernel<N, R>,                                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+    if (e2 != hipSuccess) { set_error("cqt_octave_bf16x3: cannot reserve LDS: %s", hipGetErrorString(e2)); return SYG_E_LAUNCH; } \
+    hipLaunchKernelGGL((cqt_bf16x3_staged_kernel<N, R>), grid, block, lds, st, y, L, ldy, hop, T, (const uint4*)gsplit, \
+                       n_filt, (float2*)out, out_bstride, row0, nchunks, cplane, ncopy, sh);                                 \
+  } while (0)
+      if (n_fft == 128) { if (rt == 2) SYG_CQT_ST(128, 2); else SYG_CQT_ST(128, 1); }
+      else { if (rt == 2) SYG_CQT_ST(256, 2); else SYG_CQT_ST(256, 1); }
+#undef SYG_CQT_ST
+      SYG_CHECK_LAUNCH("cqt_octave_bf16x3 (staged)");
+      return SYG_OK;
+    }
+  }
   int64_t waves = (256 * 12) / B;                  // three workgroups of four waves per CU (48 KiB of LDS each)
   if (waves < 4) waves = 4;
   if (waves > ntiles) waves = (ntiles + 3) & ~(int64_t)3;
   waves &= ~(int64_t)3;
   const dim3 grid((unsigned)(waves / 4), (unsigned)B), block(256);
-  hipStream_t st = (hipStream_t)stream;
 #define SYG_CQT_B3(N, R)                                                                                             \
   hipLaunchKernelGGL((cqt_bf16x3_kernel<N, R>), grid, block, 0, st, y, L, ldy, hop, T, (const uint4*)gsplit, n_filt,  \
                      (float2*)out, out_bstride, row0, (int)waves)

@@ -1006,6 +1006,37 @@ def decimate2(x: torch.Tensor, taps: torch.Tensor, scale: float) -> torch.Tensor
     return y
 
 
+def decimate2_chain(x: torch.Tensor, taps: torch.Tensor, scale: float, levels: int, keep=None) -> list:
+    """`levels` successive decimate2 steps; 2 or 3 at a time go through one pass of syg_decimate2_chain_f32 (identical
+    bits, every level written once).  keep[s] False: level s is not wanted (returned as None; never the last one)."""
+    require_gpu()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    keep = [True] * levels if keep is None else list(keep)
+    keep[-1] = True
+    out = []
+    cur = x
+    s = 0
+    while s < levels:
+        n = min(3, levels - s)
+        B, L = cur.shape
+        ys, lens = [], L
+        for j in range(n):
+            lens = (lens + 1) // 2
+            # (a level that feeds the next pass is needed even when the caller does not want it)
+            need = keep[s + j] or j == n - 1
+            ys.append(torch.empty((B, lens), dtype=torch.float32, device=x.device) if need else None)
+        yp = (C.c_void_p * n)(*[(_ptr(t) if t is not None else None) for t in ys])
+        ld = (C.c_int64 * n)(*[(_ld(t) if t is not None else 0) for t in ys])
+        rc = lib().syg_decimate2_chain_f32(_ptr(cur), B, L, _ld(cur), _ptr(taps), taps.numel(), float(scale), n, yp, ld,
+                                           C.c_void_p(_stream_ptr()))
+        check(rc, "syg_decimate2_chain_f32")
+        out += [t if keep[s + j] else None for j, t in enumerate(ys)]
+        cur = ys[-1]
+        s += n
+    return out
+
+
 def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: int = 84, bins_per_octave: int = 12,
         tuning: float = 0.0, filter_scale: float = 1.0, sparsity: float = 0.01) -> torch.Tensor:
     """Constant-Q transform of y [B, L] -> complex [B, n_bins, T, 2] float32, T = 1 + L // hop_length."""
@@ -1059,10 +1090,21 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
     side = _side_stream(y.device) if two else main
     if two:
         side.wait_stream(main)                    # `out` and `y` are ready for the side stream
+    # every decimation level up front (three levels per pass; SYGNALS_AMD_CQT_CHAIN=0: one launch per level)
+    n_dec = plan.early + sum(1 for o in plan.octaves[:-1] if o["decimate_after"])
+    chain = os.environ.get("SYGNALS_AMD_CQT_CHAIN", "1") != "0" and not two and n_dec > 0
+    levels = None
+    if chain:
+        keepl = [i >= plan.early - 1 for i in range(n_dec)]
+        levels = [y] + decimate2_chain(y, plan.taps_dev, s2, n_dec, keepl)
     cur = y
-    for _ in range(plan.early):
-        cur = decimate2(cur, plan.taps_dev, s2)
-    for o in plan.octaves:
+    lvl = plan.early
+    if chain:
+        cur = levels[lvl]
+    else:
+        for _ in range(plan.early):
+            cur = decimate2(cur, plan.taps_dev, s2)
+    for oi, o in enumerate(plan.octaves):
         if o["n"] > 0:
             if two:
                 ev = torch.cuda.Event()
@@ -1084,8 +1126,9 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
                                               o["hull"].ctypes.data_as(C.c_void_p), _ptr(out),
                                               plan.n_bins * Tn, o["row0"], sp)
                 check(rc, "syg_cqt_octave_f32")
-        if o["decimate_after"]:
-            cur = decimate2(cur, plan.taps_dev, s2)
+        if o["decimate_after"] and oi + 1 < len(plan.octaves):
+            lvl += 1
+            cur = levels[lvl] if chain else decimate2(cur, plan.taps_dev, s2)
     if two:
         main.wait_stream(side)
     return out

@@ -266,6 +266,69 @@ def test_cqt_both_octave_kernels_vs_oracle(path, monkeypatch):
     assert peak_rel(got[0], ref) <= TOL and peak_rel(got[1], -2 * ref) <= TOL
 
 
+@pytest.mark.parametrize("sr,hop,n_bins,L,B", [(48000, 512, 84, 48000 * 2 + 77, 1), (48000, 512, 84, 48000 * 2 + 76, 2),
+                                              (48000, 1024, 84, 48000 * 3 + 5, 1), (48000, 2048, 84, 48000 * 4, 1),
+                                              (22050, 512, 84, 22050 * 3 + 1, 1), (48000, 384, 72, 48000 + 3, 1),
+                                              (48000, 512, 84, 3000, 1)])
+def test_cqt_staged_frames_identical(sr, hop, n_bins, L, B, monkeypatch):
+    """Octaves whose frames overlap split each 128-frame run of samples once in LDS (cqt_bf16x3_staged_kernel); the
+    operands and the order of the matrix instructions are those of the per-frame kernel: identical bits, for every slot
+    skew (hop / 8 = 1 ... 32), ragged tails, runs that start before and end past the signal, and a batch."""
+    from sygnals_amd import ops
+    import torch
+    rng = np.random.default_rng(L)
+    x = ops.to_device_f32(rng.normal(0, 0.3, (B, L)).astype(np.float32))
+    monkeypatch.setenv("SYGNALS_AMD_CQT", "bf16x3")
+    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "1")
+    a = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
+    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "0")
+    b = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
+    assert a.shape == b.shape and torch.equal(a, b)
+    if L <= 48000 * 2 + 77 and B == 1:
+        ref = O.cqt(x[0].cpu().numpy().astype(np.float64), sr, hop_length=hop, n_bins=n_bins)
+        got = a[0].cpu().numpy()
+        assert peak_rel(got[..., 0] + 1j * got[..., 1], ref) <= TOL
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (1, 5), (2, 101), (1, 3823), (3, 3824 * 2 + 1), (1, 478 * 8 * 9), (2, 1 << 20), (1, (1 << 21) + 12345)])
+def test_decimate2_chain_identical_to_level_by_level(B, L):
+    """Two or three decimations carried through LDS in one pass: the same bits as one launch per level (zero padding of
+    every level at both ends, tiles whose halo crosses the signal's ends, ragged lengths, batches with odd row strides),
+    levels that are not wanted left out, and a tap count without the fused form falling back to level-by-level."""
+    from sygnals_amd import ops
+    from sygnals_amd._cqt import decimation_taps
+    import torch
+    rng = np.random.default_rng(L)
+    x = ops.to_device_f32(rng.normal(0, 1, (B, L)).astype(np.float32))
+    taps = ops.to_device_f32(decimation_taps().astype(np.float32))
+    s2 = float(np.sqrt(2.0))
+    ref, cur = [], x
+    for _ in range(7):
+        cur = ops.decimate2(cur, taps, s2)
+        ref.append(cur)
+    for levels in (1, 2, 3, 5, 7):
+        got = ops.decimate2_chain(x, taps, s2, levels)
+        assert len(got) == levels
+        for g, r in zip(got, ref):
+            assert g.shape == r.shape and torch.equal(g, r)
+    got = ops.decimate2_chain(x, taps, s2, 6, keep=[False, True, False, False, True, False])
+    assert got[0] is None and got[2] is None and got[3] is None
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[4], ref[4]) and torch.equal(got[5], ref[5])
+    t9 = ops.to_device_f32(rng.normal(0, 0.3, 9).astype(np.float32))
+    a = ops.decimate2_chain(x, t9, 1.0, 2)
+    assert torch.equal(a[1], ops.decimate2(ops.decimate2(x, t9, 1.0), t9, 1.0))
+
+
+def test_cqt_chain_and_level_by_level_identical(monkeypatch):
+    from sygnals_amd import ops
+    import torch
+    x = ops.to_device_f32(np.random.default_rng(3).normal(0, 0.3, (2, 48000 * 5 + 3)).astype(np.float32))
+    monkeypatch.setenv("SYGNALS_AMD_CQT_CHAIN", "1")
+    a = ops.cqt(x, 48000)
+    monkeypatch.setenv("SYGNALS_AMD_CQT_CHAIN", "0")
+    assert torch.equal(a, ops.cqt(x, 48000))
+
+
 def test_cqt_batch_long_stream_consistency():
     """C5-shaped use: a batch of long streams; size-independent property: linearity and time-shift by whole hops."""
     from sygnals_amd import ops
