@@ -642,51 +642,56 @@ __global__ __launch_bounds__(256) void cqt_bf16x3_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------
 // Overlapping frames (hop <= n_fft / 2, the lower octaves: hop halves with every decimation while the filters keep
-// their length, so a sample sits in 2 .. 32 frames): the kernel above splits a sample once per frame that holds it,
-// and that splitting is most of its time.  Here a workgroup of eight waves takes 128 consecutive frames, splits their
-// contiguous sample run ((128 - 1) hop + n_fft samples) ONCE into three bfloat16 planes in LDS, and every wave reads
-// its frames' B operands from the planes with ds_read_b128 (8 consecutive samples = 16 B; hop % 8 == 4 keeps a second
-// copy of the planes shifted by four samples, so that every frame start is 16-byte aligned in one of the two).  The
-// 16-byte chunk i of the run sits at slot i + (i >> sh): lane (n, kk) of step s reads chunk n hop/8 + kk + 4 s, and the
-// skew (sh = log2(hop / 8) - 1 for hop >= 32) spreads the 16 lanes of every ds_read_b128 lane group over the 16 bank
-// groups (checked by enumeration for hop / 8 in {1, 2, 4, 8, 16, 32}; other hops work with 2-way conflicts).
-// The next run's samples are requested from global memory before the products of the current one and split after
-// them.  Same operands, same MFMA order as cqt_bf16x3_kernel: the two produce identical bits.
-constexpr int CQS_NW = 8;                      // waves per workgroup
-constexpr int CQS_FB = 16 * CQS_NW;            // frames per run
-constexpr int CQS_MAXC = 5;                    // 16-byte chunks per thread and run: (127 * 128 + 256) / 8 = 2064 <= 5 * 512
-
-template <int NFFT, int RT>
-__global__ __launch_bounds__(CQS_NW * 64) void cqt_bf16x3_staged_kernel(const float* __restrict__ ysig, int64_t L,
-                                                                        int64_t ldy, int hop, int64_t T,
-                                                                        const uint4* __restrict__ gsplit, int n_filt,
-                                                                        float2* __restrict__ out, int64_t out_bstride,
-                                                                        int row0, int nchunks, int cplane, int ncopy,
-                                                                        int sh) {
+// their length, so a sample sits in 2 .. 64 frames): the kernel above splits a sample once per frame that holds it,
+// and that splitting is most of its time.  Here a WAVE splits the contiguous sample run of its 16-frame tile
+// ((16 - 1) hop + n_fft samples) once into three bfloat16 planes in an LDS region of its own and reads its frames' B
+// operands from the planes with ds_read_b128 (8 consecutive samples = 16 B; hop % 8 == 4 keeps a second copy of the
+// planes shifted by four samples, so that every frame start is 16-byte aligned in one of the two).  The 16-byte chunk i
+// of the run sits at slot i + (i >> sh): lane (n, kk) of step s reads chunk n hop/8 + kk + 4 s, and the skew
+// (sh = log2(hop / 8) - 1 for hop >= 32) spreads the 16 lanes of every ds_read_b128 lane group over the 16 bank groups
+// (checked by enumeration for hop / 8 in {1, 2, 4, 8, 16, 32}; other hops work with 2-way conflicts).  The waves of a
+// workgroup share only the operand table: no barrier after the first, each wave requests the samples of its next tile
+// before the products of the current one and splits them afterwards.  As many waves per workgroup (one workgroup per
+// CU) as the LDS holds regions.  Same operands, same MFMA order as cqt_bf16x3_kernel: the two produce identical bits.
+#ifdef SYG_CQT_STAMP
+__device__ unsigned long long cqs_stamp[4 * 4096];       // development build: per-wave wall-clock stamps (100 MHz)
+#define CQS_STAMP(k) do { if (lane == 0 && blockIdx.x * nwv + w < 4096) { cqs_stamp[(blockIdx.x * nwv + w) * 4 + (k)] = wall_clock64(); if ((k) != 1) cqs_stamp[(blockIdx.x * nwv + w) * 4 + ((k) == 0 ? 1 : 3)] = clock64(); } } while (0)
+#else
+#define CQS_STAMP(k) do { } while (0)
+#endif
+// MAXC: 16-byte chunks per lane and tile (hop 128: (15 * 128 + 256) / 8 = 272 chunks <= 5 * 64)
+template <int NFFT, int RT, int MAXC>
+__global__ __launch_bounds__(MAXC == 5 ? 512 : MAXC == 3 ? 768 : 1024) void cqt_bf16x3_staged_kernel(const float* __restrict__ ysig, int64_t L, int64_t ldy,
+                                                                 int hop, int64_t T, const uint4* __restrict__ gsplit,
+                                                                 int n_filt, float2* __restrict__ out,
+                                                                 int64_t out_bstride, int row0, int nchunks, int cplane,
+                                                                 int ncopy, int sh) {
   constexpr int S = NFFT / 32;
   constexpr int NA = 3 * RT * S * 64;
-  constexpr int NT = CQS_NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint4 cqs_lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
   uint4* atab = cqs_lds;                         // [term][row tile][step][lane]
-  uint4* stage = cqs_lds + NA;                   // [term][slot]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < NA; i += NT) atab[i] = gsplit[i];
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwv = nt >> 6;
+  CQS_STAMP(0);
+  for (int i = tid; i < NA; i += nt) atab[i] = gsplit[i];
+  const int plane = cplane * ncopy;
+  const int ntot = nchunks * ncopy;
+  uint4* stage = cqs_lds + NA + w * 3 * plane;   // this wave's [term][copy][slot]
   const int64_t b = blockIdx.y;
   const float* yb = ysig + b * ldy;
   const int n = lane & 15, kk = lane >> 4;
-  const int plane = cplane * ncopy;
-  const int ntot = nchunks * ncopy;
-  const int64_t nruns = (T + CQS_FB - 1) / CQS_FB;
+  const int64_t ntiles = (T + 15) >> 4;
+  const int64_t tstride = (int64_t)gridDim.x * nwv;
   const int f0 = 2 * kk;
 
-  float4 pre[2 * CQS_MAXC];
-  auto fetch = [&](int64_t run) {
-    const int64_t s0 = run * CQS_FB * (int64_t)hop - NFFT / 2;
+  float4 pre[2 * MAXC];
+  auto fetch = [&](int64_t tile) {
+    const int64_t s0 = tile * 16 * (int64_t)hop - NFFT / 2;
 #pragma unroll
-    for (int c = 0; c < CQS_MAXC; ++c) {
-      const int idx = tid + NT * c;
+    for (int c = 0; c < MAXC; ++c) {
+      const int idx = lane + 64 * c;
       if (idx < ntot) {
         const int cp = idx >= nchunks ? 1 : 0, i = idx - cp * nchunks;
         const int64_t g = s0 + 4 * cp + 8 * (int64_t)i;
@@ -705,8 +710,9 @@ __global__ __launch_bounds__(CQS_NW * 64) void cqt_bf16x3_staged_kernel(const fl
   };
   auto park = [&]() {
 #pragma unroll
-    for (int c = 0; c < CQS_MAXC; ++c) {
-      const int idx = tid + NT * c;
+    for (int c = 0; c < MAXC; ++c) {
+      if (c > 0) __builtin_amdgcn_sched_barrier(0);             // one chunk's temporaries at a time
+      const int idx = lane + 64 * c;
       if (idx < ntot) {
         const int cp = idx >= nchunks ? 1 : 0, i = idx - cp * nchunks;
         const float x[8] = {pre[2 * c].x, pre[2 * c].y, pre[2 * c].z, pre[2 * c].w,
@@ -721,41 +727,69 @@ __global__ __launch_bounds__(CQS_NW * 64) void cqt_bf16x3_staged_kernel(const fl
     }
   };
 
-  int64_t run = blockIdx.x;
-  if (run < nruns) fetch(run);
-  for (; run < nruns; run += gridDim.x) {
+  // wave w of workgroup g is wave w * gridDim.x + g of the grid: the waves that get one tile more than the others
+  // (the first ntiles mod n_waves of them) are then spread over all CUs instead of filling the first few
+  int64_t tile = (int64_t)w * gridDim.x + blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  __syncthreads();                               // the operand table is in place (the only workgroup barrier)
+  const int fo = n * hop;                        // the frame's first sample inside the tile's run
+  const int cp = ncopy == 2 ? (fo >> 2) & 1 : 0;
+  const int i0 = ((fo - 4 * cp) >> 3) + kk;
+  const int coff = cp * cplane;
+  for (; tile < ntiles; tile += tstride) {
     park();
-    __syncthreads();                             // (the first pass also orders the operand table)
-    const int64_t nxt = run + gridDim.x;
-    if (nxt < nruns) fetch(nxt);
+    wave_lds_sync();
+    if (tile + tstride < ntiles) fetch(tile + tstride);
     cq_v4f acc[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = cq_v4f{0.f, 0.f, 0.f, 0.f};
-    const int fo = (w * 16 + n) * hop;            // the frame's first sample inside the run
-    const int cp = ncopy == 2 ? (fo >> 2) & 1 : 0;
-    const int i0 = ((fo - 4 * cp) >> 3) + kk;
-    const int coff = cp * cplane;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
+    // operands of step s + 1 are requested from LDS before the matrix instructions of step s issue (two register
+    // sets); within a step the two row tiles alternate, so consecutive matrix instructions are independent
+    v8bf Ah[2][RT], Am[2][RT], Al[2][RT], Bh[2], Bm[2], Bl[2];
+    auto operands = [&](int s, int q) {          // (read in the order the matrix instructions consume them)
       const int i = i0 + 4 * s;
       const int slot = i + (i >> sh) + coff;
-      const v8bf bh = *reinterpret_cast<const v8bf*>(&stage[slot]);
-      const v8bf bm = *reinterpret_cast<const v8bf*>(&stage[plane + slot]);
-      const v8bf bl = *reinterpret_cast<const v8bf*>(&stage[2 * plane + slot]);
+      Bh[q] = *reinterpret_cast<const v8bf*>(&stage[slot]);
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const v8bf ah = *reinterpret_cast<const v8bf*>(&atab[((0 * RT + r) * S + s) * 64 + lane]);
-        const v8bf am = *reinterpret_cast<const v8bf*>(&atab[((1 * RT + r) * S + s) * 64 + lane]);
-        const v8bf al = *reinterpret_cast<const v8bf*>(&atab[((2 * RT + r) * S + s) * 64 + lane]);
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[r], 0, 0, 0);
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[r], 0, 0, 0);
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[r], 0, 0, 0);
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[r], 0, 0, 0);
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[r], 0, 0, 0);
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[r], 0, 0, 0);
+      for (int r = 0; r < RT; ++r) Al[q][r] = *reinterpret_cast<const v8bf*>(&atab[((2 * RT + r) * S + s) * 64 + lane]);
+      Bl[q] = *reinterpret_cast<const v8bf*>(&stage[2 * plane + slot]);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) Ah[q][r] = *reinterpret_cast<const v8bf*>(&atab[((0 * RT + r) * S + s) * 64 + lane]);
+      Bm[q] = *reinterpret_cast<const v8bf*>(&stage[plane + slot]);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) Am[q][r] = *reinterpret_cast<const v8bf*>(&atab[((1 * RT + r) * S + s) * 64 + lane]);
+    };
+    operands(0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int q = s & 1;
+      if (s + 1 < S) operands(s + 1, q ^ 1);
+      // small terms first (per accumulator the same order as cqt_bf16x3_kernel)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[q][r], Bh[q], acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[q][r], Bl[q], acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[q][r], Bm[q], acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[q][r], Bh[q], acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[q][r], Bm[q], acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[q][r], Bh[q], acc[r], 0, 0, 0);
+      // issue order of the step: one LDS read of the next step behind each of the first matrix instructions
+      if (s + 1 < S) {
+#pragma unroll
+        for (int k = 0; k < 3 + 3 * RT; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * RT - (3 + 3 * RT), 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const int64_t t = run * CQS_FB + w * 16 + n;
+    wave_lds_sync();                             // the planes have been read before the next tile's are written
+    const int64_t t = tile * 16 + n;
     if (t < T) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
@@ -765,8 +799,8 @@ __global__ __launch_bounds__(CQS_NW * 64) void cqt_bf16x3_staged_kernel(const fl
         if (f + 1 < n_filt) o[T] = make_float2(acc[r][2], acc[r][3]);
       }
     }
-    __syncthreads();                             // every wave has read the planes before the next run overwrites them
   }
+  CQS_STAMP(2);
 }
 
 bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
@@ -933,42 +967,52 @@ extern "C" int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, i
   const int rt = (2 * n_filt + 15) / 16;
   const int64_t ntiles = (T + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  // overlapping frames: split each sample once per 128-frame run (cqt_bf16x3_staged_kernel)
+  // overlapping frames: every wave splits the sample run of its 16-frame tile once (cqt_bf16x3_staged_kernel)
   {
     const char* e = getenv("SYGNALS_AMD_CQT_STAGED");
     const bool off = e && e[0] == '0';
     const bool shape_ok = hop % 4 == 0 && hop <= n_fft / 2;
     const int ncopy = hop % 8 == 0 ? 1 : 2;
-    const int nchunks = shape_ok ? ((CQS_FB - 1) * hop + n_fft) / 8 : 0;
+    const int nchunks = shape_ok ? (15 * hop + n_fft) / 8 : 0;
     int sh = 31;                                   // slot skew: floor(log2(hop / 8)) - 1 for hop >= 32, none below
     if (hop >= 32) { const int h8 = hop >> 3; int lg = 0; while ((2 << lg) <= h8) ++lg; sh = lg - 1; }
     int cplane = sh < 31 ? nchunks + (nchunks >> sh) + 1 : nchunks;
     if (ncopy == 2) cplane = ((cplane + 7) & ~15) + 8;          // the second copy starts 8 bank groups over
-    const size_t lds = (size_t)(3 * rt * (n_fft / 32) * 64 + 3 * ncopy * cplane) * 16;
-    if (!off && shape_ok && ((uintptr_t)y) % 16 == 0 && (B == 1 || ldy % 4 == 0) &&
-        ncopy * nchunks <= CQS_MAXC * CQS_NW * 64 && lds <= 160 * 1024 - 512) {
+    const size_t atab_bytes = (size_t)3 * rt * (n_fft / 32) * 64 * 16;
+    const size_t wave_bytes = (size_t)3 * ncopy * cplane * 16;
+    int nwv = shape_ok ? (int)((160 * 1024 - 512 - atab_bytes) / wave_bytes) : 0;       // regions the LDS holds
+    const int maxc = (ncopy * nchunks + 63) / 64;
+    // (hop = n_fft / 2, maxc 5: a sample sits in two frames only and the LDS holds 7 regions -- measured slower than the
+    //  per-frame kernel, 78 vs 66 us per C5 octave; SYGNALS_AMD_CQT_STAGED=2 forces it for the tests)
+    const bool worth = maxc <= 3 || (e && e[0] == '2');
+    const int wcap = maxc > 3 ? 8 : maxc == 3 ? 12 : 16;       // the kernels' launch bounds (longer runs hold more registers)
+    if (nwv > wcap) nwv = wcap;
+    if (!off && worth && shape_ok && ((uintptr_t)y) % 16 == 0 && (B == 1 || ldy % 4 == 0) && ncopy * nchunks <= 5 * 64 &&
+        nwv >= 4) {
       int dev = 0, n_cu = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
           hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
         set_error("cqt_octave_bf16x3: cannot query the device");
         return SYG_E_LAUNCH;
       }
-      const int64_t nruns = (T + CQS_FB - 1) / CQS_FB;
-      const int per_cu = lds <= 80 * 1024 - 256 ? 2 : 1;
-      int64_t gx = ((int64_t)n_cu * per_cu + B - 1) / B;
-      if (gx > nruns) gx = nruns;
+      if (const char* pe = getenv("SYGNALS_AMD_CQT_WAVES")) { const int v = atoi(pe); if (v >= 1 && v < nwv) nwv = v; }  // (development)
+      const size_t lds = atab_bytes + (size_t)nwv * wave_bytes;
+      int64_t gx = ((int64_t)n_cu + B - 1) / B;    // one workgroup per CU over the batch
+      if (gx * nwv > ntiles) gx = (ntiles + nwv - 1) / nwv;
       if (gx < 1) gx = 1;
-      const dim3 grid((unsigned)gx, (unsigned)B), block(CQS_NW * 64);
-#define SYG_CQT_ST(N, R)                                                                                             \
+      const dim3 grid((unsigned)gx, (unsigned)B), block(nwv * 64);
+#define SYG_CQT_ST(N, R, C)                                                                                          \
   do {                                                                                                               \
-    hipError_t e2 = hipFuncSetAttribute((const void*)cqt_bf16x3_staged_kernel<N, R>,                                 \
+    hipError_t e2 = hipFuncSetAttribute((const void*)cqt_bf16x3_staged_kernel<N, R, C>,                              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     if (e2 != hipSuccess) { set_error("cqt_octave_bf16x3: cannot reserve LDS: %s", hipGetErrorString(e2)); return SYG_E_LAUNCH; } \
-    hipLaunchKernelGGL((cqt_bf16x3_staged_kernel<N, R>), grid, block, lds, st, y, L, ldy, hop, T, (const uint4*)gsplit, \
-                       n_filt, (float2*)out, out_bstride, row0, nchunks, cplane, ncopy, sh);                                 \
+    hipLaunchKernelGGL((cqt_bf16x3_staged_kernel<N, R, C>), grid, block, lds, st, y, L, ldy, hop, T,                 \
+                       (const uint4*)gsplit, n_filt, (float2*)out, out_bstride, row0, nchunks, cplane, ncopy, sh);   \
   } while (0)
-      if (n_fft == 128) { if (rt == 2) SYG_CQT_ST(128, 2); else SYG_CQT_ST(128, 1); }
-      else { if (rt == 2) SYG_CQT_ST(256, 2); else SYG_CQT_ST(256, 1); }
+#define SYG_CQT_ST2(N, R) do { if (maxc <= 2) SYG_CQT_ST(N, R, 2); else if (maxc == 3) SYG_CQT_ST(N, R, 3); else SYG_CQT_ST(N, R, 5); } while (0)
+      if (n_fft == 128) { if (rt == 2) SYG_CQT_ST2(128, 2); else SYG_CQT_ST2(128, 1); }
+      else { if (rt == 2) SYG_CQT_ST2(256, 2); else SYG_CQT_ST2(256, 1); }
+#undef SYG_CQT_ST2
 #undef SYG_CQT_ST
       SYG_CHECK_LAUNCH("cqt_octave_bf16x3 (staged)");
       return SYG_OK;
@@ -988,3 +1032,9 @@ extern "C" int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, i
   SYG_CHECK_LAUNCH("cqt_octave_bf16x3");
   return SYG_OK;
 }
+
+#ifdef SYG_CQT_STAMP
+extern "C" int syg_debug_cqt_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(syg::cqs_stamp), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -271,19 +271,22 @@ def test_cqt_both_octave_kernels_vs_oracle(path, monkeypatch):
                                               (22050, 512, 84, 22050 * 3 + 1, 1), (48000, 384, 72, 48000 + 3, 1),
                                               (48000, 512, 84, 3000, 1)])
 def test_cqt_staged_frames_identical(sr, hop, n_bins, L, B, monkeypatch):
-    """Octaves whose frames overlap split each 128-frame run of samples once in LDS (cqt_bf16x3_staged_kernel); the
-    operands and the order of the matrix instructions are those of the per-frame kernel: identical bits, for every slot
-    skew (hop / 8 = 1 ... 32), ragged tails, runs that start before and end past the signal, and a batch."""
+    """Octaves whose frames overlap split the sample run of a 16-frame tile once in LDS (cqt_bf16x3_staged_kernel); the
+    operands and the order of the matrix instructions per accumulator are those of the per-frame kernel: identical
+    bits, for every slot skew (hop / 8 = 1 ... 16), hops of 4 mod 8 (two shifted copies), ragged tails, tiles that start
+    before and end past the signal, and a batch."""
     from sygnals_amd import ops
     import torch
     rng = np.random.default_rng(L)
     x = ops.to_device_f32(rng.normal(0, 0.3, (B, L)).astype(np.float32))
     monkeypatch.setenv("SYGNALS_AMD_CQT", "bf16x3")
-    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "1")
+    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "2")          # 2: also where hop = n_fft / 2 (not the default there)
     a = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
+    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "1")
+    a1 = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
     monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "0")
     b = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
-    assert a.shape == b.shape and torch.equal(a, b)
+    assert a.shape == b.shape and torch.equal(a, b) and torch.equal(a1, b)
     if L <= 48000 * 2 + 77 and B == 1:
         ref = O.cqt(x[0].cpu().numpy().astype(np.float64), sr, hop_length=hop, n_bins=n_bins)
         got = a[0].cpu().numpy()
