@@ -211,7 +211,10 @@ struct DecOut {
 };
 
 template <int NT, int NL>
-__global__ __launch_bounds__(DEC_NT, 5) void decimate2_chain_kernel(const float* __restrict__ x, int64_t ldx,
+#ifndef SYG_DEC_WAVES
+#define SYG_DEC_WAVES 4
+#endif
+__global__ __launch_bounds__(DEC_NT, SYG_DEC_WAVES) void decimate2_chain_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const float* __restrict__ taps, float scale, DecOut o,
                                                                 int64_t ntiles) {
   constexpr int HALF = (NT - 1) / 2, H2 = HALF / 2;
@@ -251,7 +254,11 @@ __global__ __launch_bounds__(DEC_NT, 5) void decimate2_chain_kernel(const float*
   constexpr int NP0 = DC::cnt(0) / 2;
   constexpr int NR0 = (NP0 + DEC_NT - 1) / DEC_NT;
   constexpr int A0OFF = HALF * ((1 << NL) - 1);  // a[0] = 2^NL a[NL] - HALF (2^NL - 1)
+#ifdef SYG_DEC_NOXCD
+  auto tile_of = [&](int64_t wg) { return wg; };
+#else
   auto tile_of = [&](int64_t wg) { return (wg & 7) * per_x + (wg >> 3); };
+#endif
   auto is_fast = [&](int64_t tile) {
     const int64_t a0 = tile * ((int64_t)DC::NF << NL) - A0OFF;
     return pair_ok && a0 >= 0 && a0 + 2 * NP0 <= len0;
@@ -868,7 +875,7 @@ extern "C" int syg_decimate2_chain_f32(const float* x, int64_t B, int64_t L, int
   const int nf = levels == 3 ? DecChain<3>::NF : DecChain<2>::NF;
   const int64_t ntiles = (o.len[levels] + nf - 1) / nf;
   int64_t blocks = ((ntiles + 7) / 8) * 8;                      // a multiple of 8: a workgroup keeps its XCD
-  const int64_t cap = (((int64_t)n_cu * 5 + B - 1) / B + 7) / 8 * 8;
+  const int64_t cap = (((int64_t)n_cu * SYG_DEC_WAVES + B - 1) / B + 7) / 8 * 8;
   if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned)blocks, (unsigned)B), block(DEC_NT);
   if (levels == 3)
