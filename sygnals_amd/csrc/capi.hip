@@ -18,5 +18,9 @@ void set_error(const char* fmt, ...) {
 extern "C" int syg_abi_version(void) { return SYG_ABI_VERSION; }
 // 0 for the product build; the SYG_ABL number of a development build (ablation / timeline variants compute WRONG
 // results by design; build_lib.sh writes them to their own path and the Python binding refuses to load one)
+#if defined(SYG_SOSC_ABL)
+extern "C" int syg_build_variant(void) { return 100 + SYG_SOSC_ABL; }      // sosfilt_clip.hip timing ablations
+#else
 extern "C" int syg_build_variant(void) { return SYG_ABL; }
+#endif
 extern "C" const char* syg_last_error(void) { return syg::g_err; }

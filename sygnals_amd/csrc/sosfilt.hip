@@ -30,7 +30,9 @@
 // global accesses stay coalesced while each lane walks its own chunk; the next tile's loads are issued before the
 // recurrence over the current one.  One wave per workgroup: ordering inside the wave replaces barriers.
 #include "common.h"
+#include "sosfilt_clip.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace syg {
 namespace {
@@ -405,8 +407,30 @@ extern "C" int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t
     host_step(sos5, S, z, 0.0);
     for (int i = 0; i < D; ++i) A1[i * MAXD + j] = z[i];
   }
-  mat_pow(A1, D, CS, P.apow);
   hipStream_t st = (hipStream_t)stream;
+  // clips that fit a workgroup's registers: both sweeps in one launch (sosfilt_clip.hip); SYGNALS_AMD_SOS_CLIP=0 keeps
+  // the chunked path below (development / tests)
+  {
+    const int64_t lext = L + 2 * (int64_t)padlen;
+    const int cs = sos_clip_chunk(lext);
+    const char* e = getenv("SYGNALS_AMD_SOS_CLIP");
+    if (cs > 0 && sos_clip_supported(S) && !(e && e[0] == '0')) {
+      SosClipParams C;
+      memset(&C, 0, sizeof(C));
+      for (int s = 0; s < S; ++s) {
+        C.b0[s] = P.b0[s]; C.b1[s] = P.b1[s]; C.b2[s] = P.b2[s]; C.a1[s] = P.a1[s]; C.a2[s] = P.a2[s];
+        C.zi[2 * s] = P.zi[2 * s]; C.zi[2 * s + 1] = P.zi[2 * s + 1];
+      }
+      double Ap[MAXD * MAXD];
+      mat_pow(A1, D, cs, Ap);
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) C.apow[i * SOSC_MAXD + j] = Ap[i * MAXD + j];
+      sos_clip_launch(x, B, (int)L, ldx, C, S, cs, padlen, y, ldy, st);
+      SYG_CHECK_LAUNCH("sosfiltfilt (clip-resident)");
+      return SYG_OK;
+    }
+  }
+  mat_pow(A1, D, CS, P.apow);
   switch (S) {
     case 1: return launch_all<1>(x, B, L, ldx, P, padlen, y, ldy, work, st);
     case 2: return launch_all<2>(x, B, L, ldx, P, padlen, y, ldy, work, st);

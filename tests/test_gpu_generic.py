@@ -156,6 +156,55 @@ def test_sosfiltfilt_c3_clips(ops):
         ops.sosfiltfilt(ops.to_device_f32(Y[:1, :27]), sos, O.sosfilt_zi(sos), 27)
 
 
+@pytest.mark.parametrize("L", [28, 100, 16384 - 54, 16384 - 53, 30000, 32768 - 54, 40001, 48000, 49152 - 54, 49152 - 53, 65000,
+                               65536 - 54, 65536 - 53])
+def test_sosfiltfilt_clip_resident_lengths(ops, L, monkeypatch):
+    """Clips that fit a workgroup's registers take both sweeps in one launch (sosfilt_clip.hip: 64 / 128 / 192 / 256
+    samples per lane): every chunk length and the lengths on either side of each boundary, against the oracle, and
+    against the chunked path (same float64 recurrences, other chunking: agreement far inside the tolerance)."""
+    sos = O.design_butterworth_sos((300.0, 3400.0), 48000.0, 4, "bandpass")
+    rng = np.random.default_rng(L)
+    x = np.stack([rng.normal(0, 0.3, L) + 0.7, np.sin(np.arange(L) * 0.05) * (1 + rng.normal(0, 0.01, L)),
+                  rng.normal(0, 1.0, L)]).astype(np.float32)
+    monkeypatch.setenv("SYGNALS_AMD_SOS_CLIP", "1")
+    y = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
+    monkeypatch.setenv("SYGNALS_AMD_SOS_CLIP", "0")
+    yc = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
+    for i in range(3):
+        ref = O.apply_sos_filter(sos, x[i].astype(np.float64))
+        assert_parity(y[i], ref, TOL, f"L={L} row {i}")
+        assert np.max(np.abs(y[i] - yc[i])) <= 2e-6 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("order,kind,cut", [(2, "lowpass", 1000.0), (4, "highpass", 500.0), (5, "lowpass", 4000.0),
+                                            (8, "lowpass", 2000.0), (3, "bandpass", (200.0, 2000.0)), (10, "lowpass", 3000.0)])
+def test_sosfiltfilt_section_counts(ops, order, kind, cut):
+    """1 ... 4 sections go through the clip-resident kernel, 5 through the chunked one."""
+    sos = O.design_butterworth_sos(cut, 48000.0, order, kind)
+    pad = O.sosfiltfilt_padlen(sos)
+    rng = np.random.default_rng(order)
+    x = (rng.normal(0, 0.5, (2, 24000)) + np.linspace(-1, 1, 24000)).astype(np.float32)
+    y = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), pad).cpu().numpy()
+    for i in range(2):
+        assert_parity(y[i], O.apply_sos_filter(sos, x[i].astype(np.float64)), TOL, f"order {order} {kind} row {i}")
+
+
+@pytest.mark.parametrize("L", [65536 - 54, 65537, 200001, 1 << 20])
+def test_sosfiltfilt_long_signals(ops, L):
+    """More than 256 chunks per signal: every thread of the chunk-state prefix owns several consecutive chunks
+    (M^q by squaring in LDS); lengths around the 256-chunk boundary and a ragged last thread."""
+    sos = O.design_butterworth_sos((300.0, 3400.0), 48000.0, 4, "bandpass")
+    rng = np.random.default_rng(L)
+    t = np.arange(L) / 48000.0
+    x = np.stack([rng.normal(0, 0.3, L) + np.sin(2 * np.pi * 1000.0 * t), rng.normal(0, 1.0, L) + 0.5]).astype(np.float32)
+    y = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
+    for i in range(2):
+        assert_parity(y[i], O.apply_sos_filter(sos, x[i].astype(np.float64)), TOL, f"L={L} row {i}")
+    sos8 = O.design_butterworth_sos(1000.0, 48000.0, 8, "lowpass")          # four sections, other poles
+    y8 = ops.sosfiltfilt(ops.to_device_f32(x[:1]), sos8, O.sosfilt_zi(sos8), O.sosfiltfilt_padlen(sos8)).cpu().numpy()
+    assert_parity(y8[0], O.apply_sos_filter(sos8, x[0].astype(np.float64)), TOL, f"L={L} lowpass 8")
+
+
 WELCH = [("w4096", dict(nperseg=4096)), ("w256", dict(nperseg=256)), ("w1024o768", dict(nperseg=1024, noverlap=768)),
          ("w512nfft1024", dict(nperseg=512, nfft=1024)), ("w1024spec", dict(nperseg=1024, scaling="spectrum")),
          ("w1024nodet", dict(nperseg=1024, detrend=False)), ("w1024hamming", dict(nperseg=1024, window="hamming"))]
