@@ -69,8 +69,8 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
   constexpr int NT = CS / 32;                    // 32-sample tiles per chunk
   static_assert(CS % 32 == 0, "chunk length must be a multiple of the tile");
   __shared__ __attribute__((aligned(16))) float tile[4][64 * LSTR];
-  __shared__ double ex[NL * D];
-  __shared__ double Mk[D * D], Mt[D * D];
+  __shared__ double ex[2 * NL * D];
+  __shared__ double PW[8 * D * D];
   __shared__ float ylast;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
       xs[32 * t + 4 * r] = q.x; xs[32 * t + 4 * r + 1] = q.y; xs[32 * t + 4 * r + 2] = q.z; xs[32 * t + 4 * r + 3] = q.w;
     }
   }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  // tile t of the registers from piece order (8 lanes x 16 bytes per lane's row) to lane order (a lane's own 32 samples)
+  auto to_lane_order = [&](int t) {
     wave_lds_sync();                             // the previous tile has been read
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -116,9 +116,7 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
       const float4 q = *reinterpret_cast<const float4*>(&tl[lane * LSTR + 4 * k]);
       xs[32 * t + 4 * k] = q.x; xs[32 * t + 4 * k + 1] = q.y; xs[32 * t + 4 * k + 2] = q.z; xs[32 * t + 4 * k + 3] = q.w;
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
+  };
   SOSC_STAMP(1);
   double z0[S], z1[S];
   auto step = [&](double u) {
@@ -131,22 +129,40 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
     }
     return u;
   };
+  // M^(2^k), k = 0 .. 7, M = A^CS: squared once per workgroup, used by both sweeps' prefixes
+  if (tid < D * D) PW[tid] = P.apow[(tid / D) * SOSC_MAXD + (tid % D)];
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 1; k < 8; ++k) {
+    if (tid < D * D) {
+      const double* Mp = PW + (k - 1) * D * D;
+      const int r = tid / D, c = tid % D;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) acc = fma(Mp[r * D + q], Mp[q * D + c], acc);
+      PW[k * D * D + tid] = acc;
+    }
+    __syncthreads();
+  }
   // inclusive prefix of the chunk end states over the scan order `ord` (0 = first chunk of the sweep); on exit
-  // (z0, z1) = the true state this lane's chunk starts from (`start` for ord 0)
+  // (z0, z1) = the true state this lane's chunk starts from (`start` for ord 0).  One barrier per round: the states
+  // alternate between two LDS arrays (component-major: a lane's neighbours sit in the next banks).
   auto scan = [&](int ord, const double (&start)[D]) {
     double a[D];
 #pragma unroll
     for (int s = 0; s < S; ++s) { a[2 * s] = z0[s]; a[2 * s + 1] = z1[s]; }
-    __syncthreads();
-    if (tid < D * D) Mk[tid] = P.apow[(tid / D) * SOSC_MAXD + (tid % D)];
-    for (int off = 1; off < NL; off <<= 1) {
+    int kk = 0;
+#pragma unroll 1
+    for (int off = 1; off < NL; off <<= 1, ++kk) {
+      double* exk = ex + (kk & 1) * NL * D;
 #pragma unroll
-      for (int d = 0; d < D; ++d) ex[d * NL + ord] = a[d];      // (component-major: a lane's neighbours sit in the next banks)
+      for (int d = 0; d < D; ++d) exk[d * NL + ord] = a[d];
       __syncthreads();
       if (ord >= off) {
+        const double* Mk = PW + kk * D * D;
         double v[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) v[k] = ex[k * NL + ord - off];
+        for (int k = 0; k < D; ++k) v[k] = exk[k * NL + ord - off];
 #pragma unroll
         for (int r = 0; r < D; ++r) {            // (fully unrolled: a[] stays in registers; Mk reads are LDS broadcasts)
           double p0 = 0.0, p1 = 0.0;
@@ -158,27 +174,15 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
           a[r] += p0 + p1;
         }
       }
-      if (2 * off < NL) {                        // Mk <- Mk Mk
-        if (tid < D * D) {
-          const int r = tid / D, c = tid % D;
-          double acc = 0.0;
-#pragma unroll
-          for (int k = 0; k < D; ++k) acc = fma(Mk[r * D + k], Mk[k * D + c], acc);
-          Mt[tid] = acc;
-        }
-        __syncthreads();                         // (also: every lane has read ex)
-        if (tid < D * D) Mk[tid] = Mt[tid];
-      } else {
-        __syncthreads();
-      }
     }
+    double* exk = ex + (kk & 1) * NL * D;       // (eight rounds: the array the last round did not read)
 #pragma unroll
-    for (int d = 0; d < D; ++d) ex[d * NL + ord] = a[d];
+    for (int d = 0; d < D; ++d) exk[d * NL + ord] = a[d];
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      z0[s] = ord > 0 ? ex[(2 * s) * NL + ord - 1] : start[2 * s];
-      z1[s] = ord > 0 ? ex[(2 * s + 1) * NL + ord - 1] : start[2 * s + 1];
+      z0[s] = ord > 0 ? exk[(2 * s) * NL + ord - 1] : start[2 * s];
+      z1[s] = ord > 0 ? exk[(2 * s + 1) * NL + ord - 1] : start[2 * s + 1];
     }
   };
 
@@ -192,10 +196,16 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
 #pragma unroll
   for (int s = 0; s < S; ++s) { z0[s] = tid == 0 ? start[2 * s] : 0.0; z1[s] = tid == 0 ? start[2 * s + 1] : 0.0; }
   // (the fences keep the scheduler from converting dozens of samples ahead of their use: a register budget, not an order)
+  // a tile is put in lane order when the zero-state pass reaches it: the later tiles' loads are still in flight
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    to_lane_order(t);
+    __builtin_amdgcn_sched_barrier(0);
 #if !defined(SYG_SOSC_ABL)
 #pragma unroll
-  for (int j = 0; j < CS; ++j) { step((double)xs[j]); if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+    for (int j = 32 * t; j < 32 * t + 32; ++j) { step((double)xs[j]); if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
 #endif
+  }
   // (without this the compiler keeps the float64 conversions of pass 1 alive for pass 3: 2 CS registers more)
 #pragma unroll
   for (int j = 0; j < CS; ++j) asm volatile("" : "+v"(xs[j]));
@@ -242,19 +252,18 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
   SOSC_STAMP(5);
   scan(ord, start);
   SOSC_STAMP(6);
-#pragma unroll
-  for (int j = CS - 1; j >= (SOSC_TRUE_PASS ? 0 : CS); --j) {
-    float o = (float)step((double)xs[j]);
-    asm volatile("" : "+v"(o));
-    xs[j] = o;
-    if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-  }
-
-  SOSC_STAMP(7);
-  // ---- store y[n] = result at sequence index n + pad
+  // the true backward pass, a tile at a time from the top; a finished tile goes out (y[n] = result at sequence index
+  // n + pad) while the next one is computed
   float* yb = y + b * ldy;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  for (int t = NT - 1; t >= 0; --t) {
+#pragma unroll
+    for (int j = 32 * t + 31; j >= (SOSC_TRUE_PASS ? 32 * t : 32 * t + 32); --j) {
+      float o = (float)step((double)xs[j]);
+      asm volatile("" : "+v"(o));
+      xs[j] = o;
+      if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
     wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -275,6 +284,7 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  SOSC_STAMP(7);
 }
 
 template <int S>
