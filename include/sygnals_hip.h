@@ -273,7 +273,7 @@ int syg_rms_from_spec_f32(const float* S, int64_t rows, int F, int frame_length,
  * ------------------------------------------------------------------------------- */
 int syg_decimate2_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const float* taps, int ntaps, float scale,
                       float* y, int64_t ldy, void* stream);
- /* syg_decimate2_chain_f32: `levels` (1..3) successive decimations in one pass; y / ldy are HOST arrays of `levels`
+ /* syg_decimate2_chain_f32: `levels` (1..4) successive decimations in one pass; y / ldy are HOST arrays of `levels`
  *   device pointers / row strides, level s of length ceil(L / 2^(s+1)); an entry of y may be NULL when that level is
  *   not wanted (41 taps only; the last level is always written).  Bit-identical to `levels` calls of
  *   syg_decimate2_f32: with the CQT's 41-tap filter a workgroup carries its tile through all levels in LDS, so every

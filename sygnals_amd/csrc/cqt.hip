@@ -181,12 +181,12 @@ __global__ __launch_bounds__(DEC_NT, 8) void decimate2_fixed_kernel(const float*
   }
 }
 
-// Two or three decimations in one pass (the CQT walks down an octave per decimation and needs every level): the chain
+// Two to four decimations in one pass (the CQT walks down an octave per decimation and needs every level): the chain
 // x -> y1 -> y2 -> y3 moves 2 x the bytes of its largest member when every level is a launch of its own, because each
 // level is written and read back; here a workgroup carries a tile through all levels in LDS and writes each level once.
 // A tile owns NF outputs of the last level and the 2 NF / 4 NF outputs of the levels above; what the next level's
 // filter needs beyond them (20 samples per side and level) is recomputed from a wider input run (+7 % reads at NF = 478,
-// three levels).  Every value is produced by the same instructions in the same order as by decimate2_fixed_kernel and
+// three levels; +20 % at four, used where the input is already small).  Every value is produced by the same instructions in the same order as by decimate2_fixed_kernel and
 // passes to the next level as the float it would have been stored as; positions outside [0, L_level) are zero, as the
 // zero padding of a level-by-level chain makes them: identical bits.
 // Level s (s = 1 .. NL) computes CNT_s outputs from the level below, which sits in LDS split into even / odd samples
@@ -199,15 +199,15 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {          // a wave-uni
 
 template <int NL>
 struct DecChain {
-  static constexpr int NF = (NL == 3) ? 478 : 990;            // CNT_1 / 2 = 1022 / 1012 pairs: four rounds of 256 lanes
+  static constexpr int NF = (NL == 4) ? 206 : (NL == 3) ? 478 : 990;   // CNT_1 / 2 = 978 / 1022 / 1012 pairs: four rounds of 256 lanes
   static constexpr int cnt(int s) { return s == NL ? NF : 2 * cnt(s + 1) + 44; }
   static constexpr int lds_floats() { int t = 0; for (int s = 0; s < NL; ++s) t += cnt(s) + 4; return t; }
 };
 
 struct DecOut {
-  float* y[3];
-  int64_t ld[3];
-  int64_t len[4];                                // len[0] = L (input), len[s] = length of level s
+  float* y[4];
+  int64_t ld[4];
+  int64_t len[5];                                // len[0] = L (input), len[s] = length of level s
 };
 
 template <int NT, int NL>
@@ -842,12 +842,12 @@ extern "C" int syg_decimate2_chain_f32(const float* x, int64_t B, int64_t L, int
                                        float scale, int levels, float* const* y, const int64_t* ldy, void* stream) {
   SYG_REQUIRE(x && taps && y && ldy, "decimate2_chain: null pointer argument");
   SYG_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && ldx >= L, "decimate2_chain: bad B/L/ldx");
-  SYG_REQUIRE(levels >= 1 && levels <= 3, "decimate2_chain: levels must be 1, 2 or 3 (got %d)", levels);
+  SYG_REQUIRE(levels >= 1 && levels <= 4, "decimate2_chain: levels must be 1 ... 4 (got %d)", levels);
   SYG_REQUIRE(ntaps >= 1 && (ntaps & 1) == 1 && ntaps <= 1025, "decimate2_chain: ntaps must be odd and <= 1025");
   SYG_REQUIRE(y[levels - 1], "decimate2_chain: the last level needs an output buffer");
   DecOut o;
   o.len[0] = L;
-  for (int s = 0; s < 3; ++s) { o.y[s] = nullptr; o.ld[s] = 0; o.len[s + 1] = 0; }
+  for (int s = 0; s < 4; ++s) { o.y[s] = nullptr; o.ld[s] = 0; o.len[s + 1] = 0; }
   for (int s = 0; s < levels; ++s) {
     o.len[s + 1] = (o.len[s] + 1) / 2;
     o.y[s] = y[s];
@@ -872,13 +872,15 @@ extern "C" int syg_decimate2_chain_f32(const float* x, int64_t B, int64_t L, int
     set_error("decimate2_chain: cannot query the device");
     return SYG_E_LAUNCH;
   }
-  const int nf = levels == 3 ? DecChain<3>::NF : DecChain<2>::NF;
+  const int nf = levels == 4 ? DecChain<4>::NF : levels == 3 ? DecChain<3>::NF : DecChain<2>::NF;
   const int64_t ntiles = (o.len[levels] + nf - 1) / nf;
   int64_t blocks = ((ntiles + 7) / 8) * 8;                      // a multiple of 8: a workgroup keeps its XCD
   const int64_t cap = (((int64_t)n_cu * SYG_DEC_WAVES + B - 1) / B + 7) / 8 * 8;
   if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned)blocks, (unsigned)B), block(DEC_NT);
-  if (levels == 3)
+  if (levels == 4)
+    hipLaunchKernelGGL((decimate2_chain_kernel<41, 4>), grid, block, 0, (hipStream_t)stream, x, ldx, taps, scale, o, ntiles);
+  else if (levels == 3)
     hipLaunchKernelGGL((decimate2_chain_kernel<41, 3>), grid, block, 0, (hipStream_t)stream, x, ldx, taps, scale, o, ntiles);
   else
     hipLaunchKernelGGL((decimate2_chain_kernel<41, 2>), grid, block, 0, (hipStream_t)stream, x, ldx, taps, scale, o, ntiles);

@@ -1007,7 +1007,7 @@ def decimate2(x: torch.Tensor, taps: torch.Tensor, scale: float) -> torch.Tensor
 
 
 def decimate2_chain(x: torch.Tensor, taps: torch.Tensor, scale: float, levels: int, keep=None) -> list:
-    """`levels` successive decimate2 steps; 2 or 3 at a time go through one pass of syg_decimate2_chain_f32 (identical
+    """`levels` successive decimate2 steps; up to 4 at a time go through one pass of syg_decimate2_chain_f32 (identical
     bits, every level written once).  keep[s] False: level s is not wanted (returned as None; never the last one)."""
     require_gpu()
     if x.stride(1) != 1:
@@ -1018,7 +1018,7 @@ def decimate2_chain(x: torch.Tensor, taps: torch.Tensor, scale: float, levels: i
     cur = x
     s = 0
     while s < levels:
-        n = min(3, levels - s)
+        n = levels - s if levels - s <= 4 else 3        # three levels per pass; a remainder of four goes in one
         B, L = cur.shape
         ys, lens = [], L
         for j in range(n):
