@@ -485,6 +485,22 @@ __device__ __noinline__ uint32_t row_kth(lds_row prow, int lane, int lo, int n, 
   return prefix;
 }
 
+// the kk-th largest over the lanes of two 32-bit values per lane (two independent selections in one loop): bisection
+// from the top bit, per bit and value one vector compare and a scalar popcount.  kk is made scalar here (it arrives in
+// a vector register when the caller is an out-of-line function): thresholds and counts then live on the scalar unit.
+__device__ __forceinline__ void wave_kth_largest2_u32(uint32_t x, uint32_t y, int kk, uint32_t& tx, uint32_t& ty) {
+  const int ks = __builtin_amdgcn_readfirstlane(kk);
+  uint32_t a = 0, b = 0;
+#pragma unroll 4
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t ca = a | (1u << bit), cb = b | (1u << bit);
+    const int na = __popcll(__ballot(x >= ca)), nb = __popcll(__ballot(y >= cb));
+    a = (na >= ks) ? ca : a;
+    b = (nb >= ks) ? cb : b;
+  }
+  tx = a; ty = b;
+}
+
 // Data-oblivious sorting networks for the R values a lane holds (Batcher's odd-even merge sort pruned to R wires;
 // checked with the 0-1 principle, tools/sortnet.py).
 template <int R> struct SortNet;
@@ -581,6 +597,46 @@ __device__ __forceinline__ void contrast_extract_lds(lds_row prow, int lane, int
   wave_lds_sync();
   int ht = nv - 1, hb = 0;                        // head indices: next largest / next smallest of this lane
   float MHl = (nv > 0) ? wrow[(nv > 0 ? ht : 0) * 64 + lane] : -1.f, MLl = (nv > 0) ? v[0] : 3.4e38f;
+  // Selection instead of k extractions (k >= 8).  The k-th largest of the 64 lane maxima, T, has at least k values of
+  // the band at or above it, all of them in the lanes whose maximum reaches it: count them (C), sum their magnitudes, and
+  // take back the C - k smallest of them -- two or three wave-wide rounds instead of k (the lane maxima of 12 values
+  // each are the top of the band: C - k is small; when it is not, ties or a constant band, the k rounds below run).
+  // T by bisection on the bit patterns (non-negative floats order like their bits): 32 compares + scalar popcounts.
+  if (k >= 8 && n >= 64) {                      // (wave-uniform; every lane holds at least one value)
+    uint32_t Tu, Bu;                              // Bu: k-th smallest of the lane minima = ~(k-th largest of their complements)
+    wave_kth_largest2_u32(__float_as_uint(MHl), ~__float_as_uint(MLl), k, Tu, Bu);
+    Bu = ~Bu;
+    const float Th = __uint_as_float(Tu), Tl = __uint_as_float(Bu);
+    int ch = nv - R, cl = 0;                      // (the pads, +huge, count as >= Th: taken off up front)
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ch += (v[r] >= Th) ? 1 : 0; cl += (v[r] <= Tl) ? 1 : 0; }
+    const int Eh = wave_sum_i(ch) - k, El = wave_sum_i(cl) - k;
+    if (Eh <= 12 && El <= 12) {
+      const int cmax = (int)wave_max((float)(ch > cl ? ch : cl));
+      float ah = 0.f, al = 0.f;
+      for (int t = 0; t < cmax; ++t) {
+        const int ih = nv - 1 - t;
+        const float vh = wrow[(ih > 0 ? ih : 0) * 64 + lane], vl = wrow[(t < R ? t : 0) * 64 + lane];
+        ah += (t < ch) ? fsqrt(vh) : 0.f;
+        al += (t < cl) ? fsqrt(vl) : 0.f;
+      }
+      float Sh = wave_sum(ah), Sl = wave_sum(al);
+      // the extras: the smallest of the upper candidates, the largest of the lower ones
+      const int emax = Eh > El ? Eh : El;
+      for (int e = 0; e < emax; ++e) {
+        float lo_c = (ch > 0) ? wrow[(nv - ch) * 64 + lane] : 3.4e38f;       // this lane's smallest upper candidate
+        float hi_c = (cl > 0) ? wrow[(cl - 1) * 64 + lane] : -1.f;           // its largest lower candidate
+        float MH = hi_c, ML = lo_c;
+        wave_maxmin(MH, ML);
+        const int fh = __ffsll((long long)__ballot(hi_c == MH)) - 1;
+        const int fl = __ffsll((long long)__ballot(lo_c == ML)) - 1;
+        if (e < Eh) { Sh -= fsqrt(ML); ch -= (lane == fl) ? 1 : 0; }
+        if (e < El) { Sl -= fsqrt(MH); cl -= (lane == fh) ? 1 : 0; }
+      }
+      spk = Sh; svl = Sl;
+      return;
+    }
+  }
   spk = 0.f; svl = 0.f;
   for (int it = 0; it < k; ++it) {
     float MH = MHl, ML = MLl;
