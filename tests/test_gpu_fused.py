@@ -195,6 +195,31 @@ def test_spectral_contrast_matches_oracle(ops, clips):
     assert unsure <= 0.10 * cells           # (measured: 5 %; a gate that excluded most cells would prove nothing)
 
 
+def test_spectral_contrast_tail_selection_cases(ops):
+    """The wide band's tails are taken by selection (k-th largest lane maximum, count, sum, take back the extras) with a
+    fall-back to k extraction rounds when too many values tie at the threshold: clips that drive both ways -- noise (two
+    or three extras), an impulse (flat spectrum: every bin ties), silence, a tone over a noise floor, a step."""
+    from sygnals_amd import _tables as T
+    rng = np.random.default_rng(77)
+    L = 48000
+    t = np.arange(L) / 48000.0
+    imp = np.zeros(L); imp[5 * 512 + 1024] = 1.0
+    step = np.zeros(L); step[L // 2:] = 0.5
+    K = np.stack([rng.normal(0, 0.3, L), imp, np.zeros(L), np.sin(2 * np.pi * 9000.0 * t) + rng.normal(0, 1e-4, L), step,
+                  rng.normal(0, 1.0, L) * np.linspace(0, 1, L)]).astype(np.float32)
+    fr = O.fft_frequencies(48000, 2048)
+    plan = T.contrast_plan(fr, 48000)
+    _, _, pv_dev = ops.stft2048_mel(ops.to_device_f32(K), 48000, n_mels=40, contrast=plan)
+    pv = pv_dev.cpu().numpy()
+    for i in range(K.shape[0]):
+        S = np.abs(O.stft(K[i].astype(np.float64), 2048, 512))
+        atol = TOL * max(S.max(), 1e-30)
+        for k, (bins, kk) in enumerate(O.contrast_bands(fr, 48000)):
+            srt = np.sort(S[bins], axis=0)
+            assert np.abs(pv[i, 1, k] - srt[:kk].mean(axis=0)).max() <= atol, f"clip {i} valley band {k}"
+            assert np.abs(pv[i, 0, k] - srt[-kk:].mean(axis=0)).max() <= atol, f"clip {i} peak band {k}"
+
+
 def test_large_batch_consistency(ops):
     """Full C2 batch size: every clip of a 1024-clip batch equals the same clip run alone
     (size-independent property; the oracle is only run on a sample)."""
