@@ -1020,14 +1020,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         const float2 v2 = reinterpret_cast<const float2*>(pq)[i];
         bq[2 * i] = v2.x; bq[2 * i + 1] = v2.y;
       }
-      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      // two accumulators (even / odd positions): consecutive matrix instructions do not wait for each other
+      v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NPRE; ++q) {
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].x, bq[4 * q + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].y, bq[4 * q + 1], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].y, bq[4 * q + 1], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].z, bq[4 * q + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].w, bq[4 * q + 3], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(apre[q].w, bq[4 * q + 3], acc2, 0, 0, 0);
       }
+      acc += acc2;
       for (int q = NPRE; q < ng; ++q) {       // (filterbanks whose chunks are longer than 28 row positions)
         const float4 a4 = wp4[q * 64];
         const float* pb = pq + 4 * q;
