@@ -306,17 +306,24 @@ void host_step(const double* sos5, int S, double* z, double x) {
 }
 
 // A^n (row-major D x D in a MAXD-strided array) by repeated multiplication; n <= CS
-void mat_pow(const double* A1, int D, int n, double* out) {
-  double R[MAXD * MAXD] = {0}, T[MAXD * MAXD];
-  for (int i = 0; i < D; ++i) R[i * MAXD + i] = 1.0;
-  for (int it = 0; it < n; ++it) {
+void mat_pow(const double* A1, int D, int n, double* out) {     // square and multiply (n <= 256: at most 16 products)
+  double R[MAXD * MAXD] = {0}, Bm[MAXD * MAXD] = {0}, T[MAXD * MAXD];
+  auto mul = [&](const double* X, const double* Y, double* Z) {  // Z = X Y (Z may alias X or Y)
     for (int i = 0; i < D; ++i)
       for (int j = 0; j < D; ++j) {
         double acc = 0.0;
-        for (int k = 0; k < D; ++k) acc += A1[i * MAXD + k] * R[k * MAXD + j];
+        for (int k = 0; k < D; ++k) acc += X[i * MAXD + k] * Y[k * MAXD + j];
         T[i * MAXD + j] = acc;
       }
-    for (int i = 0; i < MAXD * MAXD; ++i) R[i] = T[i];
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) Z[i * MAXD + j] = T[i * MAXD + j];
+  };
+  for (int i = 0; i < D; ++i) R[i * MAXD + i] = 1.0;
+  for (int i = 0; i < D; ++i)
+    for (int j = 0; j < D; ++j) Bm[i * MAXD + j] = A1[i * MAXD + j];
+  for (int e = n; e > 0; e >>= 1) {
+    if (e & 1) mul(R, Bm, R);
+    if (e > 1) mul(Bm, Bm, Bm);
   }
   for (int i = 0; i < MAXD * MAXD; ++i) out[i] = R[i];
 }
