@@ -10,6 +10,10 @@ when the timed region starts.  One step = one pass of the hot path over the batc
     python bench.py --gpus N --steps K --warmup W [--config c2|c4] [--prewarm P]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both shapes work for N > 1: started plainly (no WORLD_SIZE in the environment), the parent -- which never touches the
+GPU -- times the CPU baseline, then starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a fresh
+child process, hands it the baseline through the environment, relays rank 0's JSON line and the child's return code.
+
 `--config c4` (BASELINE.json configs[3]): per GPU 2048 clips, MFCC + spectral centroid + rolloff + contrast packed
 to one [2048, 22, 94] block per step, gathered to rank 0.
 
@@ -73,7 +77,7 @@ def cpu_baseline(target_seconds=10.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))          # a 1-GPU box's CPU share is 16 cores
+    cores = max(1, min(avail, 16))          # a 1-GPU box's CPU share is 16 cores (the box's own count is reported too)
     _cpu_worker((1, 4))                       # warm-up (imports, FFT plan caches)
     probe = _cpu_worker((2, 16))
     per_clip = probe / 16
@@ -87,7 +91,28 @@ def cpu_baseline(target_seconds=10.0):
     return {"value": round(clips * L / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"{clips} clips x 1 s @ 48 kHz (same recipe/config as the C2 GPU workload), float64 oracle, "
                       f"one clip per call, {cores} processes x 1 thread, {wall:.1f} s wall",
-            "single_core_value": round(L / per_clip / 1e6, 3)}
+            "single_core_value": round(L / per_clip / 1e6, 3), "cores_available": avail}
+
+
+CPU_ENV = "SYG_BENCH_CPU_BASELINE"
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process (which makes no GPU call,
+    so the children start on an untouched device) times the CPU baseline, then runs one rank per GPU under
+    torch.distributed.run as a child process and relays its output and return code."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    if not a.no_cpu_baseline and not env.get(CPU_ENV):
+        env[CPU_ENV] = json.dumps(cpu_baseline())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def mfma_flops_per_launch(ops, B):
@@ -115,17 +140,21 @@ def main():
                     help="N > 1, opt-in: leave this many CUs to RCCL (two-launch form, capped p2p channels)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))             # plain `python bench.py --gpus N`: start the ranks ourselves
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
-        a.gpus = world
+    a.gpus = world
 
+    # CPU baseline: on rank 0, before any GPU initialisation (forks workers); a launching parent has already timed it
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline()                  # before any GPU initialisation (forks workers)
+    if rank == 0 and not a.no_cpu_baseline:
+        if os.environ.get(CPU_ENV):
+            cpu = json.loads(os.environ[CPU_ENV])
+        else:
+            cpu = cpu_baseline()
 
     import torch
     import torch.distributed as dist
@@ -136,8 +165,13 @@ def main():
     # rehearsal on a 1-GPU box: SYG_BENCH_SAME_GPU=1 puts every rank on cuda:0 and exchanges through gloo
     # (RCCL refuses two ranks on one device); the real multi-GPU run uses one GPU per rank over RCCL
     same_gpu = os.environ.get("SYG_BENCH_SAME_GPU") == "1"
+    # SYG_BENCH_DRY=1 (tests/test_bench_launcher.py, no GPU): rehearses the launcher, the rendezvous, the gather and the
+    # JSON line with an all-zero stand-in for the kernels; the line says so and carries no measurement
+    dry = os.environ.get("SYG_BENCH_DRY") == "1"
+    same_gpu = same_gpu or dry
     dev_index = 0 if same_gpu else local_rank
-    torch.cuda.set_device(dev_index)
+    if not dry:
+        torch.cuda.set_device(dev_index)
     reserve = a.reserve_cus if world > 1 else 0
     if world > 1:
         if reserve > 0:
@@ -156,12 +190,17 @@ def main():
     cfgc = CONFIGS[a.config]
     B = a.clips or cfgc["clips"]
     rows = cfgc["rows"]
-    base = synth_clips(64, L, SR, seed=20250523 + rank)          # 64 distinct clips, tiled to the batch
-    y = ops.to_device_f32(np.tile(base, (B // 64 + 1, 1))[:B])
     n_total = B * world
     one_launch = reserve == 0
+    if not dry:
+        base = synth_clips(64, L, SR, seed=20250523 + rank)          # 64 distinct clips, tiled to the batch
+        y = ops.to_device_f32(np.tile(base, (B // 64 + 1, 1))[:B])
 
-    if a.config == "c2":
+    if dry:
+        zero = torch.zeros((B, rows, T_FRAMES), dtype=torch.float32)
+        def compute():
+            return zero
+    elif a.config == "c2":
         def compute():
             return ops.mfcc_batch(y, SR, N_FFT, HOP, N_MELS, N_MFCC, fused=None if one_launch else False)
     else:
@@ -180,33 +219,47 @@ def main():
             gat.start(out.cpu() if same_gpu else out)
         return out
 
+    def dev_sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     def sync():
         if world > 1:
             gat.finish()
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
 
-    for _ in range(a.prewarm):                         # clock pre-warm: compute only, untimed, reported
-        compute()
+    def timed(steps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # the driver's protocol exactly (W warm-up steps, K timed steps), before the clock pre-warm: reported beside `value`
+    # as `no_prewarm` (on a GPU coming from idle the first ~150 launches run at a lower clock)
     for _ in range(a.warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed_cold = timed(a.steps) if a.prewarm > 0 else None
+    for _ in range(a.prewarm):                         # clock pre-warm: compute only, untimed, reported
+        compute()
+    if a.prewarm > 0:
+        for _ in range(a.warmup):
+            step()
+    elapsed = timed(a.steps)
 
     # dominant kernel: HIP events on the stream it is launched on, back-to-back launches (steady clock: the timed
     # steps above have just run); the average includes the ~2 us dispatch gap, rocprofv3's per-dispatch average does not
     roof = None
-    if rank == 0:
+    if rank == 0 and not dry:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = max(10, min(a.steps, 100))
         if a.config == "c2" and one_launch:
@@ -263,11 +316,17 @@ def main():
         if world > 1:
             par += (", asynchronous RCCL gather to rank 0 in the timed region" +
                     (f", two-launch form on all but {reserve} CUs" if reserve else ", same kernels as N = 1"))
+        if dry:
+            value = 0.0
         line = {
             "metric": "Msamples/s STFT->MFCC (n_fft=2048, hop=512)", "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_steps": a.prewarm,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not dry else "DRY RUN: launcher rehearsal without a GPU, zeros instead of kernels, no measurement",
+            "no_prewarm": None if elapsed_cold is None else {
+                "value": round(samples / elapsed_cold / 1e6, 1), "ms_per_step": round(elapsed_cold / a.steps * 1e3, 4),
+                "note": "the same W warm-up + K timed steps run BEFORE the clock pre-warm"},
             "config": {"workload": workload, "clips_per_gpu": B, "clip_samples": L, "sr": SR, "n_fft": N_FFT, "hop": HOP,
                        "n_mels": N_MELS, "n_mfcc": N_MFCC, "rows_per_clip": rows, "parallelism": par},
             "hbm_roofline_frac_whole_step": round(job_bytes / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),

@@ -77,6 +77,7 @@ def mel_filterbank(sr: float, n_fft: int, n_mels: int = 128, fmin: float = 0.0, 
 
 
 MEL_MIN_STEPS = 28      # the kernel issues 7 groups of 4 MFMA steps unconditionally
+MEL_MAX_STEPS = 1088    # positions of one skewed power row (P_STRIDE 1090, a multiple of 4 below it)
 
 
 def row_pos(k):
@@ -121,9 +122,16 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
         p, pe = row_pos(a) & ~1, row_pos(b - 1) + 1          # even start: the kernel reads two positions per LDS word pair
         return [(q, min(q + steps, pe)) for q in range(p, pe, steps)]
 
+    # every non-empty group needs a slot of its own whatever the chunk length; positions per slot are bounded by a row
+    n_nonempty = sum(1 for a, b in rng if b > a)
+    if n_nonempty > nslots:
+        raise ValueError(f"filterbank has {n_nonempty} non-empty groups of four mel rows, a {waves}-wave plan holds "
+                         f"{nslots} slots (n_mels <= {4 * nslots} at most): use the dense filterbank path")
     steps = MEL_MIN_STEPS
     while sum(len(chunks_of(a, b, steps)) for a, b in rng) > nslots:
         steps += 4
+        if steps > MEL_MAX_STEPS:
+            raise ValueError(f"filterbank does not fit {nslots} slots of at most {MEL_MAX_STEPS} row positions")
     slot_p0 = np.zeros(64, np.int32); slot_g = -np.ones(64, np.int32)
     g_first = np.zeros(64, np.int32); g_cnt = np.zeros(64, np.int32)
     wts = np.zeros((nslots, steps, 4), np.float32)             # [slot][step][row]

@@ -41,7 +41,7 @@ class FeatureExtractionError(Exception):
 
 def mel_power_batch(y, sr, n_fft, hop, center, window, n_mels, fmin, fmax, power=2.0, win_length=None):
     """[B, L] device clips -> mel spectrogram [B, n_mels, T] of |STFT|^power."""
-    if n_fft == 2048 and power == 2.0 and n_mels <= 256:
+    if power == 2.0 and ops.fused_mel_ok(sr, n_fft, n_mels, fmin, fmax):
         mel, _, _ = ops.stft2048_mel(y, sr, hop, center, window, 2048 if win_length is None else win_length,
                                      n_mels, fmin, fmax)
         return mel
@@ -135,7 +135,7 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
             if want_contrast:
                 cplan = T.contrast_plan(freqs, sr, cp.get("n_bands", 6), cp.get("fmin", 200.0), cp.get("quantile", 0.02))
             mel = stats = cpv = None
-            if frame_length == 2048 and power == 2.0 and n_mels <= 256:
+            if power == 2.0 and ops.fused_mel_ok(sr, frame_length, n_mels if want_mfcc else 16, fmin, fmax):
                 mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
                                                    fmin, fmax, want_stats, roll, bw_p, cplan)
                 t_stft = Tn

@@ -41,11 +41,17 @@
 #define SETPRIO(n)
 #endif
 #if SYG_ABL == 9
+// -DSYG_TICK_NOVM: the stamps do not drain vector memory (the DMA / store waits then show up where the product waits)
+#ifdef SYG_TICK_NOVM
+#define SYG_TICK_WAIT "s_waitcnt lgkmcnt(0)"
+#else
+#define SYG_TICK_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#endif
 // timeline mode: per-wave cycle accumulators per phase, dumped into stats_out (tools/timeline.py)
 #define TICK(slot, reg)                                                                                         \
   do {                                                                                                          \
     unsigned long long _t;                                                                                      \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t), "+v"(reg)::"memory"); \
+    asm volatile(SYG_TICK_WAIT "\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t), "+v"(reg)::"memory"); \
     tacc[slot] += _t - tprev;                                                                                   \
     tprev = _t;                                                                                                 \
   } while (0)
@@ -153,7 +159,8 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
 // NPF > 0: the first NPF 16-byte groups of the wave's filterbank operands (pf_src, 64 float4 apart) are requested
 // behind pass 3 -- the transform's register peak is over there -- so that their L2 latency hides behind the real split
 // and the row stores instead of standing in front of barrier A.
-template <int NPF>
+// PD: priority drop (MODE 1 keeps the top level for its row functions, the transform then runs one level lower)
+template <int NPF, int PD = 0>
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
                                              const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
                                              int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512,
@@ -204,7 +211,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   }
   TICK(2, t[0].x);
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
-  SETPRIO(2);
+  SETPRIO(2 - PD > 0 ? 2 - PD : 0);
   dft16(t);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
@@ -248,7 +255,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
 #endif
   }
   TICK(4, G[0][0].x);
-  SETPRIO(1);
+  SETPRIO(1 - PD > 0 ? 1 - PD : 0);
   if (NPF > 0) {
     int lp = lane;                     // laundered: the loads may not be hoisted above this point (register peak)
     asm volatile("" : "+v"(lp));
@@ -373,96 +380,121 @@ typedef __attribute__((address_space(1))) float* gptr;
 
 // smask bits: 1 centroid, 2 bandwidth, 4 flatness, 8 rolloff, 16 dominant (only the requested rows are
 // computed and written; MAG_SUM / POWER_SUM / margin ride along with centroid / rolloff)
-__device__ __noinline__ void row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask,
-                                       gptr out, int ostride) {
-  // lane owns the 16 contiguous bins [16 lane, 16 lane + 16) -- 16 consecutive words at 17 lane of the skewed
-  // row: immediate offsets, no bank conflicts -- and lane 63 also the Nyquist bin 1024 (lanes < 63: p = 0, with
-  // k = 1024 all the same).  Every pass re-reads its powers from LDS (the lane offset is laundered so that the
-  // loads are not merged into one register array): the function then stays inside the caller-saved registers
-  // -- an out-of-line function that needs more must save and restore the rest through scratch on every call.
-  constexpr int CH = 17;
-  const int b0 = lane * 16;
+// Returns the statistics in the lanes of one register: lane SYG_STAT_x holds row x (every value is wave-uniform when it
+// is formed, so any lane can keep it).  The function does NOT store: a later out-of-line call would wait for the stores
+// at its entry (s_waitcnt vmcnt(0)), the caller writes the rows behind its last call (stats_row_mask() says which).
+__device__ __forceinline__ int stats_row_mask(int smask) {
+  return ((smask & 1) ? (1 << SYG_STAT_CENTROID) | (1 << SYG_STAT_MAG_SUM) : 0) | ((smask & 2) ? (1 << SYG_STAT_BANDWIDTH) : 0) |
+         ((smask & 4) ? (1 << SYG_STAT_FLATNESS) : 0) | ((smask & 16) ? (1 << SYG_STAT_DOMINANT_BIN) : 0) |
+         ((smask & 8) ? (1 << SYG_STAT_ROLLOFF_BIN) | (1 << SYG_STAT_POWER_SUM) | (1 << SYG_STAT_ROLLOFF_MARGIN) : 0);
+}
+__device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
+  float res = 0.f;
+#define SYG_PUT(row, val) res = (lane == (row)) ? (val) : res
+  // lane owns the 16 contiguous bins [16 lane, 16 lane + 16) -- 16 consecutive words at 17 lane of the skewed row:
+  // immediate offsets, no bank conflicts -- and lane 63 also the Nyquist bin 1024 as a 17th value (0 in the other
+  // lanes).  The powers are read ONCE and every statistic works on the registers (round 2 re-read the row per pass to
+  // stay inside the caller-saved registers; 17 + 17 values still do).
   const float EPS = 2.220446049250313e-16f;
-#define SYG_ROW_PASS(body)                                                        \
-  {                                                                               \
-    int lb = lane;                                                                \
-    asm volatile("" : "+v"(lb));                                                  \
-    lds_row pr = prow + 17 * lb;                                                  \
-    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                              \
-      const int k = (i < 16) ? b0 + i : NBIN - 1;                                 \
-      const bool in = (i < 16) || lb == 63;                                       \
-      const float p = (i < 16) ? pr[i] : (lb == 63 ? prow[ppos(NBIN - 1)] : 0.f); \
-      body                                                                        \
-    }                                                                             \
+  const bool last = (lane == 63);
+  float p[17];
+  {
+    lds_row pr = prow + 17 * lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p[i] = pr[i];
+    const float nyq = pr[17];                      // ppos(1024) = 17 * 63 + 17 for lane 63 (inside the row's slack elsewhere)
+    p[16] = last ? nyq : 0.f;
   }
   float psum = 0.f;
-  SYG_ROW_PASS(psum += p;)
+#pragma unroll
+  for (int i = 0; i < 17; ++i) psum += p[i];
   const float tot_p = wave_sum(psum);
+  const float kb = (float)(16 * lane);
   float tot_m = 0.f, cen_bin = 0.f;
   bool live = false;
   if (smask & (1 | 2 | 4)) {        // magnitude sums
-    float msum = 0.f, fsum = 0.f;
-    SYG_ROW_PASS(const float m = fsqrt(p); msum += m; fsum = fmaf(m, (float)k, fsum);)
+    float m[17];
+    float msum = 0.f, fl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+      m[i] = fsqrt(p[i]);
+      msum += m[i];
+      fl = fmaf(m[i], (float)i, fl);               // sum m (k - 16 lane): the lane's base enters once below
+    }
     tot_m = wave_sum(msum);
     live = tot_m >= EPS;
-    const float tot_f = wave_sum(fsum);
+    const float tot_f = wave_sum(fmaf(kb, msum, fl));
     cen_bin = live ? tot_f * frcp(tot_m) : 0.f;
-    if (lane == 0 && (smask & 1)) {
-      out[SYG_STAT_CENTROID * ostride] = cen_bin * binhz;
-      out[SYG_STAT_MAG_SUM * ostride] = tot_m;
+    SYG_PUT(SYG_STAT_CENTROID, cen_bin * binhz);
+    SYG_PUT(SYG_STAT_MAG_SUM, tot_m);
+    if (smask & 4) {    // flatness: exp(mean log(m + eps)) / mean(m)
+      float lsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lsum += __builtin_amdgcn_logf(m[i] + EPS);
+      const float l16 = __builtin_amdgcn_logf(m[16] + EPS);
+      lsum += last ? l16 : 0.f;
+      const float tot_l = wave_sum(lsum) * 0.69314718055994531f;
+      const float am = tot_m * (1.f / (float)NBIN);
+      SYG_PUT(SYG_STAT_FLATNESS, (am >= EPS) ? fminf(fmaxf(fexp(tot_l * (1.f / (float)NBIN)) * frcp(am), 0.f), 1.f) : 0.f);
+    }
+    if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p);  (m[16] = 0 outside lane 63)
+      const int pmode = (bw_p == 2.f) ? 2 : (bw_p == 1.f) ? 1 : 0;
+      const float d0 = kb - cen_bin;
+      float dsum = 0.f;
+      if (pmode == 2) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) { const float d = (d0 + (float)i) * binhz; dsum = fmaf(m[i], d * d, dsum); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+          const float d = fabsf(d0 + (float)i) * binhz;
+          dsum = fmaf(m[i], pmode == 1 ? d : fpow(d, bw_p), dsum);
+        }
+      }
+      const float tot_d = wave_sum(dsum);
+      const float r = live ? fmaxf(tot_d * frcp(tot_m), 0.f) : 0.f;
+      SYG_PUT(SYG_STAT_BANDWIDTH, pmode == 2 ? fsqrt(r) : pmode == 1 ? r : fpow(r, frcp(bw_p)));
     }
   }
   if (smask & 16) {   // argmax of the magnitude == argmax of the power (first occurrence)
-    float pmax = -1.f;
+    float pmax = p[0];
     int amax = 0;
-    SYG_ROW_PASS(const bool up = in && p > pmax; pmax = up ? p : pmax; amax = up ? k : amax;)
+#pragma unroll
+    for (int i = 1; i < 17; ++i) {
+      const bool up = (i < 16 || last) && p[i] > pmax;
+      pmax = up ? p[i] : pmax; amax = up ? i : amax;
+    }
     const float gm = wave_max(pmax);
-    const int cand = wave_min_i((pmax == gm) ? amax : 0x7fffffff);
-    if (lane == 0) out[SYG_STAT_DOMINANT_BIN * ostride] = (float)cand;
-  }
-  if (smask & 4) {    // flatness: exp(mean log(m + eps)) / mean(m)
-    float lsum = 0.f;
-    SYG_ROW_PASS(const float lg = flog(fsqrt(p) + EPS); lsum += in ? lg : 0.f;)
-    const float tot_l = wave_sum(lsum);
-    if (lane == 0) {
-      const float am = tot_m * (1.f / (float)NBIN);
-      out[SYG_STAT_FLATNESS * ostride] =
-          (am >= EPS) ? fminf(fmaxf(fexp(tot_l * (1.f / (float)NBIN)) * frcp(am), 0.f), 1.f) : 0.f;
-    }
-  }
-  if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p);  bins >= NBIN hold p = 0
-    const int pmode = (bw_p == 2.f) ? 2 : (bw_p == 1.f) ? 1 : 0;
-    float dsum = 0.f;
-    if (pmode == 2) {
-      SYG_ROW_PASS(const float d = ((float)k - cen_bin) * binhz; dsum = fmaf(fsqrt(p), d * d, dsum);)
-    } else {
-      SYG_ROW_PASS(const float d = fabsf((float)k - cen_bin) * binhz;
-                   dsum = fmaf(fsqrt(p), pmode == 1 ? d : fpow(d, bw_p), dsum);)
-    }
-    const float tot_d = wave_sum(dsum);
-    if (lane == 0) {
-      const float r = live ? fmaxf(tot_d * frcp(tot_m), 0.f) : 0.f;
-      out[SYG_STAT_BANDWIDTH * ostride] = pmode == 2 ? fsqrt(r) : pmode == 1 ? r : fpow(r, frcp(bw_p));
-    }
+    const int cand = wave_min_i((pmax == gm) ? 16 * lane + amax : 0x7fffffff);
+    SYG_PUT(SYG_STAT_DOMINANT_BIN, (float)cand);
   }
   if (smask & 8) {    // rolloff: first bin with cumsum(power) >= roll * total
+    // The running sum never decreases (powers are >= 0), so the number of a lane's sums below the threshold IS the
+    // position of its first hit; the decision margin is the distance of the threshold to the nearest running sum on
+    // either side (the sum in front of bin 0 excepted).
     const float thr = roll_percent * tot_p;
-    int rb = 0x7fffffff;
-    float margin = 3.4e38f;
     float c = wave_excl_scan(psum, lane);
-    SYG_ROW_PASS(const float cprev = c; c += p; const bool hit = in && (c >= thr) && (rb == 0x7fffffff);
-                 rb = hit ? k : rb;
-                 margin = hit ? fminf(c - thr, (k > 0) ? thr - cprev : 3.4e38f) : margin;)
-    int rbmin = wave_min_i(rb);
-    const float mg = wave_min((rb == rbmin && rb != 0x7fffffff) ? margin : 3.4e38f);
-    if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
-    if (lane == 0) {
-      out[SYG_STAT_ROLLOFF_BIN * ostride] = (float)rbmin;
-      out[SYG_STAT_POWER_SUM * ostride] = tot_p;
-      out[SYG_STAT_ROLLOFF_MARGIN * ostride] = (tot_p > 0.f) ? mg * frcp(tot_p) : 0.f;
+    float mg = (lane > 0) ? fabsf(c - thr) : 3.4e38f;
+    int below = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      c += p[i];
+      below += (c < thr) ? 1 : 0;
+      mg = fminf(mg, fabsf(c - thr));
     }
+    c += p[16];
+    below += (last && c < thr) ? 1 : 0;
+    mg = fminf(mg, fabsf(c - thr));
+    const int rb = (below < (last ? 17 : 16)) ? 16 * lane + below : 0x7fffffff;
+    int rbmin = wave_min_i(rb);
+    const float mgw = wave_min(mg);
+    if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
+    SYG_PUT(SYG_STAT_ROLLOFF_BIN, (float)rbmin);
+    SYG_PUT(SYG_STAT_POWER_SUM, tot_p);
+    SYG_PUT(SYG_STAT_ROLLOFF_MARGIN, (tot_p > 0.f) ? mgw * frcp(tot_p) : 0.f);
   }
-#undef SYG_ROW_PASS
+#undef SYG_PUT
+  return res;
 }
 
 // k-th order statistic of the powers of bins [lo, lo + n) by a 32-step radix select on the float bit patterns
@@ -488,11 +520,15 @@ __device__ __noinline__ uint32_t row_kth(lds_row prow, int lane, int lo, int n, 
 // the kk-th largest over the lanes of two 32-bit values per lane (two independent selections in one loop): bisection
 // from the top bit, per bit and value one vector compare and a scalar popcount.  kk is made scalar here (it arrives in
 // a vector register when the caller is an out-of-line function): thresholds and counts then live on the scalar unit.
+// Only bits 31 .. LOWBIT are decided: the result is the k-th largest ROUNDED DOWN to that precision -- still a value
+// with at least kk lane values at or above it, which is all the selection below needs (a lower threshold only lets a
+// few more candidates through).
+template <int LOWBIT>
 __device__ __forceinline__ void wave_kth_largest2_u32(uint32_t x, uint32_t y, int kk, uint32_t& tx, uint32_t& ty) {
   const int ks = __builtin_amdgcn_readfirstlane(kk);
   uint32_t a = 0, b = 0;
 #pragma unroll 4
-  for (int bit = 31; bit >= 0; --bit) {
+  for (int bit = 31; bit >= LOWBIT; --bit) {
     const uint32_t ca = a | (1u << bit), cb = b | (1u << bit);
     const int na = __popcll(__ballot(x >= ca)), nb = __popcll(__ballot(y >= cb));
     a = (na >= ks) ? ca : a;
@@ -576,14 +612,17 @@ __device__ __forceinline__ void contrast_extract_lds(lds_row prow, int lane, int
   typedef __attribute__((address_space(3))) float* lds_wrow;
   lds_wrow wrow = (lds_wrow)prow;
   float v[R];
-  int nv = 0;                                     // valid values of this lane
+  // bin lo + lane + 64 r sits at ppos(lo + lane) + 68 r (64 r / 16 = 4 r pad words, no carry): one base, immediate
+  // offsets.  Lanes past the band's end read on (still inside the LDS allocation) and are replaced by the pad.
+  lds_row pr = prow + ppos(lo + lane);
+  const int nrem = n - lane;                      // this lane holds the values r with 64 r < nrem
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = r * 64 + lane;
-    const float p = prow[ppos(lo + (i < n ? i : 0))];
-    v[r] = (i < n) ? p : 3.4e38f;                 // pads sort to the top of the list and are never a head
-    nv += (i < n) ? 1 : 0;
+    const float p = pr[68 * r];
+    v[r] = (64 * r < nrem) ? p : 3.4e38f;         // pads sort to the top of the list and are never a head
   }
+  const int nvu = (nrem + 63) >> 6;
+  const int nv = nvu < 0 ? 0 : (nvu > R ? R : nvu);   // valid values of this lane
 #pragma unroll
   for (int c = 0; c < SortNet<R>::N; ++c) {
     constexpr auto& P = SortNet<R>::P;
@@ -604,7 +643,8 @@ __device__ __forceinline__ void contrast_extract_lds(lds_row prow, int lane, int
   // T by bisection on the bit patterns (non-negative floats order like their bits): 32 compares + scalar popcounts.
   if (k >= 8 && n >= 64) {                      // (wave-uniform; every lane holds at least one value)
     uint32_t Tu, Bu;                              // Bu: k-th smallest of the lane minima = ~(k-th largest of their complements)
-    wave_kth_largest2_u32(__float_as_uint(MHl), ~__float_as_uint(MLl), k, Tu, Bu);
+    // 16 of the 32 bits (sign, exponent, 7 mantissa bits: the threshold is within 1 % of the exact order statistic)
+    wave_kth_largest2_u32<16>(__float_as_uint(MHl), ~__float_as_uint(MLl), k, Tu, Bu);
     Bu = ~Bu;
     const float Th = __uint_as_float(Tu), Tl = __uint_as_float(Bu);
     int ch = nv - R, cl = 0;                      // (the pads, +huge, count as >= Th: taken off up front)
@@ -654,6 +694,70 @@ __device__ __forceinline__ void contrast_extract_lds(lds_row prow, int lane, int
   }
 }
 
+// k = 1: the band's largest and smallest power.  Lanes past the band's end re-read its last bin (a duplicate changes
+// neither extreme): no masks.
+__device__ __forceinline__ void contrast_minmax(lds_row prow, int lane, int lo, int n, float& spk, float& svl) {
+  float hi = 0.f, lw = 3.4e38f;
+  for (int r0 = 0; r0 < n; r0 += 64) {
+    const int i = r0 + lane;
+    const float p = prow[ppos(lo + (i < n ? i : n - 1))];
+    hi = fmaxf(hi, p);
+    lw = fminf(lw, p);
+  }
+  wave_maxmin(hi, lw);
+  spk = fsqrt(hi); svl = fsqrt(lw);
+}
+
+// k <= 3 on bands of up to 192 bins: every lane sorts its (up to) three values, then the sorted triples are merged over
+// the wave by a DPP butterfly -- the three largest of the union of two descending triples a, b are
+//   c1 = max(a1, b1)   c2 = max(a2, b2, min(a1, b1))   c3 = max(a3, b3, min(a2, b1), min(a1, b2))
+// (and the mirror image for the three smallest): six steps of ten instructions, no scalar round trip, no loop over k.
+// A merge of a triple with ITSELF is wrong (elements would count twice): the row-broadcast steps leave garbage in the
+// rows they do not write, which no later step reads -- the result is taken from lane 63.
+template <int CTRL, int ROWMASK, bool TOP>
+__device__ __forceinline__ void merge3_step(float& a1, float& a2, float& a3) {
+  float b1, b2, b3;
+  if (ROWMASK == 0xF) { b1 = dpp_f<CTRL>(a1); b2 = dpp_f<CTRL>(a2); b3 = dpp_f<CTRL>(a3); }
+  else { b1 = dpp_rows_f<CTRL, ROWMASK>(a1); b2 = dpp_rows_f<CTRL, ROWMASK>(a2); b3 = dpp_rows_f<CTRL, ROWMASK>(a3); }
+  if (TOP) {
+    const float c3 = fmaxf(fmaxf(a3, b3), fmaxf(fminf(a2, b1), fminf(a1, b2)));
+    const float c2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
+    a1 = fmaxf(a1, b1); a2 = c2; a3 = c3;
+  } else {
+    const float c3 = fminf(fminf(a3, b3), fminf(fmaxf(a2, b1), fmaxf(a1, b2)));
+    const float c2 = fminf(fminf(a2, b2), fmaxf(a1, b1));
+    a1 = fminf(a1, b1); a2 = c2; a3 = c3;
+  }
+}
+template <bool TOP>
+__device__ __forceinline__ void wave_merge3(float& a1, float& a2, float& a3) {
+  merge3_step<DPP_QP_1032, 0xF, TOP>(a1, a2, a3);
+  merge3_step<DPP_QP_2301, 0xF, TOP>(a1, a2, a3);
+  merge3_step<DPP_ROW_HALF_MIRROR, 0xF, TOP>(a1, a2, a3);
+  merge3_step<DPP_ROW_MIRROR, 0xF, TOP>(a1, a2, a3);
+  merge3_step<DPP_ROW_BCAST15, 0xA, TOP>(a1, a2, a3);
+  merge3_step<DPP_ROW_BCAST31, 0xC, TOP>(a1, a2, a3);
+  a1 = rl_f(a1, 63); a2 = rl_f(a2, 63); a3 = rl_f(a3, 63);
+}
+__device__ __forceinline__ void contrast_top3(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
+  float t[3], u[3];                                  // descending with -1 pads / ascending with +huge pads
+  lds_row pr = prow + ppos(lo + lane);              // (bin lo + lane + 64 r at ppos(lo + lane) + 68 r)
+  const int nrem = n - lane;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float p = pr[68 * r];
+    t[r] = (64 * r < nrem) ? p : -1.f;
+    u[r] = (64 * r < nrem) ? p : 3.4e38f;
+  }
+  auto cx = [](float& hi, float& lw) { const float a = hi, b = lw; hi = fmaxf(a, b); lw = fminf(a, b); };
+  cx(t[0], t[1]); cx(t[1], t[2]); cx(t[0], t[1]);    // t0 >= t1 >= t2
+  cx(u[1], u[0]); cx(u[2], u[1]); cx(u[1], u[0]);    // u0 <= u1 <= u2
+  wave_merge3<true>(t[0], t[1], t[2]);
+  wave_merge3<false>(u[0], u[1], u[2]);
+  spk = fsqrt(t[0]) + (k >= 2 ? fsqrt(t[1]) : 0.f) + (k >= 3 ? fsqrt(t[2]) : 0.f);
+  svl = fsqrt(u[0]) + (k >= 2 ? fsqrt(u[1]) : 0.f) + (k >= 3 ? fsqrt(u[2]) : 0.f);
+}
+
 // mean of the k smallest and k largest MAGNITUDES of bins [lo, hi) of one LDS power row (identical to sorting,
 // as librosa does: values are non-negative, selection on power == selection on magnitude).
 //   bands of <= 768 bins with k <= 16 : register extraction, specialised by registers per lane;
@@ -661,11 +765,13 @@ __device__ __forceinline__ void contrast_extract_lds(lds_row prow, int lane, int
 //                                       tie count.
 // may_park: the bands come in ascending order and the row's statistics are done, so a wide band may park its sorted
 // lists in the part of the row below its own end (contrast_extract_lds)
-__device__ __noinline__ float2 row_contrast(lds_row prow, int lane, int lo, int hi, int k, int may_park) {   // (peak, valley)
+__device__ __forceinline__ float2 band_contrast(lds_row prow, int lane, int lo, int hi, int k, int may_park) {   // (peak, valley)
   const int n = hi - lo;
   if (n <= 768 && k <= 16) {
     float spk, svl;
-    if (n <= 64) contrast_extract<1>(prow, lane, lo, n, k, spk, svl);
+    if (k == 1) contrast_minmax(prow, lane, lo, n, spk, svl);
+    else if (k <= 3 && n <= 192) contrast_top3(prow, lane, lo, n, k, spk, svl);
+    else if (n <= 64) contrast_extract<1>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 128) contrast_extract<2>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 256) contrast_extract<4>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 448) contrast_extract<7>(prow, lane, lo, n, k, spk, svl);
@@ -706,6 +812,25 @@ __device__ __forceinline__ MfccArgs uni(const MfccArgs& a) {
   u.ref_is_max = uni(a.ref_is_max); u.ref_value = uni(a.ref_value); u.amin = uni(a.amin); u.top_db = uni(a.top_db);
   u.tp = uni(a.tp);
   return u;
+}
+
+// All contrast bands of one row in ONE out-of-line call (a call per band paid the entry / exit sequence and the
+// argument traffic seven times).  Band r's (peak, valley) tail means come back in lane r of the two result registers;
+// the caller stores them.  The plan (lo, hi, k per band) is read from its LDS copy: one read per array, lane = band.
+typedef const __attribute__((address_space(3))) int* lds_iptr;
+__device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
+  const int n_rows = uni(n_rows_v), may_park = uni(may_park_v);
+  const int lb = lane & (SYG_MAX_BANDS - 1);
+  const int plo = cpl[lb], phi = cpl[SYG_MAX_BANDS + lb], pk = cpl[2 * SYG_MAX_BANDS + lb];
+  float rp = 0.f, rv = 0.f;
+  for (int r = 0; r < n_rows; ++r) {
+    const int lo = __builtin_amdgcn_readlane(plo, r), hi = __builtin_amdgcn_readlane(phi, r),
+              k = __builtin_amdgcn_readlane(pk, r);
+    const float2 pv = band_contrast(prow, lane, lo, hi, k, may_park);
+    rp = (lane == r) ? pv.x : rp;
+    rv = (lane == r) ? pv.y : rv;
+  }
+  return make_float2(rp, rv);
 }
 
 // MODE 3 clip epilogue (a workgroup's chunk is whole clips): power_to_db + DCT-II (+ lifter) from the LDS mel
@@ -907,7 +1032,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const int64_t t0 = t0_of(tile, cq);
     const int64_t t = t0 + w;
     if (LOAD != 2) fetch(tile);
-    SETPRIO(3);
+    // MODE 1: the row functions behind barrier B are chains of dependent wave-level steps that hide their latency only
+    // behind each other; a wave that is through starts its next transform, whose dense vector work would take the
+    // issue slots from the waves still in their row functions (oldest wave first at equal priority) and stretch the
+    // tile.  The row functions therefore run at the top level and the transform one level lower (SYG_TAILPRIO = 1;
+    // 0: all equal -- measured 428 vs 373-390 us per 1024 clips of C4; 2-4: other splits, no better).
+#ifndef SYG_TAILPRIO
+#define SYG_TAILPRIO 1
+#endif
+    constexpr int PD = (MODE == 1) ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0) : 0;
+    SETPRIO(3 - PD > 0 ? 3 - PD : 0);
     // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT needs
     // all 128 VGPRs): the first NPRE groups of four steps are re-fetched every tile, behind pass 3 of the transform.
     constexpr int NPRE = 7;            // unconditional: every wave's segment holds >= NPRE groups (zero padded)
@@ -936,7 +1070,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
       TICK(0, v[0].x);
       float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre TPASS);
+      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY, PD>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre TPASS);
       if (COMPLEX_OUT) {
         float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll
@@ -1058,18 +1192,25 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     __syncthreads();                // barrier B: slab complete (and every wave has read its staged frame)
     TICK(8, tdep);
     const bool clip_done = (MODE == 3) && (t0 + TILE_T >= T);
-    if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
+    // MODE 1 runs out-of-line row functions below: a function entry waits for EVERY outstanding memory operation
+    // (s_waitcnt vmcnt(0) -- the callee cannot know the caller's counters), so nothing may be in flight when they are
+    // called: the refill of the stage buffer is issued behind them and the tile's stores behind the last call.
+    constexpr bool TAIL = (MODE == 1);
+    if (!TAIL && FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
 
     // ---- combine the slots of each mel group in a fixed order (ascending bins): one wave per group of four mel rows,
-    // lane = (row, frame); the slots of a group are consecutive
-    {
+    // lane = (row, frame); the slots of a group are consecutive.  (MODE 1: behind the row functions -- the slab stays
+    // valid until the next tile's projection -- so that their entry does not wait for these stores.)
+    auto combine = [&]() {
       constexpr int GL = 4 * TILE_T;               // outputs per group and tile (64 at 16 frames)
       for (int g = w; g < plan.n_groups; g += WAVES) {
         const int first = __builtin_amdgcn_readfirstlane(mtab[128 + g]);
         const int cnt = __builtin_amdgcn_readfirstlane(mtab[192 + g]);
-        if (GL == 64 || lane < GL) {
-          const int m = lane / TILE_T, tt = lane & (TILE_T - 1);
-          const float* sp = slab + first * GL + lane;
+        int lq = lane;                    // laundered (see lv above): no hoisted per-lane addresses that would spill
+        asm volatile("" : "+v"(lq));
+        if (GL == 64 || lq < GL) {
+          const int m = lq / TILE_T, tt = lq & (TILE_T - 1);
+          const float* sp = slab + first * GL + lq;
           float sum = 0.f;
           int q = 0;
           for (; q + 4 <= cnt; q += 4) {
@@ -1090,7 +1231,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           }
         }
       }
-    }
+    };
+    if (!TAIL) combine();
     if (clip_done) {
       // last tile of the clip: publish the per-wave maxima; the dB + DCT epilogue runs in the next tile's
       // projection phase (or behind the loop)
@@ -1101,29 +1243,46 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     }
 
     TICK(9, tdep);
-#if SYG_ABL == 9
-    if (false) {
-#else
     // ---- phase 2b: per-frame statistics / contrast means from the same LDS rows
     if (MODE == 1 && (stats_out != nullptr || contrast_out != nullptr)) {
-#endif
+      if (SYG_TAILPRIO == 1 || SYG_TAILPRIO == 3 || SYG_TAILPRIO == 4) SETPRIO(3);
+      if (SYG_TAILPRIO == 2) { if (w >= WAVES / 2) SETPRIO(3); else SETPRIO(2); }   // the younger half would otherwise run on leftovers
       if (t < T) {
-        if (stats_out != nullptr)
-          row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask,
-                    (gptr)(stats_out + (b * SYG_NSTAT) * T + t), (int)T);
+        // statistics first (a wide contrast band parks its lists in the row's low words); every result waits in a lane
+        // of a register and is stored behind the last call
+        float sres = 0.f, pk = 0.f, vl = 0.f;
+        // timing ablations (WRONG results): 20 = no row function is called, 21 = a trivial inline stand-in
+#if SYG_ABL == 20
+        if (false) {
+#elif SYG_ABL == 21
+        if (stats_out != nullptr) sres = wave_sum(prow[17 * lane]);
+        if (false) {
+#else
+        if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
         if (contrast_out != nullptr) {
-          for (int r = 0; r < cplan.n_rows; ++r) {
-            const float2 pv = row_contrast((lds_row)prow, lane, cpl[r], cpl[SYG_MAX_BANDS + r], cpl[2 * SYG_MAX_BANDS + r],
-                                           cplan.ascending);
-            if (lane == 0) {
-              contrast_out[((b * 2 + 0) * cplan.n_rows + r) * T + t] = pv.x;
-              contrast_out[((b * 2 + 1) * cplan.n_rows + r) * T + t] = pv.y;
-            }
+#endif
+          const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cpl, cplan.n_rows, cplan.ascending);
+          pk = pv.x; vl = pv.y;
+          if (lane < cplan.n_rows) {
+            contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = pk;
+            contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = vl;
           }
         }
+#if SYG_ABL == 9
+        if (stats_out != nullptr && sres == 12345.678f)      // (timeline build: stats_out carries the phase counters)
+#else
+        if (stats_out != nullptr && lane < SYG_NSTAT && ((stats_row_mask(smask) >> lane) & 1))
+#endif
+          stats_out[(b * SYG_NSTAT + lane) * T + t] = sres;
       }
       // (a wave only reads and -- parking sorted lists -- overwrites ITS OWN row here; every projection that read the
       // row finished before barrier B, and the row is next written by this wave's own FFT: no barrier needed)
+    }
+    if (TAIL) {
+      if (SYG_TAILPRIO != 0) SETPRIO(0);
+      TICK(11, tdep);
+      combine();
+      if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
     }
   }
   if (MODE == 3 && pend_b >= 0) {

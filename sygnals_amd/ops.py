@@ -104,13 +104,16 @@ class MelConfig:
         self.basis_host = basis
         self.n_mels = n_mels
         waves = fused_waves() if waves is None else waves
+        self.wpacked = None
+        self.plan = None
         if n_fft == 2048 and n_mels <= 256:
-            wp, plan = T.pack_mel_plan(basis, waves)
-            self.wpacked = _dev(wp)
-            self.plan = np.ascontiguousarray(plan, dtype=np.int32)
-        else:
-            self.wpacked = None
-            self.plan = None
+            try:
+                wp, plan = T.pack_mel_plan(basis, waves)
+            except ValueError:
+                pass        # more groups of four rows than the plan has slots (8-wave mode, n_mels > 128): dense path
+            else:
+                self.wpacked = _dev(wp)
+                self.plan = np.ascontiguousarray(plan, dtype=np.int32)
         self.basis = _dev(basis)
 
 
@@ -119,6 +122,12 @@ def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None, waves=None) -> MelConfig:
     waves = fused_waves() if waves is None else waves
     return _cached(("mel", float(sr), n_fft, n_mels, float(fmin), float(fmax), waves),
                    lambda: MelConfig(sr, n_fft, n_mels, fmin, fmax, waves))
+
+
+def fused_mel_ok(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> bool:
+    """True when the fused frame-length-2048 kernel has a block-sparse plan for this filterbank (n_mels <= 256, and
+    <= 128 in the 8-wave development mode); otherwise callers take the generic chain (stft_any -> mel_dense)."""
+    return n_fft == 2048 and 1 <= n_mels <= 256 and mel_config(sr, n_fft, n_mels, fmin, fmax).wpacked is not None
 
 
 def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
@@ -140,7 +149,7 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
         raise ValueError("signal too short for one frame")
     cfg = mel_config(sr, 2048, n_mels, fmin, fmax)
     if cfg.wpacked is None:
-        raise SygnalsHipError("fused path supports n_mels <= 256")
+        raise SygnalsHipError("fused path: no block-sparse plan for this filterbank (n_mels <= 256; <= 128 with 8 waves)")
     win = window_dev(window, win_length, 2048)
     tw = twiddle_dev(2048)
     mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
@@ -299,7 +308,7 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
     fused=None picks the one-launch clip-resident form when the clip's mel matrix fits in LDS and there are
     enough clips to fill the chip (a workgroup owns whole clips); True / False force either form.
     """
-    if n_fft != 2048 or n_mels > 256:
+    if not fused_mel_ok(sr, n_fft, n_mels, fmin, fmax):
         # no fused kernel for this shape: complex STFT (any frame length) -> |X|^2 -> dense mel -> dB + DCT
         if fused:
             raise SygnalsHipError(f"mfcc_batch: no fused kernel for n_fft={n_fft}, n_mels={n_mels}")

@@ -29,9 +29,12 @@ def test_mel_plan_reconstructs_dense_basis(n_mels, waves):
     """The block-sparse packing for v_mfma_f32_4x4x1_16b_f32: replaying the kernel's addressing (slot = lane >> 4, row =
     lane & 3, step i at row position p0 + i of the skewed power row) over every (wave, step, lane) rebuilds the dense
     filterbank exactly; pad positions and everything past a chunk carry zero weights."""
-    if n_mels == 256 and waves == 8:
-        pytest.skip("64 groups of four rows need at least 64 slots = 16 waves")
     W = T.mel_filterbank(48000, 2048, n_mels)
+    if n_mels == 256 and waves == 8:
+        # 64 groups of four rows need 64 slots = 16 waves: a clear error (callers then take the dense path), no hang
+        with pytest.raises(ValueError, match="non-empty groups"):
+            T.pack_mel_plan(W, waves)
+        return
     wp, plan = T.pack_mel_plan(W, waves)
     assert plan.tolist()[:2] == [2, waves] and plan.shape == (5,) and wp.dtype == np.float32
     steps, ng, toff = int(plan[2]), int(plan[3]), int(plan[4])
@@ -61,6 +64,14 @@ def test_mel_plan_reconstructs_dense_basis(n_mels, waves):
         sl = np.arange(gf[g], gf[g] + gc[g])
         assert (sg[sl] == g).all() and (np.diff(p0[sl]) == steps).all()
     assert gc[:ng].sum() == (sg >= 0).sum() <= 4 * waves
+
+
+def test_mel_plan_never_loops_when_groups_outnumber_slots():
+    """Round-2 advisor finding: with more non-empty groups than slots the step search could never succeed."""
+    for n_mels in (132, 160, 200, 256):
+        with pytest.raises(ValueError, match="non-empty groups"):
+            T.pack_mel_plan(T.mel_filterbank(48000, 2048, n_mels), 8)
+    T.pack_mel_plan(T.mel_filterbank(48000, 2048, 128), 8)          # 32 groups, 32 slots: fits
 
 
 def test_mel_plan_rejects_too_many_mels():
