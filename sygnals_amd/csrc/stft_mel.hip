@@ -758,6 +758,60 @@ __device__ __forceinline__ void contrast_top3(lds_row prow, int lane, int lo, in
   svl = fsqrt(u[0]) + (k >= 2 ? fsqrt(u[1]) : 0.f) + (k >= 3 ? fsqrt(u[2]) : 0.f);
 }
 
+// Wide bands whose last register is the only partly filled one (64 (R - 1) < n <= 64 R; C4's 751-bin band at 48 kHz,
+// the 728-bin band at 44.1 kHz: R = 12), 4 <= k <= 16: selection on STATIC registers, no parked lists, no re-reads.
+// A lane sorts its R values once (pads +huge on top); its four largest are then v[R-1 .. R-4], one register lower in
+// the lanes that hold a pad, its four smallest v[0 .. 3].  The threshold Th = k-th largest lane maximum (rounded down:
+// wave_kth_largest2_u32) has at least k values at or above it, all of them among the lanes' top values; the first
+// three of each lane are counted and summed, the few extras (count - k) are taken back smallest first, one wave-wide
+// round each.  A lane whose FOURTH value still reaches the threshold might hide a fifth: the function then reports
+// failure and the caller runs the general form (contrast_extract_lds) -- as it does for many extras (ties, constant
+// bands).  Mirror image for the k smallest.
+template <int R>
+__device__ __forceinline__ bool contrast_select(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
+  float v[R];
+  lds_row pr = prow + ppos(lo + lane);            // bin lo + lane + 64 r at ppos(lo + lane) + 68 r
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = pr[68 * r];
+  const bool hp = lane >= n - 64 * (R - 1);       // no value of this lane in the last register
+  v[R - 1] = hp ? 3.4e38f : v[R - 1];
+#pragma unroll
+  for (int c = 0; c < SortNet<R>::N; ++c) {
+    constexpr auto& P = SortNet<R>::P;
+    const int i = P[c][0], j = P[c][1];
+    const float a = v[i], b = v[j];
+    v[i] = fminf(a, b); v[j] = fmaxf(a, b);
+  }
+  const float t1 = hp ? v[R - 2] : v[R - 1], t2 = hp ? v[R - 3] : v[R - 2], t3 = hp ? v[R - 4] : v[R - 3],
+              t4 = hp ? v[R - 5] : v[R - 4];
+  const float b1 = v[0], b2 = v[1], b3 = v[2], b4 = v[3];
+  uint32_t Tu, Bu;
+  wave_kth_largest2_u32<16>(__float_as_uint(t1), ~__float_as_uint(b1), k, Tu, Bu);
+  const float Th = __uint_as_float(Tu), Tl = __uint_as_float(~Bu);
+  if (__ballot(t4 >= Th || b4 <= Tl) != 0) return false;
+  int ch = (t1 >= Th ? 1 : 0) + (t2 >= Th ? 1 : 0) + (t3 >= Th ? 1 : 0);
+  int cl = (b1 <= Tl ? 1 : 0) + (b2 <= Tl ? 1 : 0) + (b3 <= Tl ? 1 : 0);
+  const int Eh = wave_sum_i(ch) - k, El = wave_sum_i(cl) - k;
+  if (Eh > 10 || El > 10) return false;
+  const float q1 = fsqrt(t1), q2 = fsqrt(t2), q3 = fsqrt(t3), r1 = fsqrt(b1), r2 = fsqrt(b2), r3 = fsqrt(b3);
+  float Sh = wave_sum((ch >= 1 ? q1 : 0.f) + (ch >= 2 ? q2 : 0.f) + (ch >= 3 ? q3 : 0.f));
+  float Sl = wave_sum((cl >= 1 ? r1 : 0.f) + (cl >= 2 ? r2 : 0.f) + (cl >= 3 ? r3 : 0.f));
+  const int emax = Eh > El ? Eh : El;
+  for (int e = 0; e < emax; ++e) {
+    // this lane's smallest upper / largest lower candidate (as magnitudes: the order is the same)
+    const float lo_c = ch == 3 ? q3 : ch == 2 ? q2 : ch == 1 ? q1 : 3.4e38f;
+    const float hi_c = cl == 3 ? r3 : cl == 2 ? r2 : cl == 1 ? r1 : -1.f;
+    float MH = hi_c, ML = lo_c;
+    wave_maxmin(MH, ML);
+    const int fh = __ffsll((long long)__ballot(hi_c == MH)) - 1;
+    const int fl = __ffsll((long long)__ballot(lo_c == ML)) - 1;
+    if (e < Eh) { Sh -= ML; ch -= (lane == fl) ? 1 : 0; }
+    if (e < El) { Sl -= MH; cl -= (lane == fh) ? 1 : 0; }
+  }
+  spk = Sh; svl = Sl;
+  return true;
+}
+
 // mean of the k smallest and k largest MAGNITUDES of bins [lo, hi) of one LDS power row (identical to sorting,
 // as librosa does: values are non-negative, selection on power == selection on magnitude).
 //   bands of <= 768 bins with k <= 16 : register extraction, specialised by registers per lane;
@@ -775,6 +829,7 @@ __device__ __forceinline__ float2 band_contrast(lds_row prow, int lane, int lo, 
     else if (n <= 128) contrast_extract<2>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 256) contrast_extract<4>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 448) contrast_extract<7>(prow, lane, lo, n, k, spk, svl);
+    else if (n > 64 * 11 && k >= 4 && contrast_select<12>(prow, lane, lo, n, k, spk, svl)) {}
     else if (may_park && ppos(hi - 1) >= 64 * 12) contrast_extract_lds<12>(prow, lane, lo, n, k, spk, svl);
     else contrast_extract<12>(prow, lane, lo, n, k, spk, svl);
     const float rk = frcp((float)k);
