@@ -1095,7 +1095,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #ifndef SYG_TAILPRIO
 #define SYG_TAILPRIO 1
 #endif
-    constexpr int PD = (MODE == 1) ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0) : 0;
+#ifndef SYG_CPRIO
+#define SYG_CPRIO 0
+#endif
+    constexpr int PD = (MODE == 1) ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0)
+                                   : (SYG_CPRIO == 1 || SYG_CPRIO == 3) ? 1 : 0;
     SETPRIO(3 - PD > 0 ? 3 - PD : 0);
     // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT needs
     // all 128 VGPRs): the first NPRE groups of four steps are re-fetched every tile, behind pass 3 of the transform.
@@ -1185,6 +1189,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (staged mode: the next tile's samples have landed too)
     __syncthreads();                                    // barrier A: rows complete
     TICK(6, tdep);
+    if (MODE != 1 && SYG_CPRIO == 3) SETPRIO(3);        // experiment: projection (+ clip epilogue) at the top level
     if (MODE == 3 && pend_b >= 0) {
       if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6 && SYG_ABL != 7)
         clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, w, lane);
@@ -1246,6 +1251,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     }
     __syncthreads();                // barrier B: slab complete (and every wave has read its staged frame)
     TICK(8, tdep);
+    if (MODE != 1 && (SYG_CPRIO == 1 || SYG_CPRIO == 2)) SETPRIO(3);      // experiment: the slab combine at the top level
     const bool clip_done = (MODE == 3) && (t0 + TILE_T >= T);
     // MODE 1 runs out-of-line row functions below: a function entry waits for EVERY outstanding memory operation
     // (s_waitcnt vmcnt(0) -- the callee cannot know the caller's counters), so nothing may be in flight when they are

@@ -171,3 +171,80 @@ def test_read_clips_pcm_keeps_integer_samples(tmp_path):
         sio.read_clips_pcm([tmp_path / "a.wav", tmp_path / "m.wav"])
     with pytest.raises(ValueError, match="no input files"):
         sio.read_clips_pcm([])
+
+
+def test_reference_plugin_loader_discovers_and_loads_the_backend(tmp_path):
+    """Drives the reference's own PluginLoader.discover_and_load() (sygnals/plugins/loader.py:291-384): a local plugin
+    directory holding this package's plugin.toml -> manifest parse (:63-83), PEP 440 compatibility check against the
+    core version (:85-103), entry-point import (:105-158), setup() and the nine registration hooks in loader order
+    (:266-274).  Build container only (the reference does not exist on the GPU box).  The reference imports the
+    `toml` package, which this image lacks: a tomli-backed module with the three names the loader uses stands in
+    for it for the duration of the test."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "sygnals", "plugins")):
+        pytest.skip("reference checkout not present on this box")
+    import importlib
+    import shutil
+    import types
+    import tomli
+    stand_in = None
+    try:
+        import toml  # noqa: F401
+    except ModuleNotFoundError:
+        stand_in = types.ModuleType("toml")
+        stand_in.load = lambda f: tomli.loads(f.read()) if not isinstance(f, (str, os.PathLike)) else tomli.loads(open(f).read())
+        stand_in.loads = tomli.loads
+        stand_in.TomlDecodeError = tomli.TOMLDecodeError
+        def _dump(data, f):
+            for name, d in data.items():
+                f.write(f"[{name}]\n" + "".join(f"{k} = {str(v).lower() if isinstance(v, bool) else repr(v)}\n" for k, v in d.items()))
+        stand_in.dump = _dump
+        sys.modules["toml"] = stand_in
+    sys.path.insert(0, ref)
+    try:
+        from sygnals.config.models import SygnalsConfig
+        from sygnals.plugins.api import PluginRegistry
+        from sygnals.plugins import loader as L
+        import sygnals_amd.plugins.plugin as mod
+        importlib.reload(mod)                                   # bind the plugin class to the reference's base class
+        plug_dir = tmp_path / "plugins"
+        (plug_dir / "sygnals_amd_backend").mkdir(parents=True)
+        shutil.copy(os.path.join(ROOT, "sygnals_amd", "plugins", "plugin.toml"), plug_dir / "sygnals_amd_backend" / "plugin.toml")
+        (plug_dir / "broken").mkdir()
+        (plug_dir / "broken" / "plugin.toml").write_text('name = "broken"\nversion = "0.0.1"\n')   # missing fields: skipped
+        cfg = SygnalsConfig()
+        cfg.paths.plugin_dir = plug_dir
+        reg = PluginRegistry()
+        order = []
+        for hook in ("setup", "register_filters", "register_transforms", "register_feature_extractors",
+                     "register_visualizations", "register_audio_effects", "register_augmenters", "register_data_readers",
+                     "register_data_writers", "register_cli_commands"):
+            orig = getattr(mod.SygnalsAmdPlugin, hook)
+            def wrapped(self, *a, _o=orig, _h=hook, **k):
+                order.append(_h)
+                return _o(self, *a, **k)
+            setattr(mod.SygnalsAmdPlugin, hook, wrapped)
+        try:
+            ld = L.PluginLoader(cfg, reg)
+            ld.discover_and_load()
+        finally:
+            importlib.reload(mod)
+        assert list(ld.loaded_plugins) == ["sygnals-amd"] and ld.plugin_sources["sygnals-amd"] == "local"
+        assert "sygnals-amd" in reg.loaded_plugin_names and "broken" not in ld.plugin_manifests
+        assert order == ["setup", "register_filters", "register_transforms", "register_feature_extractors",
+                         "register_visualizations", "register_audio_effects", "register_augmenters",
+                         "register_data_readers", "register_data_writers", "register_cli_commands"]
+        _check_registered(reg.list_filters(), reg.list_transforms(), reg.list_features(),
+                          [c.name for c in reg.get_cli_commands()])
+        info = {i["name"]: i for i in ld.get_plugin_info()}
+        assert info["sygnals-amd"]["status"] == "loaded" and info["sygnals-amd"]["api_required"] == ">=1.0.0,<2.0.0"
+        # an incompatible API requirement is refused by the loader's PEP 440 check
+        (plug_dir / "sygnals_amd_backend" / "plugin.toml").write_text(
+            open(os.path.join(ROOT, "sygnals_amd", "plugins", "plugin.toml")).read().replace(">=1.0.0,<2.0.0", ">=2.0.0"))
+        ld2 = L.PluginLoader(cfg, PluginRegistry())
+        ld2.discover_and_load()
+        assert not ld2.loaded_plugins and {i["name"]: i["status"] for i in ld2.get_plugin_info()}["sygnals-amd"] == "error/incompatible"
+    finally:
+        sys.path.remove(ref)
+        if stand_in is not None:
+            sys.modules.pop("toml", None)

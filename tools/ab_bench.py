@@ -1,0 +1,48 @@
+"""A/B timing of library variants on one box: alternates the variants (subprocess per run, SYGNALS_AMD_LIB) so that
+clock drift and box-to-box differences cancel; prints min / median per variant.
+    python3 tools/ab_bench.py [--what mfcc|c4|mel] [--rounds 3] name=path.so [name=path.so ...]
+(`product` as a path means the in-tree product library)"""
+import os, subprocess, sys, statistics
+what, rounds, libs = "mfcc", 3, []
+args = sys.argv[1:]
+while args:
+    a = args.pop(0)
+    if a == "--what": what = args.pop(0)
+    elif a == "--rounds": rounds = int(args.pop(0))
+    else: libs.append(a.split("=", 1))
+CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from sygnals_amd import ops, _tables as T
+from sygnals_amd.synth import synth_clips
+what = sys.argv[1]
+B = 1024
+Y = synth_clips(64, 48000, 48000, seed=1); y = ops.to_device_f32(np.tile(Y, (B // 64, 1)))
+CP = T.contrast_plan(np.fft.rfftfreq(2048, 1 / 48000), 48000)
+fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
+      "mel": lambda: ops.stft2048_mel(y, 48000, n_mels=40),
+      "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
+for _ in range(400): fn()
+torch.cuda.synchronize()
+best = 1e9
+for rep in range(5):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100): fn()
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) * 10)
+print("US", best)
+'''
+res = {n: [] for n, _ in libs}
+for r in range(rounds):
+    for n, path in libs:
+        env = dict(os.environ)
+        if path != "product":
+            env["SYGNALS_AMD_LIB"] = os.path.abspath(path); env["SYGNALS_AMD_ALLOW_VARIANT"] = env.get("SYGNALS_AMD_ALLOW_VARIANT", "0")
+        out = subprocess.run([sys.executable, "-c", CHILD, what], env=env, capture_output=True, text=True)
+        us = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("US")]
+        if not us:
+            print(n, "FAILED", out.stderr[-400:]); continue
+        res[n].append(us[0])
+for n, v in res.items():
+    if v: print(f"{what:5s} {n:14s} min {min(v):7.1f}  median {statistics.median(v):7.1f}  runs {['%.1f' % x for x in v]}")
