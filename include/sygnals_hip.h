@@ -180,6 +180,30 @@ int syg_cabs_pow_f32(const float* x_c64, int64_t n, int power, float* out, void*
 int syg_mel_dense_f32(const float* P, int64_t B, int64_t T, int F, const float* basis, int M,
                       float* mel_out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Fused front end for the OTHER power-of-two frame lengths (n_fft = 64 ... 1024; the reference's own tests and CLI use
+ * 1024 and 256: tests/test_features_manager.py:183-220, cli/features_cmd.py:35): librosa.stft -> |.|^power -> mel
+ * filterbank in one launch, no spectrogram in HBM (manager.py:184-187, 198, 219-222).
+ *   y .. window   as syg_stft_pow2_c2c_f32;  twiddle [n_fft + n_fft/2] complex (W_nfft^k, then W_{nfft/2}^k)
+ *   basis_p    [16*ceil(n_mels/16), Fp] the dense filterbank, zero padded: Fp = (1 + n_fft/2) rounded up to a multiple
+ *              of 16; 16-byte aligned
+ *   power      1 (magnitude) or 2 (power)
+ *   mel_out    [B, n_mels, T]
+ * ------------------------------------------------------------------------------- */
+int syg_stft_mel_pow2_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
+                          int64_t T, const float* window, const float* twiddle, const float* basis_p, int Fp,
+                          int n_mels, int power, float* mel_out, void* stream);
+
+/* The whole MFCC chain for those frame lengths in one launch (a workgroup owns a clip, the clip's mel matrix stays in
+ * LDS): ... -> power_to_db(ref=np.max, top_db) -> DCT-II rows (+ lifter) (manager.py:223, cepstral.py:106-115).
+ * Arguments as syg_stft_mel_pow2_f32 (power 2) + those of syg_stft2048_mfcc_f32.  syg_stft_mfcc_pow2_fits() says
+ * whether the clip's mel matrix fits the LDS; when not, use syg_stft_mel_pow2_f32 + syg_logmel_dct_f32. */
+int syg_stft_mfcc_pow2_fits(int n_fft, int n_mels, int64_t T, int n_mfcc);
+int syg_stft_mfcc_pow2_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
+                           int64_t T, const float* window, const float* twiddle, const float* basis_p, int Fp,
+                           int n_mels, const float* dct, int n_mfcc, const float* lifter, float amin, float top_db,
+                           int ref_is_max, float ref_value, float* mel_out, float* mfcc_out, void* stream);
+
 /* Per-frame spectral statistics of frame-major magnitude spectra mag [N, F] with bin
  * frequencies freqs [F] (frequency_domain.py:24-386).  stats_out [SYG_NSTAT, N]. */
 int syg_spectral_stats_f32(const float* mag, int64_t N, int F, const float* freqs, float roll_percent,

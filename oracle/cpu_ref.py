@@ -1039,9 +1039,11 @@ def mfcc_batch(Y, sr, n_fft=2048, hop_length=512, n_mels=40, n_mfcc=13, center=T
 # Restatement of librosa.cqt / librosa.vqt (gamma = 0) as published for librosa 0.10: early downsampling,
 # per-octave STFT (rectangular window) times a sparsified frequency-domain constant-Q basis, recursive
 # decimation by two, octave stacking and length scaling.  ONE DOCUMENTED DEVIATION: librosa resamples with
-# libsoxr ('soxr_hq', a C library that is not available here); `cqt_resample2` below uses
-# scipy.signal.resample_poly(y, 1, 2) (Kaiser-windowed FIR, 41 taps) with librosa's length / sqrt(2) scaling
-# rules.  Parity target for the device CQT is THIS restatement.
+# libsoxr ('soxr_hq', a C library that is not available here: pass band to 0.913 of the new Nyquist, stop band about
+# -125 dB); `cqt_resample2` below filters with a 41-tap half-band FIR, Kaiser beta 10 (stop band <= -99 dB from
+# 0.66 pi, within 1.3e-5 up to 0.34 pi; round 2 used resample_poly's beta 5, -56 dB) and keeps librosa's length /
+# sqrt(2) scaling rules.  Measured distance to a 301-tap -155 dB half-band: 2e-5 ... 5e-5 of the CQT's peak
+# (tools/cqt_decimator_study.py).  Parity target for the device CQT is THIS restatement.
 HANN_BANDWIDTH = 1.50018310546875          # librosa.filters.WINDOW_BANDWIDTHS['hann']
 
 
@@ -1055,18 +1057,21 @@ def cqt_frequencies(n_bins, fmin, bins_per_octave=12, tuning=0.0):
     return corr * fmin * 2.0 ** (np.arange(n_bins, dtype=np.float64) / bins_per_octave)
 
 
+def cqt_decimation_taps():
+    """The octave decimator: firwin(41, 0.5, window=('kaiser', 10.0)), a half-band FIR."""
+    return scipy.signal.firwin(41, 0.5, window=("kaiser", 10.0))
+
+
 def cqt_resample2(y):
-    """Decimate by two: stand-in for librosa.resample(y, orig_sr=2, target_sr=1, res_type='soxr_hq', scale=True)."""
+    """Decimate by two: stand-in for librosa.resample(y, orig_sr=2, target_sr=1, res_type='soxr_hq', scale=True):
+    z[n] = sum_j h[j] y[2 n + 20 - j] (zero outside the signal), ceil(len / 2) outputs."""
+    y = np.asarray(y, dtype=np.float64)
+    h = cqt_decimation_taps()
     n = int(np.ceil(y.shape[-1] * 0.5))
-    z = scipy.signal.resample_poly(np.asarray(y, dtype=np.float64), 1, 2)
+    z = np.convolve(y, h)[(len(h) - 1) // 2:][::2][:n]
     if z.shape[-1] < n:
         z = np.pad(z, (0, n - z.shape[-1]))
-    return z[:n] * np.sqrt(2.0)            # scale=True: y_hat /= sqrt(ratio), ratio = 1/2
-
-
-def cqt_decimation_taps():
-    """FIR used by scipy.signal.resample_poly(x, 1, 2): firwin(41, 0.5, window=('kaiser', 5.0))."""
-    return scipy.signal.firwin(41, 0.5, window=("kaiser", 5.0))
+    return z * np.sqrt(2.0)                # scale=True: y_hat /= sqrt(ratio), ratio = 1/2
 
 
 def _wavelet_lengths(freqs, sr, filter_scale, alpha):

@@ -38,6 +38,9 @@ SIGNATURES = {
     "syg_stft_pow2_c2c_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _l, _p, _p, _p, _p]),
     "syg_cabs_pow_f32": (_i, [_p, _l, _i, _p, _p]),
     "syg_mel_dense_f32": (_i, [_p, _l, _l, _i, _p, _i, _p, _p]),
+    "syg_stft_mel_pow2_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _l, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "syg_stft_mfcc_pow2_fits": (_i, [_i, _i, _l, _i]),
+    "syg_stft_mfcc_pow2_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _l, _p, _p, _p, _i, _i, _p, _i, _p, _f, _f, _i, _f, _p, _p, _p]),
     "syg_spectral_stats_f32": (_i, [_p, _l, _i, _p, _f, _f, _p, _p]),
     "syg_contrast_pv_f32": (_i, [_p, _l, _i, _p, _p, _p]),
     "syg_contrast_db_f32": (_i, [_p, _l, _i, _l, _f, _f, _p, _p]),

@@ -118,18 +118,21 @@ def compute_cqt(y, sr: int, hop_length: Optional[int] = 512, fmin: Optional[floa
     for k, v in fixed.items():
         if k in kwargs and kwargs.pop(k) != v:
             raise SygnalsHipError(f"compute_cqt: only {k}={v!r} runs on the device")
-    # APPROXIMATE ROW: librosa decimates between octaves with its default res_type='soxr_hq'; the device
-    # (and this repository's oracle) use a 41-tap Kaiser half-band FIR (= scipy.signal.resample_poly(x, 1, 2)).  An
-    # explicit request for any other resampler cannot be honoured and is refused rather than silently dropped.
+    # APPROXIMATE ROW: librosa decimates between octaves with its default res_type='soxr_hq' (libsoxr:
+    # stop band about -125 dB); the device (and this repository's oracle) use a 41-tap half-band FIR, Kaiser beta 10:
+    # stop band <= -99 dB from 0.66 pi, pass band within 1.3e-5 up to 0.34 pi.  Measured against a -155 dB half-band:
+    # 2e-5 ... 5e-5 of the transform's peak (tools/cqt_decimator_study.py).  librosa's default spelling is accepted
+    # with that warning; a request for any OTHER resampler cannot be honoured and is refused rather than dropped.
     res_type = kwargs.pop("res_type", None)
-    if res_type not in (None, "kaiser_halfband"):
+    if res_type not in (None, "soxr_hq", "kaiser_halfband"):
         raise SygnalsHipError(f"compute_cqt: res_type={res_type!r} is not available on the device; the octave "
                               "decimator is a fixed 41-tap Kaiser half-band FIR (res_type='kaiser_halfband')")
     global _cqt_warned
-    if res_type is None and not _cqt_warned:
+    if res_type != "kaiser_halfband" and not _cqt_warned:
         _cqt_warned = True
-        logger.warning("compute_cqt: the device path decimates with a 41-tap Kaiser half-band FIR, not librosa's "
-                       "default res_type='soxr_hq'; values differ from librosa.cqt at the resampler's accuracy "
+        logger.warning("compute_cqt: the device path decimates with a 41-tap half-band FIR (Kaiser beta 10: stop band "
+                       "<= -99 dB, pass band within 1.3e-5), not librosa's res_type='soxr_hq' (about -125 dB); values "
+                       "differ from librosa.cqt by about 2e-5 ... 5e-5 of the transform's peak "
                        "(pass res_type='kaiser_halfband' to acknowledge)")
     tuning = kwargs.pop("tuning", 0.0)
     filter_scale = kwargs.pop("filter_scale", 1.0)

@@ -47,6 +47,8 @@ def mel_power_batch(y, sr, n_fft, hop, center, window, n_mels, fmin, fmax, power
         return mel
     if power not in (1.0, 2.0):
         raise SygnalsHipError("mel power must be 1.0 or 2.0 on the device")
+    if ops.fused_pow2_ok(n_fft, n_mels):
+        return ops.stft_mel_pow2(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax, int(power))
     X = ops.stft_any(y, n_fft, hop, center, window, win_length)
     P = ops.cabs_pow(X, int(power))
     cfg = ops.mel_config(sr, n_fft, n_mels, fmin, fmax)
@@ -139,6 +141,10 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
                                                    fmin, fmax, want_stats, roll, bw_p, cplan)
                 t_stft = Tn
+            elif want_mfcc and not (want_stats or want_contrast) and power in (1.0, 2.0) and ops.fused_pow2_ok(frame_length, n_mels):
+                # only the mel spectrogram is needed: fused kernel of the other power-of-two frame lengths
+                mel = ops.stft_mel_pow2(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
+                t_stft = mel.shape[2]
             else:
                 X = ops.stft_any(yd, frame_length, hop_length, center, window)
                 t_stft, F = X.shape[1], X.shape[2]

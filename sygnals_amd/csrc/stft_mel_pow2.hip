@@ -1,0 +1,510 @@
+// Fused STFT(n_fft = 2^k, 64 ... 4096) -> |X|^power -> mel filterbank (-> power_to_db -> DCT-II) for the frame
+// lengths the wave-FFT kernel of stft_mel.hip (n_fft = 2048) does not take: the reference's own tests and CLI use
+// frame_length 1024 and 256 (tests/test_features_manager.py:183-220, cli/features_cmd.py:35).  Round 2 ran these
+// as complex STFT -> |X|^2 -> dense filterbank -> dB/DCT: four launches and a power-spectrogram round trip through HBM
+// (2.4 GB at 1024 clips x 1 s, n_fft 1024 / hop 256).  Here a workgroup takes 16 consecutive frames of one clip:
+//   transform  every wave runs whole frames by itself (block_fft<WAVE>: Stockham radix-8 in LDS buffers of its own, no
+//              workgroup barrier), packs the real frame as n_fft/2 complex points, splits, and leaves |X|^power as one
+//              row of the tile's LDS power matrix [16][F];
+//   barrier
+//   project    mel[m, t] = sum_f basis[m, f] P[t, f] on v_mfma_f32_16x16x4_f32 (exact fp32): B operand = the 16 LDS
+//              rows (one ds_read_b128 per four k-steps), A operand = the zero-padded dense filterbank from L2;
+//   barrier
+// TILE mode writes the mel tile; CLIP mode (a workgroup owns a whole clip) keeps the clip's mel matrix in LDS and ends
+// with power_to_db(ref = max of the clip, amin, top_db) + DCT-II rows (+ lifter): samples in, MFCCs out, one launch.
+// Reference chain: manager.py:184-187, 198, 219-223 -> librosa.stft / melspectrogram / power_to_db; cepstral.py:106-115.
+#include "wave_fft.h"
+#include <string.h>
+
+namespace syg {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct Pow2Mfcc {
+  const float* dct;      // [n_mfcc, n_mels]
+  const float* lifter;   // [n_mfcc] or null
+  float* out;            // [B, n_mfcc, T]
+  int n_mfcc;
+  int ref_is_max;
+  float ref_value, amin, top_db;
+  int tp;                // 16 * tiles per clip: row stride of the LDS mel matrix
+};
+
+// Real-input split: Z = FFT_M(z), z[m] = x[2m] + i x[2m+1]; X[k], k in [0, M];  tw2[k] = W_{2M}^k.
+__device__ __forceinline__ float2 rbin(const float2* Z, int M, int k, const float2* __restrict__ tw2) {
+  const float2 zk = Z[k & (M - 1)], zm = Z[(M - k) & (M - 1)];
+  const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);
+  const float2 O = make_float2(zk.y + zm.y, zm.x - zk.x);
+  const float2 wO = cmul(tw2[k], O);
+  return make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
+}
+
+// LDS (floats): fft [NW][2][M] complex | P [16][PS] | twl [n_fft + M] complex (the twiddle tables: the Stockham passes
+// and the split read them per butterfly -- from global memory that was a dependent L2 round trip per pass at two waves per
+// SIMD) | CLIP: clipmel [n_mels][tp], red [NW + 2]
+template <int NW, bool CLIP>
+__global__ __launch_bounds__(NW * 64) void stft_mel_pow2_kernel(
+    const float* __restrict__ y, int64_t L, int64_t ldy, int n_fft, int hop, int pad, int64_t T,
+    const float* __restrict__ win, const float2* __restrict__ tw, const float* __restrict__ basis_p, int Fp, int n_mels,
+    int power, float* __restrict__ mel_out, int tiles_per_clip, Pow2Mfcc mf) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int M = n_fft >> 1, F = M + 1, PS = Fp + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2* fx = reinterpret_cast<float2*>(lds) + (size_t)w * 2 * M;
+  float2* fz = fx + M;
+  float* P = lds + (size_t)NW * 4 * M;
+  float2* twl = reinterpret_cast<float2*>(P + 16 * PS);
+  float* clipmel = P + 16 * PS + 2 * (n_fft + M);
+  float* red = clipmel + (CLIP ? n_mels * mf.tp : 0);
+  for (int i = tid; i < n_fft + M; i += NW * 64) twl[i] = tw[i];
+
+  const int64_t b = CLIP ? blockIdx.x : blockIdx.x / tiles_per_clip;
+  const int tile0 = CLIP ? 0 : (int)(blockIdx.x - b * tiles_per_clip);
+  const int ntile = CLIP ? tiles_per_clip : 1;
+  const float* yb = y + b * ldy;
+  // the columns [F, PS) of the power rows meet zero weights: they must hold finite values
+  for (int i = tid; i < 16 * PS; i += NW * 64) P[i] = 0.f;
+  __syncthreads();
+
+  const int n_mt = (n_mels + 15) >> 4;
+  const int n = lane & 15, kk = lane >> 4;
+  float cmax = 0.f;
+  for (int ti = 0; ti < ntile; ++ti) {
+    const int64_t t0 = (int64_t)(tile0 + ti) * 16;
+    // ---- transforms: wave w takes the frames w, w + NW, ... of the tile
+    for (int fi = w; fi < 16; fi += NW) {
+      const int64_t t = t0 + fi;
+      float* prow = P + fi * PS;
+      if (t < T) {
+        const int64_t s0 = t * (int64_t)hop - pad;
+        if (s0 >= 0 && s0 + n_fft <= L) {
+          for (int m = lane; m < M; m += 64)
+            fx[m] = make_float2(yb[s0 + 2 * m] * win[2 * m], yb[s0 + 2 * m + 1] * win[2 * m + 1]);
+        } else {
+          for (int m = lane; m < M; m += 64) {
+            const int64_t s = s0 + 2 * m;
+            const float a = (s >= 0 && s < L) ? yb[s] * win[2 * m] : 0.f;
+            const float c = (s + 1 >= 0 && s + 1 < L) ? yb[s + 1] * win[2 * m + 1] : 0.f;
+            fx[m] = make_float2(a, c);
+          }
+        }
+        wave_lds_sync();
+        const float2* Z = block_fft<true>(fx, fz, M, twl + n_fft, lane, 64);
+        for (int k = lane; k <= M; k += 64) {
+          const float2 X = rbin(Z, M, k, twl);
+          const float p2 = fmaf(X.x, X.x, X.y * X.y);
+          prow[k] = (power == 2) ? p2 : sqrtf(p2);
+        }
+        wave_lds_sync();                 // the buffers are free for the wave's next frame
+      } else {
+        for (int k = lane; k < F; k += 64) prow[k] = 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- projection: wave w takes the 16-row mel tiles w, w + NW, ...
+    for (int mt = w; mt < n_mt; mt += NW) {
+      const float* arow = basis_p + (size_t)(16 * mt + n) * Fp + 4 * kk;
+      const float* brow = P + n * PS + 4 * kk;
+      v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < Fp; s += 16) {
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + s);
+        const float4 b4 = *reinterpret_cast<const float4*>(brow + s);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc2, 0, 0, 0);
+      }
+      acc += acc2;
+      // D[row 4 kk + i][col n]: mel row 16 mt + 4 kk + i of frame t0 + n
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * mt + 4 * kk + i;
+        if (m < n_mels) {
+          if (CLIP) {
+            clipmel[m * mf.tp + (int)t0 + n] = acc[i];     // frames >= T hold 0 (their rows were cleared)
+            cmax = fmaxf(cmax, acc[i]);
+          }
+          if (mel_out != nullptr && t0 + n < T) mel_out[(b * n_mels + m) * T + t0 + n] = acc[i];
+        }
+      }
+    }
+    __syncthreads();                     // every projection has read the rows: the next tile may overwrite them
+  }
+  if (!CLIP) return;
+
+  // ---- clip epilogue: librosa.power_to_db(S, ref=np.max) (manager.py:223) -> scipy.fft.dct rows (cepstral.py:106-115)
+  cmax = wave_max(cmax);
+  if (lane == 0) red[w] = cmax;
+  __syncthreads();
+  if (tid == 0) {
+    float m = red[0];
+    for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
+    const float ref = mf.ref_is_max ? m : fabsf(mf.ref_value);
+    const float reflog = log10f(fmaxf(mf.amin, ref));
+    red[NW] = reflog;
+    red[NW + 1] = (mf.top_db >= 0.f) ? 10.f * (log10f(fmaxf(mf.amin, m)) - reflog) - mf.top_db : -3.4e38f;
+  }
+  __syncthreads();
+  const float reflog = red[NW], flo = red[NW + 1];
+  const int nm = n_mels * mf.tp;
+  for (int i = tid; i < nm; i += NW * 64)
+    clipmel[i] = fmaxf(10.f * (log10f(fmaxf(mf.amin, clipmel[i])) - reflog), flo);   // 10 (log x - log ref): exact 0 at x == ref
+  __syncthreads();
+  const int ktiles = (mf.n_mfcc + 15) >> 4, ttiles = mf.tp >> 4;
+  for (int ot = w; ot < ktiles * ttiles; ot += NW) {
+    const int kt = ot / ttiles, tq = ot - kt * ttiles;
+    const int krow = kt * 16 + n, tcol = tq * 16 + n;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int m0 = 0; m0 < n_mels; m0 += 4) {
+      const int m = m0 + kk;
+      const float a = (krow < mf.n_mfcc && m < n_mels) ? mf.dct[krow * n_mels + m] : 0.f;
+      const float bv = (m < n_mels) ? clipmel[m * mf.tp + tcol] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + 4 * kk + r;
+      if (k < mf.n_mfcc && tcol < T) {
+        float v = acc[r];
+        if (mf.lifter) v *= mf.lifter[k];
+        mf.out[(b * mf.n_mfcc + k) * T + tcol] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// n_fft = 1024 on the wave FFT (wave_fft.h): TWO real frames per 1024-point complex transform.  With z[n] = a[n] + i b[n]
+// (a, b: two windowed frames), A[k] = (Z[k] + conj Z[1024 - k]) / 2 and B[k] = -i (Z[k] - conj Z[1024 - k]) / 2 -- no
+// twiddle in the split -- and the wave FFT hands every lane Z[k] and Z[1024 - k] of its bins together.  A wave owns the
+// frames (2 w, 2 w + 1) of the 16-frame tile: one transform, 16 + 16 row stores, everything else as above.
+// The projection is split over two K halves per 16-row mel tile (six of the eight waves work at 40 mels); the second
+// halves leave their partial tiles in LDS and the first halves add them in a fixed order.
+// The two power rows of a wave ALIAS its exchange scratch (written behind the transform, read by the projection, dead
+// before the next transform): 46 KiB (tile form) / 79 KiB (clip form at 40 mels x 192 frames) of LDS per workgroup, two
+// workgroups per CU.  The window is read from global memory (4 KiB, cache resident) beside the samples.
+// LDS (floats): sc = P [8][2 * PS] | tw2l | tw1l | part [2 n_mt][256] | CLIP: clipmel, red
+struct W1024Lds {
+  static constexpr int FP = 528, PS = FP + 4;
+  static constexpr int SCW = 2 * PS;                                  // per-wave scratch: 1064 floats >= 528 complex
+  static constexpr int O_SC = 0;
+  static constexpr int O_TW2 = O_SC + 8 * SCW;
+  static constexpr int O_TW1 = O_TW2 + wfft::TW2_COMPLEX * 2;
+  static constexpr int O_PART = O_TW1 + wfft::TW1_COMPLEX * 2;
+  static_assert(SCW >= 2 * wfft::SC_COMPLEX, "the exchange scratch must fit the two aliased rows");
+};
+
+// tile form: 79 registers -> six waves per SIMD, three workgroups per CU (46 KiB of LDS each): 231 us per 1024 clips x 1 s
+// against 269 us at the compiler's own choice (85 registers, two workgroups)
+#ifndef SYG_P2_TILE_WAVES
+#define SYG_P2_TILE_WAVES 6
+#endif
+template <bool CLIP>
+__global__ __launch_bounds__(512, CLIP ? 4 : SYG_P2_TILE_WAVES) void stft_mel_w1024_kernel(
+    const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, const float* __restrict__ win,
+    const float2* __restrict__ tw1024, const float* __restrict__ basis_p, int n_mels, int power,
+    float* __restrict__ mel_out, int tiles_per_clip, Pow2Mfcc mf) {
+  typedef W1024Lds LM;
+  constexpr int NW = 8, FP = LM::FP, PS = LM::PS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2* sc = reinterpret_cast<float2*>(lds + LM::O_SC + w * LM::SCW);
+  float2* tw2l = reinterpret_cast<float2*>(lds + LM::O_TW2);
+  float2* tw1l = reinterpret_cast<float2*>(lds + LM::O_TW1);
+  float* P = lds + LM::O_SC;                       // row fi at fi * PS: rows 2 w, 2 w + 1 inside wave w's scratch
+  float* part = lds + LM::O_PART;
+  const int n_mt = (n_mels + 15) >> 4;
+  float* clipmel = part + 2 * n_mt * 256;
+  float* red = clipmel + (CLIP ? n_mels * mf.tp : 0);
+
+  wfft::Lane lc;
+  wfft::init_lane(lc, lane);
+
+  // CLIP: a workgroup owns clip blockIdx.x (all its tiles, the next tile's samples requested one tile ahead).  TILE: one
+  // tile per workgroup (a persistent form with the same prefetch needed 128 registers and spilled: 323 vs 270 us).
+  const int64_t gt0 = CLIP ? (int64_t)blockIdx.x * tiles_per_clip : (int64_t)blockIdx.x;
+  const int ntile = CLIP ? tiles_per_clip : 1;
+  const int n = lane & 15, kk = lane >> 4;
+  // projection units: (mel tile, K half); unit u -> wave u (n_mt <= 4 here: up to 8 units); more tiles: round robin
+  const int ngrp = FP / 16, gh = (ngrp + 1) / 2;                     // 33 groups of 16 bins: 17 + 16
+  float cmax = 0.f;
+  // raw samples of the wave's two frames (x: frame 2 w, y: frame 2 w + 1; zero outside the clip: center=True's padding)
+  float2 raw[16];
+  float wv[16];
+  auto fetch = [&](int64_t gt) {                  // tile gt of the batch: clip gt / tiles_per_clip, first frame 16 (gt % ...)
+    const int64_t bq = gt / tiles_per_clip;
+    const float* yb = y + bq * ldy;
+    const int64_t ta = (gt - bq * tiles_per_clip) * 16 + 2 * w, tb = ta + 1;
+    if (ta >= T) return;
+    const int64_t sa = ta * (int64_t)hop - pad, sb = tb * (int64_t)hop - pad;
+    const bool hasb = tb < T;
+    int lf = lane;
+    asm volatile("" : "+v"(lf));                  // (per-lane addresses are recomputed per tile, not hoisted)
+    if (sa >= 0 && sb + 1024 <= L && hasb) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) raw[a] = make_float2(yb[sa + 64 * a + lf], yb[sb + 64 * a + lf]);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const int64_t ia = sa + 64 * a + lf, ib = sb + 64 * a + lf;
+        raw[a] = make_float2((ia >= 0 && ia < L) ? yb[ia] : 0.f, (hasb && ib >= 0 && ib < L) ? yb[ib] : 0.f);
+      }
+    }
+  };
+#pragma unroll
+  for (int a = 0; a < 16; ++a) wv[a] = win[64 * a + lane];
+  fetch(gt0);
+  // tables of the wave FFT from tw1024[m] = W_1024^m:  W_64^(b' c') = W_1024^(16 b' c'),  W_1024^(b c), b c <= 945
+  // (behind the sample requests: the table reads and the barrier then overlap the samples' way through memory)
+  if (tid < 64) tw2l[(tid >> 4) * wfft::TW2_STRIDE + (tid & 15)] = tw1024[(16 * (tid >> 4) * (tid & 15)) & 1023];
+  for (int i = tid; i < wfft::TW1_COMPLEX; i += NW * 64) tw1l[i] = tw1024[(i & 63) * ((i >> 6) + 1)];
+  __syncthreads();
+  for (int ti = 0; ti < ntile; ++ti) {
+    const int64_t gt = gt0 + ti;
+    const int64_t b = gt / tiles_per_clip;
+    const int64_t t0 = (gt - b * tiles_per_clip) * 16;
+    // ---- transform of the frames 2 w (real part) and 2 w + 1 (imaginary part); the samples were requested one tile
+    // ahead (raw[], wv[]: the loads land behind the previous tile's projection)
+    {
+      const int64_t ta = t0 + 2 * w;
+      float* rowa = P + (2 * w) * PS;
+      float* rowb = rowa + PS;
+      if (ta < T) {
+        float2 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = make_float2(raw[a].x * wv[a], raw[a].y * wv[a]);
+        float2 zk[2][4], zm[2][4], z512;
+        wfft::cfft1024(v, lc, sc, tw1l, tw2l, lane, zk, zm, z512);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int k = wfft::bin_of(lane, j, d);
+            const int kq = k <= 512 ? k : 1024 - k;                 // |A[k]| = |A[1024 - k]|: the pair's bin below 512
+            const float ex = zk[j][d].x + zm[j][d].x, ey = zk[j][d].y - zm[j][d].y;
+            const float ox = zk[j][d].y + zm[j][d].y, oy = zm[j][d].x - zk[j][d].x;
+            const float pa = 0.25f * fmaf(ex, ex, ey * ey), pb = 0.25f * fmaf(ox, ox, oy * oy);
+            rowa[kq] = (power == 2) ? pa : sqrtf(pa);
+            rowb[kq] = (power == 2) ? pb : sqrtf(pb);
+          }
+        if (lane == 0) {
+          rowa[512] = (power == 2) ? z512.x * z512.x : fabsf(z512.x);
+          rowb[512] = (power == 2) ? z512.y * z512.y : fabsf(z512.y);
+        }
+        if (lane >= 1 && lane < PS - 512) { rowa[512 + lane] = 0.f; rowb[512 + lane] = 0.f; }   // [513, PS): zero weights
+      } else {
+        for (int k = lane; k < PS; k += 64) { rowa[k] = 0.f; rowb[k] = 0.f; }
+      }
+#ifndef SYG_P2_LATEFETCH
+      if (ti + 1 < ntile) fetch(gt + 1);
+#endif
+    }
+    __syncthreads();
+    // ---- projection
+    for (int u = w; u < 2 * n_mt; u += NW) {
+      const int mt = u >> 1, half = u & 1;
+      const int g0 = half ? gh : 0, g1 = half ? ngrp : gh;
+      const float* arow = basis_p + (size_t)(16 * mt + n) * FP + 4 * kk;
+      const float* brow = P + n * PS + 4 * kk;
+      v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      for (int g = g0; g < g1; ++g) {
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * g);
+        const float4 b4 = *reinterpret_cast<const float4*>(brow + 16 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc2, 0, 0, 0);
+      }
+      acc += acc2;
+      // both halves leave their sums in `part`; the first half's wave adds them behind the barrier
+      float* dst = part + u * 256 + lane * 4;
+      dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3];
+    }
+    __syncthreads();                     // rows read, partial tiles written
+    for (int u = w; u < 2 * n_mt; u += NW) {
+      if (u & 1) continue;
+      const int mt = u >> 1;
+      const float* kp = part + u * 256 + lane * 4;
+      const float* pt = kp + 256;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float sum = kp[i] + pt[i];                              // first half + second half, fixed order
+        const int m = 16 * mt + 4 * kk + i;
+        if (m < n_mels) {
+          if (CLIP) {
+            clipmel[m * mf.tp + (int)t0 + n] = sum;
+            cmax = fmaxf(cmax, sum);
+          }
+          if (mel_out != nullptr && t0 + n < T) mel_out[(b * n_mels + m) * T + t0 + n] = sum;
+        }
+      }
+    }
+#ifdef SYG_P2_LATEFETCH
+    if (ti + 1 < ntile) fetch(gt + 1);          // (timing variant: the loads are requested right in front of their use)
+#endif
+    // (the next transform overwrites the rows -- every projection read them before the barrier above -- and `part` is
+    // next written behind the next tile's first barrier)
+  }
+  if (!CLIP) return;
+  const int64_t b = blockIdx.x;
+  __syncthreads();
+  cmax = wave_max(cmax);
+  if (lane == 0) red[w] = cmax;
+  __syncthreads();
+  if (tid == 0) {
+    float m = red[0];
+    for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
+    const float ref = mf.ref_is_max ? m : fabsf(mf.ref_value);
+    const float reflog = log10f(fmaxf(mf.amin, ref));
+    red[NW] = reflog;
+    red[NW + 1] = (mf.top_db >= 0.f) ? 10.f * (log10f(fmaxf(mf.amin, m)) - reflog) - mf.top_db : -3.4e38f;
+  }
+  __syncthreads();
+  const float reflog = red[NW], flo = red[NW + 1];
+  const int nm = n_mels * mf.tp;
+  for (int i = tid; i < nm; i += NW * 64)
+    clipmel[i] = fmaxf(10.f * (log10f(fmaxf(mf.amin, clipmel[i])) - reflog), flo);
+  __syncthreads();
+  const int ktiles = (mf.n_mfcc + 15) >> 4, ttiles = mf.tp >> 4;
+  for (int ot = w; ot < ktiles * ttiles; ot += NW) {
+    const int kt = ot / ttiles, tq = ot - kt * ttiles;
+    const int krow = kt * 16 + n, tcol = tq * 16 + n;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int m0 = 0; m0 < n_mels; m0 += 4) {
+      const int m = m0 + kk;
+      const float a = (krow < mf.n_mfcc && m < n_mels) ? mf.dct[krow * n_mels + m] : 0.f;
+      const float bv = (m < n_mels) ? clipmel[m * mf.tp + tcol] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + 4 * kk + r;
+      if (k < mf.n_mfcc && tcol < T) {
+        float v = acc[r];
+        if (mf.lifter) v *= mf.lifter[k];
+        mf.out[(b * mf.n_mfcc + k) * T + tcol] = v;
+      }
+    }
+  }
+}
+
+size_t w1024_lds_bytes(int n_mels, int tp) {
+  const int n_mt = (n_mels + 15) / 16;
+  return ((size_t)W1024Lds::O_PART + (size_t)2 * n_mt * 256 + (size_t)n_mels * tp + 8 + 2) * sizeof(float);
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr int NWAVES = 8;
+
+size_t lds_bytes(int n_fft, int Fp, int n_mels, int tp) {
+  return ((size_t)NWAVES * 2 * n_fft + 16 * (size_t)(Fp + 4) + 3 * (size_t)n_fft + (size_t)n_mels * tp + NWAVES + 2) * sizeof(float);
+}
+
+int check_args(const char* who, const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center, int64_t T,
+               const float* window, const float* twiddle, const float* basis_p, int Fp, int n_mels, int power) {
+  SYG_REQUIRE(y && window && twiddle && basis_p, "%s: null pointer argument", who);
+  SYG_REQUIRE(B >= 1 && L >= 1 && ldy >= L, "%s: need B >= 1, L >= 1, ldy >= L", who);
+  SYG_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0, "%s: n_fft must be a power of two in [64, 4096] (got %d)",
+              who, n_fft);
+  SYG_REQUIRE(hop >= 1, "%s: hop must be >= 1", who);
+  const int64_t Texp = center ? 1 + L / hop : (L >= n_fft ? 1 + (L - n_fft) / hop : 0);
+  SYG_REQUIRE(T >= 1 && T == Texp, "%s: T=%lld does not match the framing rule (%lld)", who, (long long)T, (long long)Texp);
+  SYG_REQUIRE(Fp % 16 == 0 && Fp >= n_fft / 2 + 1 && Fp < n_fft / 2 + 1 + 16, "%s: Fp must be 1 + n_fft/2 rounded up to a multiple of 16 (got %d)",
+              who, Fp);
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= 256, "%s: n_mels must be in [1, 256]", who);
+  SYG_REQUIRE(power == 1 || power == 2, "%s: power must be 1 or 2", who);
+  SYG_REQUIRE(B * ((T + 15) / 16) < (int64_t)0x7fffffff, "%s: grid too large", who);
+  SYG_REQUIRE(((uintptr_t)basis_p) % 16 == 0, "%s: the padded filterbank must be 16-byte aligned", who);
+  return SYG_OK;
+}
+
+}  // namespace
+}  // namespace syg
+
+using namespace syg;
+
+extern "C" int syg_stft_mel_pow2_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
+                                     int64_t T, const float* window, const float* twiddle, const float* basis_p, int Fp,
+                                     int n_mels, int power, float* mel_out, void* stream) {
+  int rc = check_args("stft_mel_pow2", y, B, L, ldy, n_fft, hop, center, T, window, twiddle, basis_p, Fp, n_mels, power);
+  if (rc) return rc;
+  SYG_REQUIRE(mel_out, "stft_mel_pow2: null output");
+  if (n_fft == 1024) {
+    const size_t lds = w1024_lds_bytes(n_mels, 0);
+    auto kern = stft_mel_w1024_kernel<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("stft_mel_pow2: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return SYG_E_LAUNCH; }
+    const int tiles = (int)((T + 15) / 16);
+    Pow2Mfcc mf;
+    memset(&mf, 0, sizeof(mf));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(512), lds, (hipStream_t)stream, y, L, ldy, hop,
+                       center ? 512 : 0, T, window, (const float2*)twiddle, basis_p, n_mels, power, mel_out, tiles, mf);
+    SYG_CHECK_LAUNCH("stft_mel_pow2");
+    return SYG_OK;
+  }
+  const size_t lds = lds_bytes(n_fft, Fp, 0, 0);
+  SYG_REQUIRE(lds <= LDS_LIMIT, "stft_mel_pow2: n_fft=%d needs %zu B of LDS", n_fft, lds);
+  auto kern = stft_mel_pow2_kernel<NWAVES, false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("stft_mel_pow2: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return SYG_E_LAUNCH; }
+  const int tiles = (int)((T + 15) / 16);
+  Pow2Mfcc mf;
+  memset(&mf, 0, sizeof(mf));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(NWAVES * 64), lds, (hipStream_t)stream, y, L, ldy, n_fft, hop,
+                     center ? n_fft / 2 : 0, T, window, (const float2*)twiddle, basis_p, Fp, n_mels, power, mel_out, tiles, mf);
+  SYG_CHECK_LAUNCH("stft_mel_pow2");
+  return SYG_OK;
+}
+
+extern "C" int syg_stft_mfcc_pow2_fits(int n_fft, int n_mels, int64_t T, int n_mfcc) {
+  if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)) || n_mels < 1 || n_mels > 256 || T < 1 || T > (1 << 20) ||
+      n_mfcc < 1 || n_mfcc > n_mels)
+    return 0;
+  const int Fp = ((n_fft / 2 + 1) + 15) / 16 * 16;
+  const int tp = (int)((T + 15) / 16) * 16;
+  if (n_fft == 1024) return w1024_lds_bytes(n_mels, tp) <= LDS_LIMIT ? 1 : 0;
+  return lds_bytes(n_fft, Fp, n_mels, tp) <= LDS_LIMIT ? 1 : 0;
+}
+
+extern "C" int syg_stft_mfcc_pow2_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
+                                      int64_t T, const float* window, const float* twiddle, const float* basis_p, int Fp,
+                                      int n_mels, const float* dct, int n_mfcc, const float* lifter, float amin,
+                                      float top_db, int ref_is_max, float ref_value, float* mel_out, float* mfcc_out,
+                                      void* stream) {
+  int rc = check_args("stft_mfcc_pow2", y, B, L, ldy, n_fft, hop, center, T, window, twiddle, basis_p, Fp, n_mels, 2);
+  if (rc) return rc;
+  SYG_REQUIRE(dct && mfcc_out, "stft_mfcc_pow2: null pointer argument");
+  SYG_REQUIRE(n_mfcc >= 1 && n_mfcc <= n_mels, "stft_mfcc_pow2: need 1 <= n_mfcc <= n_mels");
+  SYG_REQUIRE(amin > 0.f, "stft_mfcc_pow2: amin must be strictly positive");
+  SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft_mfcc_pow2: ref_is_max must be 0 or 1");
+  SYG_REQUIRE(B <= 0x7fffffff, "stft_mfcc_pow2: too many clips");
+  const int tiles = (int)((T + 15) / 16);
+  Pow2Mfcc mf;
+  mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
+  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = tiles * 16;
+  if (n_fft == 1024) {
+    const size_t lds = w1024_lds_bytes(n_mels, mf.tp);
+    SYG_REQUIRE(lds <= LDS_LIMIT, "stft_mfcc_pow2: the clip's mel matrix (%d x %d) does not fit the LDS (%zu B > %zu B); use "
+                "syg_stft_mel_pow2_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
+    auto kern = stft_mel_w1024_kernel<true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("stft_mfcc_pow2: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return SYG_E_LAUNCH; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, y, L, ldy, hop, center ? 512 : 0, T,
+                       window, (const float2*)twiddle, basis_p, n_mels, 2, mel_out, tiles, mf);
+    SYG_CHECK_LAUNCH("stft_mfcc_pow2");
+    return SYG_OK;
+  }
+  const size_t lds = lds_bytes(n_fft, Fp, n_mels, mf.tp);
+  SYG_REQUIRE(lds <= LDS_LIMIT, "stft_mfcc_pow2: the clip's mel matrix (%d x %d) does not fit the LDS (%zu B > %zu B); use "
+              "syg_stft_mel_pow2_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
+  auto kern = stft_mel_pow2_kernel<NWAVES, true>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("stft_mfcc_pow2: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return SYG_E_LAUNCH; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(NWAVES * 64), lds, (hipStream_t)stream, y, L, ldy, n_fft, hop,
+                     center ? n_fft / 2 : 0, T, window, (const float2*)twiddle, basis_p, Fp, n_mels, 2, mel_out, tiles, mf);
+  SYG_CHECK_LAUNCH("stft_mfcc_pow2");
+  return SYG_OK;
+}

@@ -130,6 +130,76 @@ def fused_mel_ok(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> bool:
     return n_fft == 2048 and 1 <= n_mels <= 256 and mel_config(sr, n_fft, n_mels, fmin, fmax).wpacked is not None
 
 
+def fused_pow2_ok(n_fft, n_mels) -> bool:
+    """True when the fused kernel for the other power-of-two frame lengths (stft_mel_pow2.hip) takes this shape."""
+    return is_pow2(n_fft) and 64 <= n_fft <= 1024 and 1 <= n_mels <= 256
+
+
+def _basis_padded(cfg: "MelConfig", n_fft: int):
+    """[16 ceil(M / 16), Fp] zero-padded dense filterbank (Fp = F rounded up to a multiple of 16) on the device."""
+    if getattr(cfg, "basis_padded", None) is None:
+        M, F = cfg.basis_host.shape
+        Mp, Fp = -(-M // 16) * 16, -(-F // 16) * 16
+        bp = np.zeros((Mp, Fp), np.float32)
+        bp[:M, :F] = cfg.basis_host
+        cfg.basis_padded, cfg.Fp = _dev(bp), Fp
+    return cfg.basis_padded, cfg.Fp
+
+
+def _pow2_front(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax):
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if not fused_pow2_ok(n_fft, n_mels):
+        raise SygnalsHipError(f"no fused kernel for n_fft={n_fft}, n_mels={n_mels} (powers of two 64 ... 1024; 2048: stft2048_mel)")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    B, L = y.shape
+    Tn = num_frames(L, n_fft, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    cfg = mel_config(sr, n_fft, n_mels, fmin, fmax)
+    bp, Fp = _basis_padded(cfg, n_fft)
+    win = window_dev(window, n_fft if win_length is None else win_length, n_fft)
+    return y, B, L, Tn, bp, Fp, win, twiddle_rfft_dev(n_fft)
+
+
+def stft_mel_pow2(y: torch.Tensor, sr: float, n_fft: int, hop: int, center: bool = True, window="hann", win_length=None,
+                  n_mels: int = 128, fmin: float = 0.0, fmax=None, power: int = 2) -> torch.Tensor:
+    """Fused STFT(n_fft = 64 ... 1024) -> |X|^power -> mel [B, n_mels, T]: one launch, no spectrogram in HBM."""
+    y, B, L, Tn, bp, Fp, win, tw = _pow2_front(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax)
+    mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
+    rc = lib().syg_stft_mel_pow2_f32(_ptr(y), B, L, y.stride(0), n_fft, hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(bp),
+                                     Fp, n_mels, int(power), _ptr(mel), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_mel_pow2_f32")
+    return mel
+
+
+def mfcc_pow2_fits(n_fft, n_mels, n_frames, n_mfcc) -> bool:
+    return bool(lib().syg_stft_mfcc_pow2_fits(int(n_fft), int(n_mels), int(n_frames), int(n_mfcc)))
+
+
+def stft_mfcc_pow2(y: torch.Tensor, sr: float, n_fft: int, hop: int, center: bool = True, window="hann", win_length=None,
+                   n_mels: int = 128, n_mfcc: int = 13, fmin: float = 0.0, fmax=None, lifter: float = 0.0,
+                   amin: float = 1e-10, top_db: Optional[float] = 80.0, keep_mel: bool = False):
+    """One launch for the other power-of-two frame lengths: [B, L] clips -> MFCC [B, n_mfcc, T] (a workgroup owns a
+    clip; its mel matrix stays in LDS).  Returns (mfcc, mel_power | None)."""
+    y, B, L, Tn, bp, Fp, win, tw = _pow2_front(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax)
+    if not mfcc_pow2_fits(n_fft, n_mels, Tn, n_mfcc):
+        raise SygnalsHipError("stft_mfcc_pow2: the clip's mel matrix does not fit the LDS; use stft_mel_pow2 + logmel_dct")
+    dct = _cached(("dct", n_mfcc, n_mels, 2, "ortho"), lambda: _dev(T.dct_matrix(n_mfcc, n_mels, 2, "ortho")))
+    lw = T.lifter_weights(n_mfcc, lifter)
+    lif = None if lw is None else _dev(lw)
+    mf = torch.empty((B, n_mfcc, Tn), dtype=torch.float32, device=y.device)
+    mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device) if keep_mel else None
+    rc = lib().syg_stft_mfcc_pow2_f32(_ptr(y), B, L, y.stride(0), n_fft, hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(bp),
+                                      Fp, n_mels, _ptr(dct), n_mfcc, None if lif is None else _ptr(lif), float(amin),
+                                      -1.0 if top_db is None else float(top_db), 1, 1.0,
+                                      None if mel is None else _ptr(mel), _ptr(mf), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_mfcc_pow2_f32")
+    return mf, mel
+
+
 def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
                  win_length: int = 2048, n_mels: int = 128, fmin: float = 0.0, fmax=None,
                  want_stats=False, roll_percent: float = 0.85, bw_p: float = 2.0,
@@ -308,6 +378,17 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
     fused=None picks the one-launch clip-resident form when the clip's mel matrix fits in LDS and there are
     enough clips to fill the chip (a workgroup owns whole clips); True / False force either form.
     """
+    if n_fft != 2048 and fused_pow2_ok(n_fft, n_mels) and fused is not False:
+        # the other power-of-two frame lengths.  fused=True: ONE launch (a workgroup owns a clip, needs the clip's mel
+        # matrix to fit the LDS).  Default: the tile kernel + logmel_dct -- two launches, but three workgroups per CU
+        # instead of two (n_fft 1024: 231 + 17 us against 318 us per 1024 clips x 1 s); one launch where that is faster
+        # (the other lengths, whose tile kernel is the LDS Stockham form)
+        fits = mfcc_pow2_fits(n_fft, n_mels, num_frames(y.shape[1], n_fft, hop, center), n_mfcc)
+        if fused and not fits:
+            raise SygnalsHipError("mfcc_batch: the clip's mel matrix does not fit the LDS of the one-launch form")
+        if fits and (fused or n_fft != 1024):
+            return stft_mfcc_pow2(y, sr, n_fft, hop, center, window, None, n_mels, n_mfcc, fmin, fmax, lifter)[0]
+        return logmel_dct(stft_mel_pow2(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)[1]
     if not fused_mel_ok(sr, n_fft, n_mels, fmin, fmax):
         # no fused kernel for this shape: complex STFT (any frame length) -> |X|^2 -> dense mel -> dB + DCT
         if fused:

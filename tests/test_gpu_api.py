@@ -245,6 +245,12 @@ def test_compute_cqt_vs_oracle():
         compute_cqt(np.zeros((2, 100)), sr)
     with pytest.raises(ValueError, match="Nyquist"):
         compute_cqt(y2, 8000)
+    # librosa's default spelling of the resampler is accepted (with the logged deviation), another one is refused
+    assert np.array_equal(compute_cqt(y2, 48000, res_type="soxr_hq"), C2)
+    assert np.array_equal(compute_cqt(y2, 48000, res_type="kaiser_halfband"), C2)
+    from sygnals_amd._lib import SygnalsHipError
+    with pytest.raises(SygnalsHipError, match="res_type"):
+        compute_cqt(y2, 48000, res_type="kaiser_best")
 
 
 @pytest.mark.parametrize("path", ["bf16x3", "gemm", "fft"])

@@ -241,3 +241,55 @@ def test_mel_dense_mfma_shapes(ops, n_fft, n_mels, L):
     assert mel.shape == (3, n_mels, Tn)
     for b in range(3):
         assert_parity(mel[b], want[b], TOL, f"dense mel n_fft={n_fft} n_mels={n_mels}")
+
+
+# ---- fused kernel for the other power-of-two frame lengths (stft_mel_pow2.hip): the reference's own tests use 1024 / 256
+@pytest.mark.parametrize("n_fft,hop,n_mels,L,center", [
+    (1024, 256, 40, 48000, True),      # tests/test_features_manager.py:183-220 shape, 1 s @ 48 kHz
+    (1024, 256, 128, 16000, True),     # librosa's default n_mels
+    (512, 128, 40, 22051, True),       # odd length, T not a multiple of 16
+    (256, 64, 13, 4000, True),         # the CLI's small frame
+    (1024, 300, 40, 9000, False),      # center=False, hop that does not divide anything
+    (64, 16, 8, 1000, True),           # the smallest frame
+    (1024, 512, 20, 600, True),        # clip shorter than a frame
+])
+def test_mfcc_batch_other_frame_lengths(ops, n_fft, hop, n_mels, L, center):
+    """mfcc_batch for n_fft != 2048: ONE launch (clip-resident), against the float64 oracle at 1e-5; the mel matrix the
+    same launch can emit, the tile form (mel only) and the generic four-launch chain agree with it."""
+    sr = 48000 if L >= 40000 else 16000
+    Y = O.synth_clips(5, L, sr, seed=n_fft + hop)
+    Y[3] *= 1e-3
+    y = ops.to_device_f32(Y)
+    n_mfcc = min(13, n_mels)
+    want = O.mfcc_batch(Y, sr, n_fft, hop, n_mels, n_mfcc, center)
+    got = ops.mfcc_batch(y, sr, n_fft, hop, n_mels, n_mfcc, center, fused=True).cpu().numpy()      # one launch
+    assert got.shape == want.shape
+    dflt = ops.mfcc_batch(y, sr, n_fft, hop, n_mels, n_mfcc, center).cpu().numpy()                 # default: one or two launches
+    assert peak_rel(dflt, got) <= 2e-6
+    for b in range(len(Y)):
+        assert_parity(got[b], want[b], TOL, f"mfcc n_fft={n_fft} clip {b}")
+    assert ops.mfcc_pow2_fits(n_fft, n_mels, want.shape[2], n_mfcc)
+    mf1, mel1 = ops.stft_mfcc_pow2(y, sr, n_fft, hop, center, "hann", None, n_mels, n_mfcc, keep_mel=True)
+    assert np.array_equal(mf1.cpu().numpy(), got)
+    mel_t = ops.stft_mel_pow2(y, sr, n_fft, hop, center, "hann", None, n_mels).cpu().numpy()
+    assert np.array_equal(mel1.cpu().numpy(), mel_t)                         # clip form and tile form: same bits
+    S = [np.abs(O.stft(Y[b].astype(np.float64), n_fft, hop, n_fft, "hann", center)) ** 2 for b in range(len(Y))]
+    for b in range(len(Y)):
+        assert_parity(mel_t[b], O.melspectrogram(S[b], sr, n_fft, n_mels), TOL, f"mel n_fft={n_fft} clip {b}")
+    generic = ops.mfcc_batch(y, sr, n_fft, hop, n_mels, n_mfcc, center, fused=False).cpu().numpy()
+    assert peak_rel(generic, got) <= 2e-6
+    # magnitude mel (power = 1), the manager's melspec 'power' parameter
+    mel_m = ops.stft_mel_pow2(y, sr, n_fft, hop, center, "hann", None, n_mels, power=1).cpu().numpy()
+    for b in (0, 3):
+        assert_parity(mel_m[b], O.mel_filterbank(sr, n_fft, n_mels).astype(np.float64) @ np.sqrt(S[b]), TOL, "magnitude mel")
+
+
+def test_mfcc_other_frame_length_long_clip_two_launch(ops):
+    """A clip whose mel matrix does not fit the LDS beside the transform buffers takes the tile kernel + logmel_dct."""
+    sr, n_fft, hop, n_mels = 16000, 1024, 64, 128
+    Y = O.synth_clips(2, 60000, sr, seed=5)
+    assert not ops.mfcc_pow2_fits(n_fft, n_mels, 1 + 60000 // hop, 13)
+    got = ops.mfcc_batch(ops.to_device_f32(Y), sr, n_fft, hop, n_mels, 13).cpu().numpy()
+    want = O.mfcc_batch(Y, sr, n_fft, hop, n_mels, 13)
+    for b in range(2):
+        assert_parity(got[b], want[b], TOL, "long clip")

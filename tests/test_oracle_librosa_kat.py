@@ -207,6 +207,38 @@ def test_cqt_closed_form_amplitude():
         assert abs(mid[k] - 0.25 * np.sqrt(Q * sr / f[k])) <= 0.02 * mid[k]
 
 
+def test_cqt_decimator_response():
+    """The stated deviation of a15, as numbers: the octave decimator is a 41-tap half-band FIR (Kaiser
+    beta 10) -- stop band <= -99 dB from 0.66 pi (librosa's soxr_hq: about -125 dB), pass band within 1.3e-5 up to
+    0.34 pi (the band the next octave's wavelets use under librosa's early-downsampling rule), half of its taps zero."""
+    import scipy.signal
+    h = O.cqt_decimation_taps()
+    assert h.shape == (41,) and abs(h.sum() - 1.0) < 1e-12 and np.allclose(h, h[::-1], atol=0, rtol=0)
+    assert np.all(np.abs(h[20 + 2::2]) < 1e-16)                                 # half-band: zero at even offsets
+    w = np.linspace(0, np.pi, 4097)
+    H = np.abs(scipy.signal.freqz(h, worN=w)[1])
+    assert np.max(H[w >= 0.66 * np.pi]) <= 1.2e-5                               # -99 dB
+    assert np.max(np.abs(H[w <= 0.34 * np.pi] - 1.0)) <= 1.4e-5
+    assert np.max(H[w >= 0.83 * np.pi]) <= 5e-6                                 # what folds onto the C5 plan's band
+    # a decimated in-band tone keeps its amplitude (x sqrt(2): librosa's scale=True), an out-of-band one is removed
+    n = np.arange(1 << 14)
+    for f, want in ((0.05, np.sqrt(2.0)), (0.15, np.sqrt(2.0)), (0.42, 0.0), (0.49, 0.0)):   # cycles per input sample
+        z = O.cqt_resample2(np.cos(2 * np.pi * f * n))[200:-200]
+        assert abs(np.abs(z).max() - want) <= 2e-5 * np.sqrt(2.0), (f, np.abs(z).max())
+
+
+def test_cqt_against_librosa_where_installed():
+    """Bounds the restatement against the real librosa.cqt (res_type='soxr_hq') -- runs only where librosa is
+    installed (not in the build image: parity for this row stays unpinned there)."""
+    librosa = pytest.importorskip("librosa")
+    sr = 48000
+    y = O.synth_clips(1, 2 * sr, sr, seed=3)[0].astype(np.float64)
+    ref = librosa.cqt(y, sr=sr)
+    got = O.cqt(y, sr)
+    inner = slice(20, -20)
+    assert np.max(np.abs(np.abs(got) - np.abs(ref))[:, inner]) <= 2e-4 * np.abs(ref).max()
+
+
 def test_cqt_plan_schedule():
     p = O.cqt_plan(48000)
     assert p["early"] == 1 and [o["hop"] for o in p["octaves"]] == [256, 128, 64, 32, 16, 8, 4]

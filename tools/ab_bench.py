@@ -21,6 +21,9 @@ Y = synth_clips(64, 48000, 48000, seed=1); y = ops.to_device_f32(np.tile(Y, (B /
 CP = T.contrast_plan(np.fft.rfftfreq(2048, 1 / 48000), 48000)
 fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "mel": lambda: ops.stft2048_mel(y, 48000, n_mels=40),
+      "mfcc1024": lambda: ops.stft_mfcc_pow2(y, 48000, 1024, 256, True, "hann", None, 40, 13),
+      "mel1024": lambda: ops.stft_mel_pow2(y, 48000, 1024, 256, True, "hann", None, 40),
+      "mfcc512": lambda: ops.stft_mfcc_pow2(y, 48000, 512, 128, True, "hann", None, 40, 13),
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
 for _ in range(400): fn()
 torch.cuda.synchronize()

@@ -2,7 +2,7 @@
 Prints one line per row: time, input Msamples/s and algorithmic GB/s (bytes per SURVEY 8d).
 
     python tools/row_bench.py [substring ...]     only the rows whose name contains one of the substrings
-    ROWS_OUT=path                                 where the JSON goes (default gpurun_out/rows_r02.json)
+    ROWS_OUT=path                                 where the JSON goes (default gpurun_out/rows_r03.json)
 """
 import json, os, sys, time
 import numpy as np, torch
@@ -41,6 +41,17 @@ for _ in range(300): ops.mfcc_batch(y, SR, n_mels=40)       # clock warm-up
 Tn = 94
 report("C2 a1-a5 STFT->mel->MFCC (one launch)", lambda: ops.mfcc_batch(y, SR, n_mels=40), B * L, B * (4 * L + 4 * 13 * Tn), n=100)
 report("a1 complex STFT 2048/512 (frame-major c64 out)", lambda: ops.stft2048_c2c(y[:256]), 256 * L, 256 * (4 * L + 8 * 1025 * Tn), "256 clips")
+# the other power-of-two frame lengths (the reference's tests: 1024 / 256): one launch, clip-resident
+for nf, hp in ((1024, 256), (512, 128)):
+    Tf = 1 + L // hp
+    report(f"a1-a5 STFT->mel->MFCC n_fft={nf} hop={hp} (mfcc_batch default, 1024 clips)", lambda: ops.mfcc_batch(y, SR, nf, hp, n_mels=40), B * L,
+           B * (4 * L + 4 * 13 * Tf))
+    report(f"a1-a5 n_fft={nf} hop={hp} ONE launch (clip-resident, fused=True)", lambda: ops.mfcc_batch(y, SR, nf, hp, n_mels=40, fused=True), B * L,
+           B * (4 * L + 4 * 13 * Tf))
+    report(f"a1-a5 n_fft={nf} hop={hp} two launches (tile form + logmel_dct)",
+           lambda: ops.logmel_dct(ops.stft_mel_pow2(y, SR, nf, hp, True, "hann", None, 40), 13), B * L, B * (4 * L + 4 * 13 * Tf))
+    report(f"a1-a5 n_fft={nf} hop={hp} generic chain of round 2 (STFT -> |X|^2 -> dense mel -> dB/DCT, 4 launches)",
+           lambda: ops.mfcc_batch(y, SR, nf, hp, n_mels=40, fused=False), B * L, B * (4 * L + 4 * 13 * Tf), n=5, warm=2)
 # C3: band-pass filtfilt then MFCC
 sos = FL.design_butterworth_sos((300.0, 3400.0), SR, 4, "bandpass")
 report("a13 sosfiltfilt order-4 band-pass (C3 filter alone)", lambda: FL.apply_sos_filter_batch(sos, y), B * L, B * 8 * L)
@@ -88,6 +99,6 @@ if want("f-3 convolution autocorrelation Hilbert periodogram"):
     report("f-3 Hilbert envelope, 1024 rows x 65536", lambda: ops.cabs_pow(D.analytic_batch(y65), 1), 1024 * 65536, 1024 * 8 * 65536)
     report("f-3 Hilbert envelope, 1024 clips x 48000 (mixed radix 200 x 240)", lambda: ops.cabs_pow(D.analytic_batch(y), 1), B * L, B * 8 * L, n=5, warm=2)
     report("f-3 periodogram, 1024 clips x 48000 (mixed radix 200 x 240)", lambda: D.periodogram_batch(y, fs=SR), B * L, B * (4 * L + 4 * (L // 2 + 1)), n=5, warm=2)
-out = os.environ.get("ROWS_OUT", "gpurun_out/rows_r02.json")
+out = os.environ.get("ROWS_OUT", "gpurun_out/rows_r03.json")
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
 json.dump(rows, open(out, "w"), indent=1)
