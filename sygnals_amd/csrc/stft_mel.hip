@@ -66,6 +66,11 @@
 namespace syg {
 namespace {
 
+#ifndef SYG_NOX2
+constexpr bool X2_MEL = true;    // mel-only modes keep 4 |X|^2 in the power rows (see stft2048_kernel)
+#else
+constexpr bool X2_MEL = false;
+#endif
 constexpr int NFFT = 2048;
 constexpr int MC = 1024;         // complex points per frame
 constexpr int NBIN = 1025;
@@ -160,7 +165,9 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
 // behind pass 3 -- the transform's register peak is over there -- so that their L2 latency hides behind the real split
 // and the row stores instead of standing in front of barrier A.
 // PD: priority drop (MODE 1 keeps the top level for its row functions, the transform then runs one level lower)
-template <int NPF, int PD = 0>
+// X2: return 2 X instead of X (the two halvings of the real split are left out; the caller's powers are then 4 |X|^2 --
+// an exact scaling that the mel-only modes take back where the mel values leave the kernel: 32 instructions per frame)
+template <int NPF, int PD = 0, bool X2 = false>
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
                                              const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
                                              int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512,
@@ -263,7 +270,8 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
     for (int q = 0; q < NPF; ++q) pf[q] = pf_src[(int64_t)q * 64 + lp];
   }
   // ---- real split on mirror pairs
-  x512 = make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
+  x512 = X2 ? make_float2(2.f * G[0][2].x, -2.f * G[0][2].y)
+            : make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     float2 zk[4] = {G[j][0], G[j][1], G[j][2], G[j][3]};
@@ -292,8 +300,13 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
       else if (d == 2) rO = make_float2(O.y, -O.x);
       else rO = make_float2(R * (O.y - O.x), -R * (O.x + O.y));
       const float2 wO = cmul(lc.twb[j], rO);
-      xs[j][d] = make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
-      xm[j][d] = make_float2(0.5f * (E.x - wO.x), -0.5f * (E.y - wO.y));
+      if (X2) {
+        xs[j][d] = make_float2(E.x + wO.x, E.y + wO.y);
+        xm[j][d] = make_float2(E.x - wO.x, wO.y - E.y);
+      } else {
+        xs[j][d] = make_float2(0.5f * (E.x + wO.x), 0.5f * (E.y + wO.y));
+        xm[j][d] = make_float2(0.5f * (E.x - wO.x), -0.5f * (E.y - wO.y));
+      }
     }
   }
 }
@@ -998,6 +1011,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr bool COMPLEX_OUT = (MODE == 2);
+  // MODE 0 / 3 (mel only): the power rows hold 4 |X|^2 (wave_rfft2048<.., X2>); the factor is taken back -- exactly, a
+  // power of two -- where mel values leave the kernel (MODE 0: at the store; MODE 3: the dB conversion works on 4 x mel
+  // with 4 x amin and 4 x ref, the optional mel copy is scaled at its store).  MODE 1's statistics need the true powers.
+  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3);
+  constexpr float MELSC = X2 ? 0.25f : 1.f;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Pbuf = lds;
   float* slab = lds + LM::O_SLAB;
@@ -1095,8 +1113,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #ifndef SYG_TAILPRIO
 #define SYG_TAILPRIO 1
 #endif
+    // MODE 0 / 3: projection, clip epilogue and slab combine at the top level, the transform one level lower
+    // (SYG_CPRIO = 3: 150.3 vs 151.0 us for the one-launch MFCC at C2; 0: the round-2 levels)
 #ifndef SYG_CPRIO
-#define SYG_CPRIO 0
+#define SYG_CPRIO 3
 #endif
     constexpr int PD = (MODE == 1) ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0)
                                    : (SYG_CPRIO == 1 || SYG_CPRIO == 3) ? 1 : 0;
@@ -1129,7 +1149,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
       TICK(0, v[0].x);
       float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY, PD>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre TPASS);
+      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY, PD, X2>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre TPASS);
       if (COMPLEX_OUT) {
         float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll
@@ -1286,9 +1306,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
               clipmel[mel * mf.tp + (int)t0 + tt] = sum;     // frames >= T hold 0 (rows were cleared)
               cmax = fmaxf(cmax, sum);                        // power is non-negative
             }
-            if (SYG_ABL != 9 && mel_out != nullptr && mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+            if (SYG_ABL != 9 && mel_out != nullptr && mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = MELSC * sum;
           } else {
-            if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = sum;
+            if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = MELSC * sum;
           }
         }
       }
@@ -1428,6 +1448,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
     per = cper * tiles;
     wgs = cw;
     mf.tp = tiles * WAVES;
+    if (X2_MEL) { mf.amin *= 4.f; mf.ref_value *= 4.f; }     // the clip's mel matrix holds 4 x mel (exact scaling)
     lds += ((size_t)n_mels * mf.tp + WAVES + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
     SYG_REQUIRE(lds <= LDS_LIMIT, "stft2048_mfcc: the clip's mel matrix (%d x %d) does not fit the LDS left over (%zu B > %zu B); "
                 "use syg_stft2048_mel_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
