@@ -282,6 +282,44 @@ __global__ __launch_bounds__(64 * WF_G) void welch_final_kernel(const float* __r
 }
 
 
+// Few streams (config C5: ONE per GPU) leave the kernel above with F / 64 = 33 workgroups for 2048 partial rows: 40 us.
+// Two stages then: stage 1 cuts the partial rows into WF_SLICES contiguous slices (grid z), every slice sums its rows in
+// order into float64 sub-results; stage 2 adds the slices in order and scales.  Same order of additions inside a slice,
+// slices added first to last: deterministic.
+constexpr int WF_SLICES = 16;
+__global__ __launch_bounds__(64 * WF_G) void welch_slice_kernel(const float* __restrict__ partial, int nblk, int F,
+                                                                 double* __restrict__ dsub) {
+  __shared__ double sub[WF_G][64];
+  const int64_t b = blockIdx.y;
+  const int z = blockIdx.z;
+  const int kx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kx;
+  const int per = (nblk + WF_SLICES - 1) / WF_SLICES;
+  const int j0 = z * per, j1 = (j0 + per < nblk) ? j0 + per : nblk;
+  double s = 0.0;
+  if (k < F)
+    for (int j = j0 + g; j < j1; j += WF_G) s += (double)partial[((int64_t)b * nblk + j) * F + k];
+  sub[g][kx] = s;
+  __syncthreads();
+  if (g != 0 || k >= F) return;
+  s = 0.0;
+#pragma unroll
+  for (int i = 0; i < WF_G; ++i) s += sub[i][kx];
+  dsub[((int64_t)b * WF_SLICES + z) * F + k] = s;
+}
+__global__ __launch_bounds__(256) void welch_final2_kernel(const double* __restrict__ dsub, int F, int64_t nseg, double scale,
+                                                           int odd_nfft, float* __restrict__ psd) {
+  const int64_t b = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= F) return;
+  double s = 0.0;
+#pragma unroll
+  for (int z = 0; z < WF_SLICES; ++z) s += dsub[((int64_t)b * WF_SLICES + z) * F + k];
+  s = s * scale / (double)nseg;
+  if (k > 0 && (odd_nfft || k < F - 1)) s *= 2.0;
+  psd[b * (int64_t)F + k] = (float)s;
+}
+
 // Strided variant used to compose large transforms (four-step) on the host side:
 // element e of transform (o, b) lives at in[o*in_os + b*in_bs + e*in_es]; the output may be
 // multiplied by the four-step twiddle W_bign^(b*k) (conjugated for the inverse).
@@ -492,7 +530,28 @@ extern "C" int syg_mel_dense_f32(const float* P, int64_t B, int64_t T, int F, co
 
 extern "C" int64_t syg_welch_work_bytes(int64_t B, int nfft) {
   if (B < 1 || nfft < 2) return -1;
-  return B * (int64_t)welch_nblk(B) * (nfft / 2 + 1) * (int64_t)sizeof(float);
+  // float partial rows, then (8-byte aligned) the float64 slice sums of the two-stage combine
+  const int64_t part = (B * (int64_t)welch_nblk(B) * (nfft / 2 + 1) * (int64_t)sizeof(float) + 7) & ~(int64_t)7;
+  return part + B * WF_SLICES * (int64_t)(nfft / 2 + 1) * (int64_t)sizeof(double);
+}
+
+// combine the partial rows: one stage when the streams alone fill the chip, two stages otherwise
+static int welch_combine(const float* work, int64_t B, int nblk, int F, int64_t nseg, double scale, float* psd_out,
+                         hipStream_t st) {
+  if (B * ((F + 63) / 64) >= 512 || nblk < 4 * WF_SLICES) {
+    hipLaunchKernelGGL(welch_final_kernel, dim3((F + 63) / 64, (unsigned)B), dim3(64 * WF_G), 0, st, work, nblk, F, nseg, scale,
+                       0, psd_out);
+    SYG_CHECK_LAUNCH("welch_final");
+    return SYG_OK;
+  }
+  const int64_t part = (B * (int64_t)welch_nblk(B) * F * (int64_t)sizeof(float) + 7) & ~(int64_t)7;
+  double* dsub = reinterpret_cast<double*>(reinterpret_cast<char*>(const_cast<float*>(work)) + part);
+  hipLaunchKernelGGL(welch_slice_kernel, dim3((F + 63) / 64, (unsigned)B, WF_SLICES), dim3(64 * WF_G), 0, st, work, nblk, F, dsub);
+  SYG_CHECK_LAUNCH("welch_slice");
+  hipLaunchKernelGGL(welch_final2_kernel, dim3((F + 255) / 256, (unsigned)B), dim3(256), 0, st, (const double*)dsub, F, nseg,
+                     scale, 0, psd_out);
+  SYG_CHECK_LAUNCH("welch_final2");
+  return SYG_OK;
 }
 
 extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg, int step, int nfft,
@@ -518,19 +577,13 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
     if ((int64_t)nblk > nseg) nblk = (int)((nseg + 3) & ~(int64_t)3);
     rc = welch_wave_launch(x, B, ldx, step, nseg, window, twiddle, detrend, nblk, (float*)work, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(welch_final_kernel, dim3((F + 63) / 64, (unsigned)B), dim3(64 * WF_G), 0, st, (const float*)work,
-                       nblk, F, nseg, 0.25 * scale, 0, psd_out);
-    SYG_CHECK_LAUNCH("welch_final");
-    return SYG_OK;
+    return welch_combine((const float*)work, B, nblk, F, nseg, 0.25 * scale, psd_out, st);
   }
   if ((int64_t)nblk > nseg) nblk = (int)nseg;
   hipLaunchKernelGGL(welch_partial_kernel, dim3(nblk, (unsigned)B), dim3(WELCH_NT), lds, st, x, L, ldx, nperseg,
                      step, nfft, nseg, window, (const float2*)twiddle, detrend, (float*)work);
   SYG_CHECK_LAUNCH("welch_partial");
-  hipLaunchKernelGGL(welch_final_kernel, dim3((F + 63) / 64, (unsigned)B), dim3(64 * WF_G), 0, st, (const float*)work,
-                     nblk, F, nseg, scale, 0, psd_out);
-  SYG_CHECK_LAUNCH("welch_final");
-  return SYG_OK;
+  return welch_combine((const float*)work, B, nblk, F, nseg, scale, psd_out, st);
 }
 
 extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t outer, int64_t batch, int n,
