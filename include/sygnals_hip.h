@@ -11,7 +11,11 @@
  *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
  *   - the caller owns every buffer (inputs, outputs, tables, workspaces); the library
  *     allocates nothing; its only state is a thread-local error string (no caches keyed by shape or
- *     device: kernel attributes are set at every launch, the CU count is queried per call);
+ *     device: kernel attributes are set at every launch, the CU count is queried per call).  A few
+ *     DEVELOPMENT switches are read from the environment at every call and select between kernels
+ *     that the tests hold to the same results (unset in production): SYGNALS_AMD_RESERVE_CUS,
+ *     SYGNALS_AMD_LOAD (syg_stft2048_*), SYGNALS_AMD_SOS_CLIP (syg_sosfiltfilt_*), SYGNALS_AMD_CQT_STAGED,
+ *     SYGNALS_AMD_CQT_RT, SYGNALS_AMD_CQT_WAVES (syg_cqt_octave_*) -- listed in INTEGRATION.md section 4b;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
  *     enqueue work on it and never synchronise;
  *   - return value: 0 on success, negative SYG_E_* on error, message via syg_last_error();
@@ -228,7 +232,8 @@ int syg_contrast_db_f32(const float* pv, int64_t B, int R, int64_t T, float amin
  *   sos_host    HOST float64 [n_sections, 6]
  *   zi_host     HOST float64 [n_sections, 2]  sosfilt_zi(sos)
  *   padlen      edge extension length (3*ntaps rule), must be < L
- *   work        device workspace of syg_sosfiltfilt_work_bytes(B, L, padlen, n_sections) bytes
+ *   work        device workspace of syg_sosfiltfilt_work_bytes(B, L, padlen, n_sections) bytes; that is 0 for
+ *               clips the clip-resident form takes (L + 2 padlen <= 65536, <= 4 sections): work may then be NULL
  * ------------------------------------------------------------------------------- */
 int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, int n_sections);
 int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const double* sos_host,

@@ -129,10 +129,14 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
             power = mp.get("power", 2.0)
             roll = feature_params.get("spectral_rolloff", {}).get("roll_percent", 0.85)
             bw_p = float(feature_params.get("spectral_bandwidth", {}).get("p", 2))
-            if not 0.0 <= roll <= 1.0:
-                raise ValueError("roll_percent must be between 0.0 and 1.0.")
-            if bw_p <= 0:
-                raise ValueError("Order 'p' for spectral bandwidth must be positive.")
+            # a bad parameter of ONE feature must only cost that feature (frequency_domain.py:116, 314 raise inside the
+            # per-feature try of manager.py:304-316): the shared launch runs with the default in its place and the
+            # feature's own branch below raises
+            cache["roll_ok"], cache["bw_ok"] = 0.0 <= roll <= 1.0, bw_p > 0
+            if not cache["roll_ok"]:
+                roll = 0.85
+            if not cache["bw_ok"]:
+                bw_p = 2.0
             cplan = None
             if want_contrast:
                 cplan = T.contrast_plan(freqs, sr, cp.get("n_bands", 6), cp.get("fmin", 200.0), cp.get("quantile", 0.02))
@@ -205,6 +209,10 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 items.append((name, host(rows[name])))
             elif name in _SPECTRUM_BASED:
                 _, stats, _, cur_T = stft_products()
+                if name == "spectral_rolloff" and not cache["roll_ok"]:
+                    raise ValueError("roll_percent must be between 0.0 and 1.0.")
+                if name == "spectral_bandwidth" and not cache["bw_ok"]:
+                    raise ValueError("Order 'p' for spectral bandwidth must be positive.")
                 if name == "spectral_bandwidth" and "spectral_centroid" not in res:
                     logger.warning("Feature 'spectral_bandwidth' requires 'spectral_centroid', calculating it first.")
                     res["spectral_centroid"] = host(stats[:, 0])

@@ -375,9 +375,16 @@ int launch_all(const float* x, int64_t B, int64_t L, int64_t ldx, const SosParam
 
 using namespace syg;
 
+// true when the clip-resident form (both sweeps in one launch, no workspace) takes this shape
+static bool clip_resident(int64_t lext, int n_sections) {
+  const char* e = getenv("SYGNALS_AMD_SOS_CLIP");      // development switch: =0 keeps the chunked path
+  return sos_clip_chunk(lext) > 0 && sos_clip_supported(n_sections) && !(e && e[0] == '0');
+}
+
 extern "C" int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, int n_sections) {
   if (B < 1 || L < 1 || padlen < 0 || n_sections < 1 || n_sections > MAXS) return -1;
   const int64_t lext = L + 2 * (int64_t)padlen;
+  if (clip_resident(lext, n_sections)) return 0;        // the clip stays in registers: `work` may be NULL
   const int64_t nch = (lext + (CS - 1) + CS - 1) / CS;   // grid = sequence + up to CS - 1 alignment positions
   return B * nch * CS * (int64_t)sizeof(float) + 2 * B * nch * 2 * n_sections * (int64_t)sizeof(double);
 }
@@ -385,7 +392,7 @@ extern "C" int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, 
 extern "C" int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t ldx, const double* sos_host,
                                    const double* zi_host, int n_sections, int padlen, float* y, int64_t ldy,
                                    void* work, void* stream) {
-  SYG_REQUIRE(x && y && sos_host && zi_host && work, "sosfiltfilt: null pointer argument");
+  SYG_REQUIRE(x && y && sos_host && zi_host, "sosfiltfilt: null pointer argument");
   SYG_REQUIRE(n_sections >= 1 && n_sections <= MAXS, "sosfiltfilt: n_sections must be in [1, %d] (got %d)", MAXS,
               n_sections);
   SYG_REQUIRE(B >= 1 && B <= 65535 && L >= 2 && ldx >= L && ldy >= L, "sosfiltfilt: bad B/L/ld");
@@ -420,8 +427,7 @@ extern "C" int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t
   {
     const int64_t lext = L + 2 * (int64_t)padlen;
     const int cs = sos_clip_chunk(lext);
-    const char* e = getenv("SYGNALS_AMD_SOS_CLIP");
-    if (cs > 0 && sos_clip_supported(S) && !(e && e[0] == '0')) {
+    if (clip_resident(lext, S)) {
       SosClipParams C;
       memset(&C, 0, sizeof(C));
       for (int s = 0; s < S; ++s) {
@@ -437,6 +443,7 @@ extern "C" int syg_sosfiltfilt_f32(const float* x, int64_t B, int64_t L, int64_t
       return SYG_OK;
     }
   }
+  SYG_REQUIRE(work, "sosfiltfilt: this shape takes the chunked path and needs the work buffer of syg_sosfiltfilt_work_bytes");
   mat_pow(A1, D, CS, P.apow);
   switch (S) {
     case 1: return launch_all<1>(x, B, L, ldx, P, padlen, y, ldy, work, st);

@@ -380,13 +380,12 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
     """
     if n_fft != 2048 and fused_pow2_ok(n_fft, n_mels) and fused is not False:
         # the other power-of-two frame lengths.  fused=True: ONE launch (a workgroup owns a clip, needs the clip's mel
-        # matrix to fit the LDS).  Default: the tile kernel + logmel_dct -- two launches, but three workgroups per CU
-        # instead of two (n_fft 1024: 231 + 17 us against 318 us per 1024 clips x 1 s); one launch where that is faster
-        # (the other lengths, whose tile kernel is the LDS Stockham form)
+        # matrix to fit the LDS).  Default: the tile kernel + logmel_dct -- two launches, but more workgroups per CU
+        # (n_fft 1024: 266 us against 318 us per 1024 clips x 1 s; n_fft 512: 709 against 973 us)
         fits = mfcc_pow2_fits(n_fft, n_mels, num_frames(y.shape[1], n_fft, hop, center), n_mfcc)
         if fused and not fits:
             raise SygnalsHipError("mfcc_batch: the clip's mel matrix does not fit the LDS of the one-launch form")
-        if fits and (fused or n_fft != 1024):
+        if fits and fused:
             return stft_mfcc_pow2(y, sr, n_fft, hop, center, window, None, n_mels, n_mfcc, fmin, fmax, lifter)[0]
         return logmel_dct(stft_mel_pow2(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)[1]
     if not fused_mel_ok(sr, n_fft, n_mels, fmin, fmax):
@@ -612,10 +611,12 @@ def sosfiltfilt(x: torch.Tensor, sos: np.ndarray, zi: np.ndarray, padlen: int) -
     nbytes = lib().syg_sosfiltfilt_work_bytes(B, L, padlen, S)
     if nbytes < 0:
         raise SygnalsHipError(f"sosfiltfilt: unsupported configuration (sections={S}, max 8)")
-    work = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+    # (0 bytes: the clip-resident form keeps the clip in registers and needs no workspace)
+    work = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device) if nbytes > 0 else None
     y = torch.empty((B, L), dtype=torch.float32, device=x.device)
     rc = lib().syg_sosfiltfilt_f32(_ptr(x), B, L, _ld(x), sos.ctypes.data_as(C.c_void_p),
-                                   zi.ctypes.data_as(C.c_void_p), S, int(padlen), _ptr(y), _ld(y), _ptr(work),
+                                   zi.ctypes.data_as(C.c_void_p), S, int(padlen), _ptr(y), _ld(y),
+                                   None if work is None else _ptr(work),
                                    C.c_void_p(_stream_ptr()))
     check(rc, "syg_sosfiltfilt_f32")
     return y

@@ -500,6 +500,19 @@ def test_a_failing_feature_leaves_the_others_in_the_output(monkeypatch, caplog):
     out2 = M.extract_features(y, 16000, ["spectral_rolloff", "rms_energy"], output_format="dict_of_arrays",
                               feature_params={"spectral_rolloff": {"roll_percent": 1.5}})
     assert list(out2) == ["time", "rms_energy"]
+    # ... and costs ONLY the offending feature: the other STFT-based ones still come out (the reference validates inside
+    # each feature's own try, frequency_domain.py:116, 314)
+    with caplog.at_level(logging.ERROR):
+        out3 = M.extract_features(y, 16000, ["spectral_centroid", "spectral_rolloff", "spectral_bandwidth", "mfcc"],
+                                  output_format="dict_of_arrays",
+                                  feature_params={"spectral_rolloff": {"roll_percent": 1.5}, "spectral_bandwidth": {"p": 0},
+                                                  "mfcc": {"n_mels": 40}})
+    assert "spectral_rolloff" not in out3 and "spectral_bandwidth" not in out3
+    assert "roll_percent must be between 0.0 and 1.0." in caplog.text and "must be positive" in caplog.text
+    ref3 = O.extract_features(y, 16000, ["spectral_centroid", "mfcc"], feature_params={"mfcc": {"n_mels": 40}})
+    assert set(out3) == set(ref3)
+    for k in ref3:
+        assert_parity(out3[k], ref3[k], TOL, k)
 
 
 def test_odd_frame_length_retimes_from_the_stft_like_the_reference():
