@@ -299,7 +299,7 @@ def extract_features(y, sr: int, features: List[str], frame_length: int = 2048, 
 
 # ------------------------------------------------------------------ config C4: the packed per-clip feature block
 def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: int = 13, roll_percent: float = 0.85,
-                  n_bands: int = 6, fmin_contrast: float = 200.0, quantile: float = 0.02, out=None):
+                  n_bands: int = 6, fmin_contrast: float = 200.0, quantile: float = 0.02, out=None, one_launch=None):
     """BASELINE config C4 on the device: y [B, L] float32 device clips -> [B, n_mfcc + 2 + (n_bands + 1), T] float32,
     rows = mfcc_0..mfcc_{n-1}, spectral_centroid (Hz), spectral_rolloff (Hz), contrast_band_0..{n_bands-1},
     contrast_delta -- the columns `extract_features(["mfcc", "spectral_centroid", "spectral_rolloff",
@@ -315,14 +315,38 @@ def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: i
     rows = n_mfcc + 2 + R
     if out is None:
         out = torch.empty((B, rows, Tn), dtype=torch.float32, device=y.device)
-    mel, stats, cpv = ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8, roll_percent,
-                                       2.0, cplan)
     dct = ops._cached(("dct", n_mfcc, n_mels, 2, "ortho"), lambda: ops._dev(T.dct_matrix(n_mfcc, n_mels, 2, "ortho")))
     import ctypes as C
     from ..._lib import check, lib
+    st = C.c_void_p(ops._stream_ptr())
+    # one_launch=True: everything from ONE fused launch (syg_stft2048_features_f32, the mel matrix never reaches HBM) +
+    # the small rows kernel.  Measured SLOWER than mel -> feature_block at C4's shape (735 vs 724 us per 2048 clips: the
+    # clip epilogue occupies six of the sixteen waves while the others wait at the tile barrier), so it is not the default.
+    if one_launch is None:
+        one_launch = False
+    if one_launch and not (ops.mfcc_fused_fits(n_mels, Tn, n_mfcc) and ops.fused_waves() == 16):
+        raise SygnalsHipError("feature_block: the one-launch form needs the clip's mel matrix to fit the LDS (16-wave plan)")
+    if one_launch:
+        # ONE fused launch: samples in; MFCC rows straight into the head of the block, statistics rows and contrast tail
+        # means out (the mel matrix stays in LDS) -- then the small kernel that turns those into the block's other rows
+        cfg = ops.mel_config(sr, 2048, n_mels, 0.0, None, waves=16)
+        stats = torch.empty((B, 8, Tn), dtype=torch.float32, device=y.device)       # (only the rows read below are written)
+        cpv = torch.empty((B, 2, R, Tn), dtype=torch.float32, device=y.device)
+        rc = lib().syg_stft2048_features_f32(ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn,
+                                             ops._ptr(ops.window_dev("hann", 2048, 2048)), ops._ptr(ops.twiddle_dev(2048)),
+                                             ops._ptr(cfg.wpacked), cfg.plan.ctypes.data_as(C.c_void_p), n_mels, ops._ptr(dct),
+                                             n_mfcc, None, 1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), 2.0, 1 | 8,
+                                             ops._ptr(stats), np.ascontiguousarray(cplan, np.int32).ctypes.data_as(C.c_void_p),
+                                             ops._ptr(cpv), None, ops._ptr(out), rows, st)
+        check(rc, "syg_stft2048_features_f32")
+        rc = lib().syg_feature_block_f32(None, B, n_mels, Tn, None, n_mfcc, 1e-10, 80.0, ops._ptr(stats), float(sr) / 2048.0,
+                                         ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out), st)
+        check(rc, "syg_feature_block_f32")
+        return out
+    mel, stats, cpv = ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8, roll_percent,
+                                       2.0, cplan)
     rc = lib().syg_feature_block_f32(ops._ptr(mel), B, n_mels, Tn, ops._ptr(dct), n_mfcc, 1e-10, 80.0, ops._ptr(stats),
-                                     float(sr) / 2048.0, ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out),
-                                     C.c_void_p(ops._stream_ptr()))
+                                     float(sr) / 2048.0, ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out), st)
     check(rc, "syg_feature_block_f32")
     return out
 

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(NT) void feature_block_kernel(const float* __restri
   float* ob = out + b * (int64_t)rows * T;
   const int64_t n = (int64_t)M * T, nc = (int64_t)R * T;
   float mx = 0.f, m0 = 0.f, m1 = 0.f;       // powers and magnitudes are non-negative
-  for (int64_t i = tid; i < n; i += NT) mx = fmaxf(mx, src[i]);
+  const bool have_mel = mel != nullptr;     // (null: rows 0 .. K-1 were written by syg_stft2048_features_f32)
+  if (have_mel)
+    for (int64_t i = tid; i < n; i += NT) mx = fmaxf(mx, src[i]);
   for (int64_t i = tid; i < nc; i += NT) { m0 = fmaxf(m0, pk[i]); m1 = fmaxf(m1, vl[i]); }
   mx = wave_max(mx); m0 = wave_max(m0); m1 = wave_max(m1);
   if (lane == 0) { red[0][w] = mx; red[1][w] = m0; red[2][w] = m1; }
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(NT) void feature_block_kernel(const float* __restri
   // (the same expressions as logmel_dct_kernel / contrast_db_kernel: the two forms give identical values)
   const float reflog = log10f(fmaxf(amin, mx));
   const float flo = (top_db >= 0.f) ? 10.f * (log10f(fmaxf(amin, mx)) - reflog) - top_db : -3.4e38f;
-  for (int64_t i = tid; i < n; i += NT) db[i] = fmaxf(10.f * (log10f(fmaxf(amin, src[i])) - reflog), flo);
+  if (have_mel)
+    for (int64_t i = tid; i < n; i += NT) db[i] = fmaxf(10.f * (log10f(fmaxf(amin, src[i])) - reflog), flo);
   const float f0 = (c_top_db >= 0.f) ? 10.f * log10f(fmaxf(c_amin, m0)) - c_top_db : -3.4e38f;
   const float f1 = (c_top_db >= 0.f) ? 10.f * log10f(fmaxf(c_amin, m1)) - c_top_db : -3.4e38f;
   for (int64_t i = tid; i < nc; i += NT) {
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(NT) void feature_block_kernel(const float* __restri
     ob[(int64_t)K * T + t] = st[SYG_STAT_CENTROID * T + t];
     ob[(int64_t)(K + 1) * T + t] = st[SYG_STAT_ROLLOFF_BIN * T + t] * binhz;
   }
+  if (!have_mel) return;
   __syncthreads();
   const int ktiles = (K + 15) / 16, ttiles = (int)((T + 15) / 16);
   const int f = lane & 15, g = lane >> 4;
@@ -165,11 +169,11 @@ using namespace syg;
 extern "C" int syg_feature_block_f32(const float* mel, int64_t B, int M, int64_t T, const float* dct, int K, float amin,
                                      float top_db, const float* stats, float binhz, const float* contrast_pv, int R,
                                      float c_amin, float c_top_db, float* block_out, void* stream) {
-  SYG_REQUIRE(mel && dct && stats && contrast_pv && block_out, "feature_block: null pointer argument");
+  SYG_REQUIRE((dct || !mel) && stats && contrast_pv && block_out, "feature_block: null pointer argument");
   SYG_REQUIRE(B >= 1 && B < (int64_t)0x7fffffff && M >= 1 && T >= 1 && K >= 1 && K <= M && R >= 1,
               "feature_block: bad shape (B=%lld M=%d T=%lld K=%d R=%d)", (long long)B, M, (long long)T, K, R);
   SYG_REQUIRE(amin > 0.f && c_amin > 0.f, "feature_block: amin must be strictly positive");
-  const size_t lds = (size_t)M * (size_t)T * sizeof(float);
+  const size_t lds = mel ? (size_t)M * (size_t)T * sizeof(float) : 0;       // (mel == NULL: only the statistics / contrast rows)
   SYG_REQUIRE(lds <= 150 * 1024, "feature_block: the clip's dB matrix (%d x %lld) does not fit LDS; use "
               "syg_logmel_dct_f32 + syg_contrast_db_f32", M, (long long)T);
   if (lds > 64 * 1024) {

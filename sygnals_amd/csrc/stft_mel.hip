@@ -115,6 +115,7 @@ struct MfccArgs {
   int ref_is_max;        // 1: reference = max of the clip's mel powers, 0: ref_value
   float ref_value, amin, top_db;   // top_db < 0: no floor
   int tp;                // padded frames per clip (tiles_per_clip * TILE_T): row stride of the LDS mel matrix
+  int rows_per_clip;     // rows between two clips of `out` (n_mfcc, or more when the MFCCs are the head of a wider block)
 };
 
 // exchange 2 (half buffer by c' & 7, planar in b'): slot of group (c, c') inside a plane
@@ -878,8 +879,75 @@ __device__ __forceinline__ MfccArgs uni(const MfccArgs& a) {
   MfccArgs u;
   u.dct = uni(a.dct); u.lifter = uni(a.lifter); u.out = uni(a.out); u.n_mfcc = uni(a.n_mfcc);
   u.ref_is_max = uni(a.ref_is_max); u.ref_value = uni(a.ref_value); u.amin = uni(a.amin); u.top_db = uni(a.top_db);
-  u.tp = uni(a.tp);
+  u.tp = uni(a.tp); u.rows_per_clip = uni(a.rows_per_clip);
   return u;
+}
+
+// The LEADING bands with k = 1 that end at or below bin 192 (C4: five of the seven bands, bins 0 ... 135) in ONE pass: the
+// bins sit in three strided registers (bin lane + 64 r); band b's largest power goes to slot 2 b, the negative of its
+// smallest to slot 2 b + 1 (so that all sixteen slots are MAX reductions), and the sixteen slots are reduced over the wave
+// together by a butterfly that halves the number of live slots at every step: at the step with lane distance d the
+// lanes with bit d clear keep the even slot of a pair and hand the odd one to their partner, and vice versa -- 56
+// instructions for sixteen wave-wide reductions instead of sixteen times six.  Afterwards every lane holds the wave's
+// result of slot (lane & 15); lane b fetches its band's two slots through the LDS crossbar.
+// Returns the number of bands taken (0: fewer than two such bands, the caller's loop does everything).
+template <int CTRL>
+__device__ __forceinline__ float dpp_partner(float v) { return dpp_f<CTRL>(v); }
+__device__ __forceinline__ float xor4_partner(float v) {       // lane ^ 4 inside a row: two bank-masked row shifts
+  int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+  t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+  return __int_as_float(t);
+}
+__device__ __forceinline__ int contrast_narrow_group(lds_row prow, int lane, int plo, int phi, int pk, int n_rows,
+                                                     float& rp, float& rv) {
+  // leading run of bands with k == 1 and hi <= 192 (lane = band in plo / phi / pk)
+  const uint64_t okm = __ballot(lane < n_rows && pk == 1 && phi <= 192 && phi > plo);
+  int nb = __ffsll((long long)~okm) - 1;                      // (~okm is never zero: lanes >= 16 are clear)
+  nb = nb > 8 ? 8 : nb;
+#ifdef SYG_NO_NARROW_GROUP
+  return 0;                                                    // (timing variant: every band through the loop)
+#endif
+  if (nb < 2) return 0;
+  lds_row pr = prow + ppos(lane);                              // bin lane + 64 r at ppos(lane) + 68 r
+  const float q0 = pr[0], q1 = pr[68], q2 = pr[136];
+  float v[16];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    float mx = -3.4e38f, mn = -3.4e38f;
+    if (b < nb) {                                              // (wave-uniform)
+      const int lo = __builtin_amdgcn_readlane(plo, b), n = __builtin_amdgcn_readlane(phi, b) - lo;
+      const bool i0 = (unsigned)(lane - lo) < (unsigned)n, i1 = (unsigned)(lane + 64 - lo) < (unsigned)n,
+                 i2 = (unsigned)(lane + 128 - lo) < (unsigned)n;
+      mx = fmaxf(fmaxf(i0 ? q0 : mx, i1 ? q1 : mx), i2 ? q2 : mx);
+      mn = fmaxf(fmaxf(i0 ? -q0 : mn, i1 ? -q1 : mn), i2 ? -q2 : mn);
+    }
+    v[2 * b] = mx; v[2 * b + 1] = mn;
+  }
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float w[8], x[4], y[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    w[j] = fmaxf(b0 ? v[2 * j + 1] : v[2 * j], dpp_partner<DPP_QP_1032>(b0 ? v[2 * j] : v[2 * j + 1]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    x[j] = fmaxf(b1 ? w[2 * j + 1] : w[2 * j], dpp_partner<DPP_QP_2301>(b1 ? w[2 * j] : w[2 * j + 1]));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) y[j] = fmaxf(b2 ? x[2 * j + 1] : x[2 * j], xor4_partner(b2 ? x[2 * j] : x[2 * j + 1]));
+  float z = fmaxf(b3 ? y[1] : y[0], dpp_partner<0x128 /* row_ror:8 = lane ^ 8 */>(b3 ? y[0] : y[1]));
+  // the four rows: lane ^ 16, then lane ^ 32
+  {
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+    z = fmaxf(z, __uint_as_float((lane & 16) ? r16[0] : r16[1]));
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+    z = fmaxf(z, __uint_as_float((lane & 32) ? r32[0] : r32[1]));
+  }
+  // slot s sits in every lane with (lane & 15) == s: lane b takes slots 2 b and 2 b + 1
+  const int src = (2 * lane) & 15;
+  const float pmax = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * src, __float_as_int(z)));
+  const float nmin = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (src + 1), __float_as_int(z)));
+  rp = (lane < nb) ? fsqrt(pmax) : rp;
+  rv = (lane < nb) ? fsqrt(-nmin) : rv;
+  return nb;
 }
 
 // All contrast bands of one row in ONE out-of-line call (a call per band paid the entry / exit sequence and the
@@ -891,7 +959,8 @@ __device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr
   const int lb = lane & (SYG_MAX_BANDS - 1);
   const int plo = cpl[lb], phi = cpl[SYG_MAX_BANDS + lb], pk = cpl[2 * SYG_MAX_BANDS + lb];
   float rp = 0.f, rv = 0.f;
-  for (int r = 0; r < n_rows; ++r) {
+  const int r0 = contrast_narrow_group(prow, lane, plo, phi, pk, n_rows, rp, rv);
+  for (int r = r0; r < n_rows; ++r) {
     const int lo = __builtin_amdgcn_readlane(plo, r), hi = __builtin_amdgcn_readlane(phi, r),
               k = __builtin_amdgcn_readlane(pk, r);
     const float2 pv = band_contrast(prow, lane, lo, hi, k, may_park);
@@ -962,7 +1031,7 @@ __device__ __noinline__ void clip_dct(int clipmel_addr, MfccArgs mfv, int n_mels
       if (k < mf.n_mfcc && tcol < T) {
         float val = acc[r];
         if (mf.lifter) val *= lifl[k];
-        mf.out[(b * mf.n_mfcc + k) * (int64_t)T + tcol] = val;
+        mf.out[(b * mf.rows_per_clip + k) * (int64_t)T + tcol] = val;
       }
     }
   }
@@ -1011,6 +1080,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr bool COMPLEX_OUT = (MODE == 2);
+  // MODE 5 = MODE 1 (statistics / contrast rows) + MODE 3 (clip-resident dB + DCT): config C4's four features from ONE
+  // launch -- only samples in, MFCCs + statistics rows + contrast tail means out (the mel matrix never reaches HBM)
+  constexpr bool ROWFN = (MODE == 1 || MODE == 5);      // per-frame row functions behind barrier B
+  constexpr bool CLIPM = (MODE == 3 || MODE == 5);      // the clip's mel matrix lives in LDS; epilogue at clip end
   // MODE 0 / 3 (mel only): the power rows hold 4 |X|^2 (wave_rfft2048<.., X2>); the factor is taken back -- exactly, a
   // power of two -- where mel values leave the kernel (MODE 0: at the store; MODE 3: the dB conversion works on 4 x mel
   // with 4 x amin and 4 x ref, the optional mel copy is scaled at its store).  MODE 1's statistics need the true powers.
@@ -1055,7 +1128,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   if (tid < 64) tw2l[(tid >> 4) * TW2_STRIDE + (tid & 15)] = twid[32 * (tid >> 4) * (tid & 15)];
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
   for (int i = tid; i < NFFT / 2; i += NTHREADS) winl[i] = win2[i];
-  if (MODE == 3) {
+  if (CLIPM) {
     float* dctl = clipmel + n_mels * mf.tp + WAVES;
     for (int i = tid; i < mf.n_mfcc * n_mels; i += NTHREADS) dctl[i] = mf.dct[i];
     if (mf.lifter != nullptr && tid < mf.n_mfcc) dctl[mf.n_mfcc * n_mels + tid] = mf.lifter[tid];
@@ -1118,7 +1191,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #ifndef SYG_CPRIO
 #define SYG_CPRIO 3
 #endif
-    constexpr int PD = (MODE == 1) ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0)
+    constexpr int PD = ROWFN ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0)
                                    : (SYG_CPRIO == 1 || SYG_CPRIO == 3) ? 1 : 0;
     SETPRIO(3 - PD > 0 ? 3 - PD : 0);
     // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT needs
@@ -1209,8 +1282,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (staged mode: the next tile's samples have landed too)
     __syncthreads();                                    // barrier A: rows complete
     TICK(6, tdep);
-    if (MODE != 1 && SYG_CPRIO == 3) SETPRIO(3);        // experiment: projection (+ clip epilogue) at the top level
-    if (MODE == 3 && pend_b >= 0) {
+    if (!ROWFN && SYG_CPRIO == 3) SETPRIO(3);           // projection (+ clip epilogue) at the top level
+    if (CLIPM && pend_b >= 0) {
       if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6 && SYG_ABL != 7)
         clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, w, lane);
       pend_b = -1;
@@ -1271,12 +1344,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     }
     __syncthreads();                // barrier B: slab complete (and every wave has read its staged frame)
     TICK(8, tdep);
-    if (MODE != 1 && (SYG_CPRIO == 1 || SYG_CPRIO == 2)) SETPRIO(3);      // experiment: the slab combine at the top level
-    const bool clip_done = (MODE == 3) && (t0 + TILE_T >= T);
+    if (!ROWFN && (SYG_CPRIO == 1 || SYG_CPRIO == 2)) SETPRIO(3);         // experiment: the slab combine at the top level
+    const bool clip_done = CLIPM && (t0 + TILE_T >= T);
     // MODE 1 runs out-of-line row functions below: a function entry waits for EVERY outstanding memory operation
     // (s_waitcnt vmcnt(0) -- the callee cannot know the caller's counters), so nothing may be in flight when they are
     // called: the refill of the stage buffer is issued behind them and the tile's stores behind the last call.
-    constexpr bool TAIL = (MODE == 1);
+    constexpr bool TAIL = ROWFN;
     if (!TAIL && FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
 
     // ---- combine the slots of each mel group in a fixed order (ascending bins): one wave per group of four mel rows,
@@ -1301,7 +1374,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           }
           for (; q < cnt; ++q) { sum += sp[0]; sp += GL; }
           const int mel = g * 4 + m;
-          if (MODE == 3) {
+          if (CLIPM) {
             if (mel < n_mels) {
               clipmel[mel * mf.tp + (int)t0 + tt] = sum;     // frames >= T hold 0 (rows were cleared)
               cmax = fmaxf(cmax, sum);                        // power is non-negative
@@ -1313,19 +1386,22 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         }
       }
     };
-    if (!TAIL) combine();
-    if (clip_done) {
+    auto publish = [&]() {
       // last tile of the clip: publish the per-wave maxima; the dB + DCT epilogue runs in the next tile's
       // projection phase (or behind the loop)
       const float cm = wave_max(cmax);
       cmax = 0.f;
       if (lane == 0) clipmel[n_mels * mf.tp + w] = cm;
       pend_b = b;
+    };
+    if (!TAIL) {
+      combine();
+      if (clip_done) publish();
     }
 
     TICK(9, tdep);
     // ---- phase 2b: per-frame statistics / contrast means from the same LDS rows
-    if (MODE == 1 && (stats_out != nullptr || contrast_out != nullptr)) {
+    if (ROWFN && (stats_out != nullptr || contrast_out != nullptr)) {
       if (SYG_TAILPRIO == 1 || SYG_TAILPRIO == 3 || SYG_TAILPRIO == 4) SETPRIO(3);
       if (SYG_TAILPRIO == 2) { if (w >= WAVES / 2) SETPRIO(3); else SETPRIO(2); }   // the younger half would otherwise run on leftovers
       if (t < T) {
@@ -1363,10 +1439,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       if (SYG_TAILPRIO != 0) SETPRIO(0);
       TICK(11, tdep);
       combine();
+      if (clip_done) publish();
       if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
     }
   }
-  if (MODE == 3 && pend_b >= 0) {
+  if (CLIPM && pend_b >= 0) {
     __syncthreads();
     if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6)
       clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, w, lane);
@@ -1441,14 +1518,14 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   int wgs = 0, per = 0;
   persistent_grid(total_tiles, WAVES, wgs, per);
   size_t lds = lds_bytes<WAVES>();
-  if (MODE == 3) {
+  if (MODE == 3 || MODE == 5) {
     // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
     int cw = 0, cper = 0;
     persistent_grid(B, WAVES, cw, cper);
     per = cper * tiles;
     wgs = cw;
     mf.tp = tiles * WAVES;
-    if (X2_MEL) { mf.amin *= 4.f; mf.ref_value *= 4.f; }     // the clip's mel matrix holds 4 x mel (exact scaling)
+    if (X2_MEL && MODE == 3) { mf.amin *= 4.f; mf.ref_value *= 4.f; }     // the clip's mel matrix holds 4 x mel (exact scaling)
     lds += ((size_t)n_mels * mf.tp + WAVES + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
     SYG_REQUIRE(lds <= LDS_LIMIT, "stft2048_mfcc: the clip's mel matrix (%d x %d) does not fit the LDS left over (%zu B > %zu B); "
                 "use syg_stft2048_mel_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
@@ -1464,7 +1541,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   {
     // set at every launch: the attribute belongs to the (function, device) pair, and a per-process "already set"
     // flag would leave a second device without it
-    const size_t cap = (MODE == 3) ? LDS_LIMIT : lds_bytes<WAVES>();
+    const size_t cap = (MODE == 3 || MODE == 5) ? LDS_LIMIT : lds_bytes<WAVES>();
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
@@ -1485,6 +1562,25 @@ using namespace syg;
 
 namespace syg {
 namespace {
+int parse_contrast_plan(const float* contrast_out, const int32_t* cplan_host, ContrastPlan& cp) {
+  memset(&cp, 0, sizeof(cp));
+  if (!contrast_out) return SYG_OK;
+  SYG_REQUIRE(cplan_host, "stft2048: contrast_out given without cplan_host");
+  cp.n_rows = cplan_host[0];
+  SYG_REQUIRE(cp.n_rows >= 1 && cp.n_rows <= SYG_MAX_BANDS, "stft2048: contrast rows must be in [1, %d]", SYG_MAX_BANDS);
+  for (int r = 0; r < cp.n_rows; ++r) {
+    cp.lo[r] = cplan_host[1 + r];
+    cp.hi[r] = cplan_host[1 + SYG_MAX_BANDS + r];
+    cp.k[r] = cplan_host[1 + 2 * SYG_MAX_BANDS + r];
+    SYG_REQUIRE(cp.lo[r] >= 0 && cp.hi[r] <= NBIN && cp.lo[r] < cp.hi[r] && cp.k[r] >= 1 && cp.k[r] <= cp.hi[r] - cp.lo[r],
+                "stft2048: contrast band %d invalid (lo=%d hi=%d k=%d)", r, cp.lo[r], cp.hi[r], cp.k[r]);
+  }
+  cp.ascending = 1;
+  for (int r = 1; r < cp.n_rows; ++r)
+    if (cp.lo[r] < cp.hi[r - 1] - 1 || cp.hi[r] < cp.hi[r - 1]) cp.ascending = 0;   // (a band may include the bin below it)
+  return SYG_OK;
+}
+
 int parse_mel_plan(const char* who, const int32_t* plan_host, int n_mels, MelPlan& plan) {
   // plan_host: {2 (layout version), waves, steps, n_groups, table_off}
   SYG_REQUIRE(plan_host[0] == 2, "%s: mel plan layout %d, this library needs layout 2 (sygnals_amd._tables.pack_mel_plan)",
@@ -1519,24 +1615,8 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
   rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, waves);
   if (rc) return rc;
   ContrastPlan cp;
-  memset(&cp, 0, sizeof(cp));
-  if (contrast_out) {
-    SYG_REQUIRE(cplan_host, "stft2048_mel: contrast_out given without cplan_host");
-    cp.n_rows = cplan_host[0];
-    SYG_REQUIRE(cp.n_rows >= 1 && cp.n_rows <= SYG_MAX_BANDS, "stft2048_mel: contrast rows must be in [1, %d]",
-                SYG_MAX_BANDS);
-    for (int r = 0; r < cp.n_rows; ++r) {
-      cp.lo[r] = cplan_host[1 + r];
-      cp.hi[r] = cplan_host[1 + SYG_MAX_BANDS + r];
-      cp.k[r] = cplan_host[1 + 2 * SYG_MAX_BANDS + r];
-      SYG_REQUIRE(cp.lo[r] >= 0 && cp.hi[r] <= NBIN && cp.lo[r] < cp.hi[r] && cp.k[r] >= 1 &&
-                      cp.k[r] <= cp.hi[r] - cp.lo[r],
-                  "stft2048_mel: contrast band %d invalid (lo=%d hi=%d k=%d)", r, cp.lo[r], cp.hi[r], cp.k[r]);
-    }
-    cp.ascending = 1;
-    for (int r = 1; r < cp.n_rows; ++r)
-      if (cp.lo[r] < cp.hi[r - 1] - 1 || cp.hi[r] < cp.hi[r - 1]) cp.ascending = 0;   // (a band may include the bin below it)
-  }
+  rc = parse_contrast_plan(contrast_out, cplan_host, cp);
+  if (rc) return rc;
   if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f &&
                                  stats_mask > 0 && stats_mask < 32 && T < ((int64_t)1 << 27),
                              "stft2048_mel: invalid statistics parameters");
@@ -1581,9 +1661,46 @@ extern "C" int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64
   memset(&cp, 0, sizeof(cp));
   MfccArgs mf;
   mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
-  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0;
+  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = n_mfcc;
   return launch<16, 3>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out, 0.f,
                        0.f, 0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
+}
+
+// MODE 5: the statistics / contrast rows of syg_stft2048_mel_f32 AND the clip-resident MFCC of syg_stft2048_mfcc_f32
+// from one launch (BASELINE config C4: extract_features(["mfcc", "spectral_centroid", "spectral_rolloff",
+// "spectral_contrast"]), manager.py:289-371).  mfcc_out rows of clip b start at (b * mfcc_rows_per_clip) * T, so the
+// MFCCs can be written straight into the head of a wider per-clip block.
+extern "C" int syg_stft2048_features_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                                         const float* window, const float* twiddle, const float* wpacked,
+                                         const int32_t* plan_host, int n_mels, const float* dct, int n_mfcc,
+                                         const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
+                                         float sr, float roll_percent, float bw_p, int stats_mask, float* stats_out,
+                                         const int32_t* cplan_host, float* contrast_out, float* mel_out, float* mfcc_out,
+                                         int mfcc_rows_per_clip, void* stream) {
+  SYG_REQUIRE(wpacked && plan_host && dct && mfcc_out, "stft2048_features: null pointer argument");
+  SYG_REQUIRE(stats_out || contrast_out, "stft2048_features: no statistics requested (use syg_stft2048_mfcc_f32)");
+  MelPlan plan;
+  int rc = parse_mel_plan("stft2048_features", plan_host, n_mels, plan);
+  if (rc) return rc;
+  SYG_REQUIRE(plan_host[1] == 16, "stft2048_features: needs a 16-wave plan (got %d)", plan_host[1]);
+  rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
+  if (rc) return rc;
+  SYG_REQUIRE(n_mfcc >= 1 && n_mfcc <= n_mels && mfcc_rows_per_clip >= n_mfcc, "stft2048_features: need 1 <= n_mfcc <= n_mels "
+              "and mfcc_rows_per_clip >= n_mfcc");
+  SYG_REQUIRE(amin > 0.f, "stft2048_features: amin must be strictly positive");
+  SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft2048_features: ref_is_max must be 0 or 1");
+  SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_features: clip too long");
+  ContrastPlan cp;
+  rc = parse_contrast_plan(contrast_out, cplan_host, cp);
+  if (rc) return rc;
+  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && stats_mask > 0 &&
+                                 stats_mask < 32, "stft2048_features: invalid statistics parameters");
+  MfccArgs mf;
+  mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
+  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = mfcc_rows_per_clip;
+  return launch<16, 5>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out,
+                       sr / (float)NFFT, roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr,
+                       (hipStream_t)stream, mf);
 }
 
 extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,

@@ -50,12 +50,15 @@ def test_argument_errors_are_reported_without_device_work():
     sos = (C.c_double * 6)(1, 0, 0, 1, 0, 0); zi = (C.c_double * 2)(0, 0)
     rc = h.syg_sosfiltfilt_f32(p, 1, 20, 20, C.cast(sos, C.c_void_p), C.cast(zi, C.c_void_p), 1, 27, p, 20, p, None)
     assert rc == -1 and b"greater than padlen, which is 27" in h.syg_last_error()
-    assert h.syg_sosfiltfilt_work_bytes(1024, 48000, 27, 4) > 0
+    assert h.syg_sosfiltfilt_work_bytes(1024, 48000, 27, 4) == 0       # clip-resident form: no workspace
+    assert h.syg_sosfiltfilt_work_bytes(4, 200000, 27, 4) > 0 and h.syg_sosfiltfilt_work_bytes(4, 48000, 27, 6) > 0
+    assert h.syg_stft_mfcc_pow2_fits(1024, 40, 188, 13) == 1 and h.syg_stft_mfcc_pow2_fits(1024, 128, 1000, 13) == 0
     assert h.syg_sosfiltfilt_work_bytes(1, 100, 9, 9) == -1
     # partial sums per stream: clamp(8192 / B rounded down to a multiple of 4, 16, 2048)
-    assert h.syg_welch_work_bytes(8, 4096) == 8 * 1024 * 2049 * 4
-    assert h.syg_welch_work_bytes(1, 4096) == 1 * 2048 * 2049 * 4
-    assert h.syg_welch_work_bytes(1024, 256) == 1024 * 16 * 129 * 4
+    # float32 partial rows + the float64 slice sums of the two-stage combine (16 slices)
+    assert h.syg_welch_work_bytes(8, 4096) == 8 * 1024 * 2049 * 4 + 8 * 16 * 2049 * 8
+    assert h.syg_welch_work_bytes(1, 4096) == 1 * 2048 * 2049 * 4 + 1 * 16 * 2049 * 8
+    assert h.syg_welch_work_bytes(1024, 256) == 1024 * 16 * 129 * 4 + 1024 * 16 * 129 * 8
     # the one-launch MFCC form: the library owns the LDS-fit rule
     assert h.syg_stft2048_mfcc_fits(40, 94, 13) == 1 and h.syg_stft2048_mfcc_fits(128, 313, 13) == 0
     assert h.syg_stft2048_mfcc_fits(40, 94, 41) == 0 and h.syg_stft2048_mfcc_fits(0, 94, 1) == 0

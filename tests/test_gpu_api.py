@@ -544,5 +544,12 @@ def test_c4_feature_block_equals_the_manager_columns():
     names = [k for k in d if k != "time"]
     assert names == [f"mfcc_{i}" for i in range(13)] + ["spectral_centroid", "spectral_rolloff"] + \
         [f"contrast_band_{i}" for i in range(6)] + ["contrast_delta"]
+    blk2 = feature_block(ops.to_device_f32(Y), 48000, one_launch=False).cpu().numpy()      # mel -> feature_block form
     for r, k in enumerate(names):
-        assert np.array_equal(blk[:, r].astype(np.float64), d[k]), k
+        assert np.array_equal(blk2[:, r].astype(np.float64), d[k]), k
+        if r < 13:
+            # the one-launch form converts to dB with the hardware log2 (like syg_stft2048_mfcc_f32): same values within
+            # a fifth of the parity gate, not the same bits
+            assert peak_rel(blk[:, r].astype(np.float64), d[k]) <= 2e-6, k
+        else:
+            assert np.array_equal(blk[:, r].astype(np.float64), d[k]), k

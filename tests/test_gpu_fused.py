@@ -303,3 +303,29 @@ def test_reserved_cus_change_shares_not_results(monkeypatch):
         monkeypatch.setenv("SYGNALS_AMD_RESERVE_CUS", r)
         assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=True), ref1), r
         assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=False), ref2), r
+
+
+def test_c4_features_one_launch_matches_two_launch_and_oracle():
+    """MODE 5 (syg_stft2048_features_f32): MFCC + centroid + rolloff + contrast from ONE fused launch -- the block it
+    builds (with the small rows kernel behind it) equals the mel -> feature_block form and the oracle's columns."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.features.manager import feature_block
+    sr = 48000
+    Y = O.synth_clips(20, 48000, sr, seed=77)
+    Y[5] *= 1e-3
+    Y[7][:] = 0.0
+    y = ops.to_device_f32(Y)
+    one = feature_block(y, sr, one_launch=True).cpu().numpy()
+    two = feature_block(y, sr, one_launch=False).cpu().numpy()
+    assert one.shape == two.shape == (20, 22, 94)
+    # the statistics / contrast rows come from the same row functions: identical; the MFCC rows differ by the dB form
+    # (hardware log2 vs log10f) within the parity gate
+    assert np.array_equal(one[:, 13:], two[:, 13:])
+    for b in range(20):
+        assert peak_rel(one[b, :13], two[b, :13]) <= 2e-6 or np.abs(two[b, :13]).max() == 0
+    feats = ["mfcc", "spectral_centroid", "spectral_rolloff"]
+    for b in (0, 5, 11):
+        ref = O.extract_features(Y[b].astype(np.float64), sr, feats, feature_params={"mfcc": {"n_mels": 40}})
+        want = np.stack([ref[f"mfcc_{i}"] for i in range(13)])
+        assert_parity(one[b, :13], want, TOL, f"MODE 5 mfcc clip {b}")
+        assert_parity(one[b, 13], ref["spectral_centroid"], TOL, f"MODE 5 centroid clip {b}")

@@ -19,11 +19,15 @@ what = sys.argv[1]
 B = 1024
 Y = synth_clips(64, 48000, 48000, seed=1); y = ops.to_device_f32(np.tile(Y, (B // 64, 1)))
 CP = T.contrast_plan(np.fft.rfftfreq(2048, 1 / 48000), 48000)
+from sygnals_amd.core.features.manager import feature_block as FB
+y2 = ops.to_device_f32(np.tile(Y, (2048 // 64, 1))) if what.startswith("c4blk") else None
 fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "mel": lambda: ops.stft2048_mel(y, 48000, n_mels=40),
       "mfcc1024": lambda: ops.stft_mfcc_pow2(y, 48000, 1024, 256, True, "hann", None, 40, 13),
       "mel1024": lambda: ops.stft_mel_pow2(y, 48000, 1024, 256, True, "hann", None, 40),
       "mfcc512": lambda: ops.stft_mfcc_pow2(y, 48000, 512, 128, True, "hann", None, 40, 13),
+      "c4blk1": lambda: FB(y2, 48000, one_launch=True),
+      "c4blk2": lambda: FB(y2, 48000, one_launch=False),
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
 for _ in range(400): fn()
 torch.cuda.synchronize()
