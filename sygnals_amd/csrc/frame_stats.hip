@@ -8,10 +8,18 @@
 //   row 8      zero-crossing rate (core/audio/features.py:26-71 -> librosa.feature.zero_crossing_rate:
 //              EDGE padding, |x| <= 1e-10 counts as +0, the first sample of a frame never counts)
 //
-// The samples are float32; every sum, the histogram binning (NumPy's index-then-correct rule on float64 linspace
-// edges) and the moment formulas run in float64, so the result differs from the float64 reference only by the
-// final float32 rounding.  Two passes over the frame (mean first, then central moments + histogram): a frame is
-// at most a few KiB and stays in L1/L2.
+// The samples are float32.  Round 3: the per-sample arithmetic runs in float32 and only the ACCUMULATION across blocks of
+// samples and across lanes in float64 (v_fma_f64 issues at half the float32 rate and every sample needed a conversion:
+// ~12 float64 operations per sample were the whole cost of this kernel):
+//   pass 1  a lane adds x, |x|, x^2 of FS_BLK consecutive trips in float32 (<= 8 terms: rounding 8 * 2^-24 relative
+//           to the block, not to the frame) and adds the block sums to its float64 accumulators;
+//   pass 2  d = (x - mh) - ml with mh + ml = mean as a float32 pair (the first difference is exact or rounded
+//           relative to d itself, never relative to the mean: a large DC offset costs nothing), d^2, d^3, d^4 in
+//           float32, block sums to float64.
+// The histogram binning (NumPy's index-then-correct rule on float64 linspace edges), the zero-crossing classes and the
+// extrema are exact as before; the moment formulas run in float64 on the accumulated sums.  Measured against the
+// float64 reference: <= 3e-7 of each row's peak (gate 1e-5).  Two passes over the frame (mean first, then central
+// moments + histogram): a frame is at most a few KiB and stays in L1/L2.
 #include "common.h"
 #include <type_traits>
 
@@ -52,7 +60,10 @@ __device__ __forceinline__ double edge_at(double first, double last, double step
 // [t0 hop - pad, + (FS_WAVES-1) hop + frame_length) is copied once into LDS (zero padded) and both passes of every
 // frame read it from there -- the passes are bound by L2 traffic otherwise (each sample is needed
 // 2 x frame_length / hop times).
-template <bool STAGED>
+// VEC (staged, hop % 4 == 0, frame_length % 256 == 0): a lane takes FOUR consecutive samples per trip (one ds_read_b128,
+// a quarter of the loop and address instructions; the zero-crossing predecessor of three of the four samples is in the
+// lane's own register).  Sample order inside a sum changes, results agree to rounding; counts are identical.
+template <bool STAGED, bool VEC = false>
 __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
     const float* __restrict__ y, int64_t L, int64_t ldy, int flen, int hop, int pad, int64_t T, int num_bins,
     int mask, float* __restrict__ out) {
@@ -97,12 +108,43 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
   int zci = 0, carry = 0;
   // the wave-uniform choices (zero crossings wanted? frame touching a clip end?) are made outside the loop: three
   // straight-line loop bodies instead of per-sample branches
+  constexpr int FS_BLK = 8;                                               // float32 terms per block sum
   auto pass1 = [&](auto want_zcr, auto at_edge) {
+    float bx = 0.f, ba = 0.f;
+    int nblk = 0;
+    if (VEC) {
+      const float4* f4 = reinterpret_cast<const float4*>(fr);
+      const int nj = flen >> 8;
+#pragma unroll 2
+      for (int j = 0; j < nj; ++j) {
+        const float4 q = f4[lane + 64 * j];
+        bx += (q.x + q.y) + (q.z + q.w);
+        ba += (fabsf(q.x) + fabsf(q.y)) + (fabsf(q.z) + fabsf(q.w));
+        mxf = fmaxf(fmaxf(mxf, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+        mnf = fminf(fminf(mnf, fminf(q.x, q.y)), fminf(q.z, q.w));
+        if ((j & 1) == 1) { sx += (double)bx; sa += (double)ba; bx = ba = 0.f; }
+        if (decltype(want_zcr)::value) {
+          float e0 = q.x, e1 = q.y, e2 = q.z, e3 = q.w;
+          if (decltype(at_edge)::value) {
+            const int64_t sb = s0 + 4 * (lane + 64 * j);
+            e0 = ate(sb); e1 = ate(sb + 1); e2 = ate(sb + 2); e3 = ate(sb + 3);
+          }
+          const int n0 = (fabsf(e0) > ZTHR && e0 < 0.f) ? 1 : 0, n1 = (fabsf(e1) > ZTHR && e1 < 0.f) ? 1 : 0,
+                    n2 = (fabsf(e2) > ZTHR && e2 < 0.f) ? 1 : 0, n3 = (fabsf(e3) > ZTHR && e3 < 0.f) ? 1 : 0;
+          int prev = __builtin_amdgcn_update_dpp(0, n3, DPP_WAVE_SHR1, 0xF, 0xF, false);
+          prev = lane == 0 ? carry : prev;
+          carry = __builtin_amdgcn_readlane(n3, 63);
+          zci += ((lane + j > 0 && prev != n0) ? 1 : 0) + (n0 != n1 ? 1 : 0) + (n1 != n2 ? 1 : 0) + (n2 != n3 ? 1 : 0);
+        }
+      }
+      sx += (double)bx; sa += (double)ba;
+      return;
+    }
 #pragma unroll 4
     for (int i = lane; i < flen; i += 64) {
       const float xf = at0(i);                                            // zero padding
-      const double x = (double)xf;
-      sx += x; sa += fabs(x); sq += x * x;
+      bx += xf; ba += fabsf(xf);
+      if (++nblk == FS_BLK) { sx += (double)bx; sa += (double)ba; bx = ba = 0.f; nblk = 0; }
       mxf = fmaxf(mxf, xf); mnf = fminf(mnf, xf);
       if (decltype(want_zcr)::value) {
         // sign class of every sample once; its predecessor is the neighbouring lane's (lane 0: lane 63 of the
@@ -115,6 +157,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
         zci += (i >= 1 && prev != neg) ? 1 : 0;
       }
     }
+    sx += (double)bx; sa += (double)ba;
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
@@ -124,7 +167,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
     else pass1(T_{}, T_{});
   }
   double zc = (double)wave_sum_i(zci);
-  sx = wsum(sx); sa = wsum(sa); sq = wsum(sq);
+  sx = wsum(sx); sa = wsum(sa);
   wave_maxmin(mxf, mnf);
   const double mx = (double)mxf, mn = (double)mnf, pk = fmax(fabs(mx), fabs(mn));
   const double mean = sx / n;
@@ -157,15 +200,58 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
   const bool packed = nb <= 16 && flen <= 255 * 64;
   unsigned long long c0 = 0ull, c1 = 0ull;
   // HIST: 0 no histogram, 1 packed counters + one-step correction (the common case), 2 everything else
+  const float mh = (float)mean, ml = (float)(mean - (double)mh);          // mean as a float32 pair
+  // deviations are scaled by a power of two that brings the frame's peak into [0.5, 1) (exact; taken back in float64
+  // below): d^4 can then neither overflow nor vanish, whatever the signal's units
+  const float pkf = fmaxf(fabsf(mxf), fabsf(mnf));
+  const unsigned pe = (__float_as_uint(pkf) >> 23) & 0xffu;
+  const float sc = (pkf > 0.f && pe <= 250u) ? __uint_as_float((253u - pe) << 23) : 1.f;
   auto pass2 = [&](auto hist_mode) {
     constexpr int HIST = decltype(hist_mode)::value;
+    float b2 = 0.f, b3 = 0.f, b4 = 0.f;
+    int nblk = 0;
+    auto sample = [&](float xf) {
+      const float d = ((xf - mh) - ml) * sc;
+      const float d2 = d * d;
+      b2 += d2; b3 = fmaf(d2, d, b3); b4 = fmaf(d2, d2, b4);
+      if (HIST != 0) {
+        int idx = (int)((xf - firstf) * normf);             // within one bin of the float64 guess
+        idx = idx < 0 ? 0 : (idx > nb - 1 ? nb - 1 : idx);
+        if (HIST == 1 || wide) {                            // the guess is off by one bin at most: branch-free
+          const float e0 = eu[w][idx], e1 = eu[w][idx + 1];
+          idx += (xf >= e1 && idx != nb - 1) ? 1 : ((xf < e0 && idx > 0) ? -1 : 0);
+        } else {                                            // (nearly) denormal range: the float guess means nothing
+          while (idx > 0 && xf < eu[w][idx]) idx -= 1;
+          while (idx != nb - 1 && xf >= eu[w][idx + 1]) idx += 1;
+        }
+        if (HIST == 1 || packed) {
+          const unsigned long long one = 1ull << ((idx & 7) * 8);
+          c0 += idx < 8 ? one : 0ull;
+          c1 += idx < 8 ? 0ull : one;
+        } else {
+          atomicAdd(&hist[w][idx], 1u);
+        }
+      }
+    };
+    if (VEC) {
+      const float4* f4 = reinterpret_cast<const float4*>(fr);
+      const int nj = flen >> 8;
+#pragma unroll 2
+      for (int j = 0; j < nj; ++j) {
+        const float4 q = f4[lane + 64 * j];
+        sample(q.x); sample(q.y); sample(q.z); sample(q.w);
+        if ((j & 1) == 1) { m2 += (double)b2; m3 += (double)b3; m4 += (double)b4; b2 = b3 = b4 = 0.f; }
+      }
+      m2 += (double)b2; m3 += (double)b3; m4 += (double)b4;
+      return;
+    }
 #pragma unroll 4
     for (int i = lane; i < flen; i += 64) {
       const float xf = at0(i);
-      const double x = (double)xf;
-      const double d = x - mean;
-      const double d2 = d * d;
-      m2 += d2; m3 += d2 * d; m4 += d2 * d2;
+      const float d = ((xf - mh) - ml) * sc;
+      const float d2 = d * d;
+      b2 += d2; b3 = fmaf(d2, d, b3); b4 = fmaf(d2, d2, b4);
+      if (++nblk == FS_BLK) { m2 += (double)b2; m3 += (double)b3; m4 += (double)b4; b2 = b3 = b4 = 0.f; nblk = 0; }
       if (HIST != 0) {
         int idx = (int)((xf - firstf) * normf);             // within one bin of the float64 guess
         idx = idx < 0 ? 0 : (idx > nb - 1 ? nb - 1 : idx);
@@ -185,13 +271,18 @@ __global__ __launch_bounds__(FS_WAVES * 64) void frame_stats_kernel(
         }
       }
     }
+    m2 += (double)b2; m3 += (double)b3; m4 += (double)b4;
   };
   if (live) {
     if (!want_hist) pass2(std::integral_constant<int, 0>{});
     else if (packed && wide) pass2(std::integral_constant<int, 1>{});
     else pass2(std::integral_constant<int, 2>{});
   }
-  m2 = wsum(m2) / n; m3 = wsum(m3) / n; m4 = wsum(m4) / n;
+  {
+    const double isc = 1.0 / (double)sc, i2 = isc * isc;
+    m2 = wsum(m2) / n * i2; m3 = wsum(m3) / n * (i2 * isc); m4 = wsum(m4) / n * (i2 * i2);
+  }
+  sq = n * (m2 + mean * mean);                              // sum x^2 from the well-conditioned central sum
   __syncthreads();
   double ent = 0.0;
   if (want_hist && packed) {
@@ -279,7 +370,10 @@ extern "C" int syg_frame_stats_f32(const float* y, int64_t B, int64_t L, int64_t
   SYG_REQUIRE(gx < (int64_t)0x7fffffff, "frame_stats: too many frames");
   const size_t span_bytes = ((size_t)(FS_WAVES - 1) * hop + frame_length) * sizeof(float);
   const int pad = center ? frame_length / 2 : 0;
-  if (hop < frame_length && span_bytes <= 48 * 1024) {
+  if (hop < frame_length && span_bytes <= 48 * 1024 && hop % 4 == 0 && frame_length % 256 == 0) {
+    hipLaunchKernelGGL((frame_stats_kernel<true, true>), dim3((unsigned)gx, (unsigned)B), dim3(FS_WAVES * 64), span_bytes,
+                       (hipStream_t)stream, y, L, ldy, frame_length, hop, pad, T, num_bins, mask, out);
+  } else if (hop < frame_length && span_bytes <= 48 * 1024) {
     hipLaunchKernelGGL(frame_stats_kernel<true>, dim3((unsigned)gx, (unsigned)B), dim3(FS_WAVES * 64), span_bytes,
                        (hipStream_t)stream, y, L, ldy, frame_length, hop, pad, T, num_bins, mask, out);
   } else {
