@@ -1284,8 +1284,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     TICK(6, tdep);
     if (!ROWFN && SYG_CPRIO == 3) SETPRIO(3);           // projection (+ clip epilogue) at the top level
     if (CLIPM && pend_b >= 0) {
-      if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6 && SYG_ABL != 7)
-        clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, w, lane);
+#ifndef SYG_DCTSHIFT
+#define SYG_DCTSHIFT 0
+#endif
+      {
+        const int wd = (w + WAVES - SYG_DCTSHIFT) % WAVES;       // output tile wd is formed by wave (wd + SYG_DCTSHIFT) mod WAVES
+        if (wd < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6 && SYG_ABL != 7)
+          clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, wd, lane);
+      }
       pend_b = -1;
       TICK(10, tdep);
     }
@@ -1357,7 +1363,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // valid until the next tile's projection -- so that their entry does not wait for these stores.)
     auto combine = [&]() {
       constexpr int GL = 4 * TILE_T;               // outputs per group and tile (64 at 16 frames)
-      for (int g = w; g < plan.n_groups; g += WAVES) {
+#ifndef SYG_REDSHIFT
+#define SYG_REDSHIFT 6
+#endif
+      // group g is combined by wave (g + SYG_REDSHIFT) mod WAVES.  Ten groups at 40 mels: with shift 0 the ten OLDEST waves
+      // carry the combine and the six youngest -- which the arbiter already serves last -- none; shift 6 gives it to
+      // the waves 6 .. 15 (148.5 vs 150.8 us for the one-launch MFCC at C2; 3: 149.1, 10: slower than 6)
+      for (int g = (w + WAVES - SYG_REDSHIFT) % WAVES; g < plan.n_groups; g += WAVES) {
         const int first = __builtin_amdgcn_readfirstlane(mtab[128 + g]);
         const int cnt = __builtin_amdgcn_readfirstlane(mtab[192 + g]);
         int lq = lane;                    // laundered (see lv above): no hoisted per-lane addresses that would spill
