@@ -37,6 +37,9 @@
 // wave, which then idles at barrier A while the youngest finishes alone with nothing to hide its LDS latency.
 #ifndef SYG_NOPRIO
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+// level n for the younger waves, one lower for the older ones (experiment SYG_AGEPRIO: the arbiter serves the oldest wave
+// first at equal priority)
+#define SETPRIO_AGE(n, older) do { if (older) SETPRIO((n) > 0 ? (n) - 1 : 0); else SETPRIO(n); } while (0)
 #else
 #define SETPRIO(n)
 #endif
@@ -172,7 +175,7 @@ template <int NPF, int PD = 0, bool X2 = false>
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
                                              const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
                                              int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512,
-                                             const float4* __restrict__ pf_src, float4* __restrict__ pf TARGS) {
+                                             const float4* __restrict__ pf_src, float4* __restrict__ pf, bool older TARGS) {
   const int cl = lane >> 2, bp = lane & 3;
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
   dft16(v);
@@ -219,7 +222,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   }
   TICK(2, t[0].x);
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
-  SETPRIO(2 - PD > 0 ? 2 - PD : 0);
+  SETPRIO_AGE(2 - PD > 0 ? 2 - PD : 0, older);
   dft16(t);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
@@ -263,7 +266,7 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
 #endif
   }
   TICK(4, G[0][0].x);
-  SETPRIO(1 - PD > 0 ? 1 - PD : 0);
+  SETPRIO_AGE(1 - PD > 0 ? 1 - PD : 0, older);
   if (NPF > 0) {
     int lp = lane;                     // laundered: the loads may not be hoisted above this point (register peak)
     asm volatile("" : "+v"(lp));
@@ -1193,7 +1196,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
     constexpr int PD = ROWFN ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0)
                                    : (SYG_CPRIO == 1 || SYG_CPRIO == 3) ? 1 : 0;
-    SETPRIO(3 - PD > 0 ? 3 - PD : 0);
+#ifndef SYG_AGEPRIO
+#define SYG_AGEPRIO 0
+#endif
+    // (wave-uniform; SYG_AGEPRIO = n > 0: the n oldest waves one level lower -- measured SLOWER: 148.0 -> 148.7 / 151.2 /
+    // 152.4 us for n = 4 / 8 / 12; n < 0: the -n youngest waves one level lower)
+    const bool older = (SYG_AGEPRIO > 0 && w < SYG_AGEPRIO) || (SYG_AGEPRIO < 0 && w >= WAVES + SYG_AGEPRIO);
+    SETPRIO_AGE(3 - PD > 0 ? 3 - PD : 0, older);
     // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT needs
     // all 128 VGPRs): the first NPRE groups of four steps are re-fetched every tile, behind pass 3 of the transform.
     constexpr int NPRE = 7;            // unconditional: every wave's segment holds >= NPRE groups (zero padded)
@@ -1222,7 +1231,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
       TICK(0, v[0].x);
       float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY, PD, X2>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre TPASS);
+      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY, PD, X2>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre, older TPASS);
       if (COMPLEX_OUT) {
         float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll

@@ -32,6 +32,10 @@ d = st.reshape(-1)[: 256 * W * 16].reshape(256, W, 16).cpu().numpy()[:, :, :12]
 names = ["load+window", "pass1+tw1", "exchange1", "pass2+tw2", "exchange2+pass3", "split+P store", "barrier A",
          "MFMA", "barrier B", "reduce+store", "clip DCT (MODE 3)", "row functions (MODE 1)"]
 tot = d.sum(axis=2)
+if len(sys.argv) > 2 and sys.argv[2] == "waves":      # per-wave means of the barrier waits and the whole tile
+    print("per-wave: wave | barrier A | barrier B | reduce | total")
+    for wv in range(W):
+        print(f"  {wv:2d}  {d[:, wv, 6].mean():8.0f} {d[:, wv, 8].mean():8.0f} {d[:, wv, 9].mean():8.0f} {tot[:, wv].mean():8.0f}")
 print(f"cycles per tile per wave: mean {tot.mean():.0f}  min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(names[:12]):
     col = d[:, :, i]
