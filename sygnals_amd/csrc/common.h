@@ -87,6 +87,13 @@ __device__ __forceinline__ void dft8(float2 (&a)[8]) {
   a[3] = cadd(e3, t3); a[7] = csub(e3, t3);
 }
 
+// power_to_db on the hardware logarithm: 10 log10(x / ref) = 10 log10(2) (log2 x - log2 ref).  v_log_f32 is good to one
+// ulp of the log2 value (<= 2.4e-6 at |log2| = 40, i.e. 7e-6 dB) against ~40 instructions for the library log10f -- the
+// conversion was most of logmel_dct's time; the difference of logs is exactly 0 at x == ref.  Inputs must be normal
+// numbers (callers clamp with amin >= FLT_MIN).
+constexpr float SYG_DB_PER_LOG2 = 3.01029995663981195f;
+__device__ __forceinline__ float syg_log2(float x) { return __builtin_amdgcn_logf(x); }
+
 // Lanes of one wave exchange data through LDS without a workgroup barrier (the LDS executes a wave's
 // DS instructions in order).  To the COMPILER that is a data race: it may assume a lane that did not store
 // re-reads unchanged memory.  This wavefront-scope release/acquire pair emits no instruction but makes every

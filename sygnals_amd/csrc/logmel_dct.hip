@@ -41,17 +41,17 @@ __global__ __launch_bounds__(NT) void logmel_dct_kernel(float* __restrict__ mel,
     float m = red[0];
     for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, red[i]);
     const float ref = ref_is_max ? m : fabsf(ref_value);
-    // dB values are formed as 10*(log10 x - log10 ref): the difference of logs is exact (0) when
-    // x == ref, whatever the compiler contracts into FMAs
-    const float reflog = log10f(fmaxf(amin, ref));
+    // dB values are formed as 10 log10(2) (log2 x - log2 ref): the difference of logs is exact (0) when
+    // x == ref, whatever the compiler contracts into FMAs (hardware log2: common.h)
+    const float reflog = syg_log2(fmaxf(amin, ref));
     s_refdb = reflog;
     // log_spec.max() - top_db, with log_spec monotone in the power
-    s_floor = (top_db >= 0.f) ? 10.f * (log10f(fmaxf(amin, m)) - reflog) - top_db : -3.4e38f;
+    s_floor = (top_db >= 0.f) ? SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, m)) - reflog) - top_db : -3.4e38f;
   }
   __syncthreads();
   const float reflog = s_refdb, flo = s_floor;
   for (int64_t i = tid; i < n; i += NT) {
-    float v = 10.f * (log10f(fmaxf(amin, src[i])) - reflog);
+    float v = SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, src[i])) - reflog);
     dst[i] = fmaxf(v, flo);
   }
   }
@@ -80,6 +80,103 @@ dct_stage:
         float v = acc[r];
         if (lifter) v *= lifter[k];
         mfcc[(b * K + k) * T + tcol] = v;
+      }
+    }
+  }
+}
+
+// The same with the clip's matrix staged in LDS (M * T * 4 bytes <= 96 KiB: every clip of the BASELINE configurations and of
+// the other frame lengths' tile kernels): one read of the mel matrix, the dB matrix written once (the in-place /
+// logmel_out contract) and read back from LDS by the DCT, whose rows wait in registers; 512 threads.  The form above read
+// the matrix from global memory three times, one dependent L2 round trip per DCT step (32 us per 1024 clips at T = 188).
+constexpr int NTL = 512;
+__global__ __launch_bounds__(NTL) void logmel_dct_lds_kernel(float* __restrict__ mel, int M, int64_t T,
+                                                             const float* __restrict__ dct, int K,
+                                                             const float* __restrict__ lifter, float amin, float top_db,
+                                                             int ref_is_max, float ref_value, float* __restrict__ logmel,
+                                                             float* __restrict__ mfcc) {
+  extern __shared__ __attribute__((aligned(16))) float db[];     // [M][T]
+  __shared__ float red[NTL / 64];
+  __shared__ float s_floor, s_refdb;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t b = blockIdx.x;
+  float* src = mel + b * (int64_t)M * T;
+  float* dst = logmel ? logmel + b * (int64_t)M * T : src;
+  const int n = M * (int)T;
+  float mx = 0.f;  // power is non-negative
+  if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+    for (int i = tid; i < (n >> 2); i += NTL) {
+      const float4 q = reinterpret_cast<const float4*>(src)[i];
+      reinterpret_cast<float4*>(db)[i] = q;
+      mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+    }
+  } else {
+    for (int i = tid; i < n; i += NTL) { const float q = src[i]; db[i] = q; mx = fmaxf(mx, q); }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float m = red[0];
+    for (int i = 1; i < NTL / 64; ++i) m = fmaxf(m, red[i]);
+    const float ref = ref_is_max ? m : fabsf(ref_value);
+    const float reflog = syg_log2(fmaxf(amin, ref));
+    s_refdb = reflog;
+    s_floor = (top_db >= 0.f) ? SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, m)) - reflog) - top_db : -3.4e38f;
+  }
+  __syncthreads();
+  const float reflog = s_refdb, flo = s_floor;
+  if ((n & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+    for (int i = tid; i < (n >> 2); i += NTL) {
+      float4 q = reinterpret_cast<float4*>(db)[i];
+      q.x = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, q.x)) - reflog), flo);
+      q.y = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, q.y)) - reflog), flo);
+      q.z = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, q.z)) - reflog), flo);
+      q.w = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, q.w)) - reflog), flo);
+      reinterpret_cast<float4*>(db)[i] = q;
+      reinterpret_cast<float4*>(dst)[i] = q;
+    }
+  } else {
+    for (int i = tid; i < n; i += NTL) {
+      const float v = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, db[i])) - reflog), flo);
+      db[i] = v; dst[i] = v;
+    }
+  }
+  if (mfcc == nullptr) return;
+  __syncthreads();
+  // ---- DCT: out[k, t] = sum_m dct[k, m] * dB[m, t]   (16 x 16 output tiles on the MFMA, the A operands of a k tile
+  // loaded once per wave: M / 4 registers)
+  const int ktiles = (K + 15) / 16, ttiles = (int)((T + 15) / 16);
+  const int f = lane & 15, g = lane >> 4;
+  constexpr int MAXS = 32;                            // k-steps of four mel rows kept in registers: M <= 128
+  const int steps = (M + 3) >> 2;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int krow = kt * 16 + f;
+    float a[MAXS];
+#pragma unroll
+    for (int sidx = 0; sidx < MAXS; ++sidx) {
+      const int m = 4 * sidx + g;
+      a[sidx] = (sidx < steps && krow < K && m < M) ? dct[krow * M + m] : 0.f;
+    }
+    for (int tt = w; tt < ttiles; tt += NTL / 64) {
+      const int tcol = tt * 16 + f;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sidx = 0; sidx < MAXS; ++sidx) {
+        if (sidx < steps) {
+          const int m = 4 * sidx + g;
+          const float bv = (tcol < T && m < M) ? db[m * (int)T + tcol] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sidx], bv, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = kt * 16 + 4 * g + r;
+        if (k < K && tcol < T) {
+          float v = acc[r];
+          if (lifter) v *= lifter[k];
+          mfcc[(b * K + k) * T + tcol] = v;
+        }
       }
     }
   }
@@ -122,10 +219,10 @@ __global__ __launch_bounds__(NT) void feature_block_kernel(const float* __restri
 #pragma unroll
   for (int i = 1; i < NT / 64; ++i) { mx = fmaxf(mx, red[0][i]); m0 = fmaxf(m0, red[1][i]); m1 = fmaxf(m1, red[2][i]); }
   // (the same expressions as logmel_dct_kernel / contrast_db_kernel: the two forms give identical values)
-  const float reflog = log10f(fmaxf(amin, mx));
-  const float flo = (top_db >= 0.f) ? 10.f * (log10f(fmaxf(amin, mx)) - reflog) - top_db : -3.4e38f;
+  const float reflog = syg_log2(fmaxf(amin, mx));
+  const float flo = (top_db >= 0.f) ? SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, mx)) - reflog) - top_db : -3.4e38f;
   if (have_mel)
-    for (int64_t i = tid; i < n; i += NT) db[i] = fmaxf(10.f * (log10f(fmaxf(amin, src[i])) - reflog), flo);
+    for (int64_t i = tid; i < n; i += NT) db[i] = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, src[i])) - reflog), flo);
   const float f0 = (c_top_db >= 0.f) ? 10.f * log10f(fmaxf(c_amin, m0)) - c_top_db : -3.4e38f;
   const float f1 = (c_top_db >= 0.f) ? 10.f * log10f(fmaxf(c_amin, m1)) - c_top_db : -3.4e38f;
   for (int64_t i = tid; i < nc; i += NT) {
@@ -172,7 +269,7 @@ extern "C" int syg_feature_block_f32(const float* mel, int64_t B, int M, int64_t
   SYG_REQUIRE((dct || !mel) && stats && contrast_pv && block_out, "feature_block: null pointer argument");
   SYG_REQUIRE(B >= 1 && B < (int64_t)0x7fffffff && M >= 1 && T >= 1 && K >= 1 && K <= M && R >= 1,
               "feature_block: bad shape (B=%lld M=%d T=%lld K=%d R=%d)", (long long)B, M, (long long)T, K, R);
-  SYG_REQUIRE(amin > 0.f && c_amin > 0.f, "feature_block: amin must be strictly positive");
+  SYG_REQUIRE(amin >= 1.17549435e-38f && c_amin > 0.f, "feature_block: amin must be a positive normal float");
   const size_t lds = mel ? (size_t)M * (size_t)T * sizeof(float) : 0;       // (mel == NULL: only the statistics / contrast rows)
   SYG_REQUIRE(lds <= 150 * 1024, "feature_block: the clip's dB matrix (%d x %lld) does not fit LDS; use "
               "syg_logmel_dct_f32 + syg_contrast_db_f32", M, (long long)T);
@@ -193,10 +290,21 @@ extern "C" int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const
   SYG_REQUIRE(mel, "logmel_dct: null mel pointer");
   SYG_REQUIRE(B >= 1 && M >= 1 && T >= 1, "logmel_dct: need B, M, T >= 1");
   SYG_REQUIRE(ref_is_max >= 0 && ref_is_max <= 2, "logmel_dct: ref_is_max must be 0, 1 or 2");
-  SYG_REQUIRE(ref_is_max == 2 || amin > 0.f, "logmel_dct: amin must be strictly positive");
+  SYG_REQUIRE(ref_is_max == 2 || amin >= 1.17549435e-38f, "logmel_dct: amin must be a positive normal float (>= 1.17549435e-38)");
   SYG_REQUIRE(ref_is_max != 2 || mfcc_out, "logmel_dct: DCT-only mode needs mfcc_out");
   if (mfcc_out) SYG_REQUIRE(dct && K >= 1 && K <= M, "logmel_dct: need dct and 1 <= K <= M (K=%d M=%d)", K, M);
   SYG_REQUIRE(B < (int64_t)0x7fffffff, "logmel_dct: batch too large");
+  const size_t lds = (size_t)M * (size_t)T * sizeof(float);
+  if (ref_is_max != 2 && lds <= 96 * 1024 && M <= 128) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)logmel_dct_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("logmel_dct: cannot reserve %zu B of LDS", lds); return SYG_E_LAUNCH; }
+    }
+    hipLaunchKernelGGL(logmel_dct_lds_kernel, dim3((unsigned)B), dim3(NTL), lds, (hipStream_t)stream, mel, M, T, dct, K,
+                       lifter, amin, top_db, ref_is_max, ref_value, logmel_out, mfcc_out);
+    SYG_CHECK_LAUNCH("logmel_dct");
+    return SYG_OK;
+  }
   hipLaunchKernelGGL(logmel_dct_kernel, dim3((unsigned)B), dim3(NT), 0, (hipStream_t)stream, mel, M, T, dct, K,
                      lifter, amin, top_db, ref_is_max, ref_value, logmel_out, mfcc_out);
   SYG_CHECK_LAUNCH("logmel_dct");

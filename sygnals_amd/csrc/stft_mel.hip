@@ -1675,7 +1675,7 @@ extern "C" int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64
   if (rc) return rc;
   SYG_REQUIRE(n_mfcc >= 1 && n_mfcc <= n_mels, "stft2048_mfcc: need 1 <= n_mfcc <= n_mels (n_mfcc=%d n_mels=%d)",
               n_mfcc, n_mels);
-  SYG_REQUIRE(amin > 0.f, "stft2048_mfcc: amin must be strictly positive");
+  SYG_REQUIRE(amin >= 1.17549435e-38f, "stft2048_mfcc: amin must be strictly positive (a normal float)");
   SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft2048_mfcc: ref_is_max must be 0 or 1");
   SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_mfcc: clip too long");
   ContrastPlan cp;
@@ -1708,7 +1708,7 @@ extern "C" int syg_stft2048_features_f32(const float* y, int64_t B, int64_t L, i
   if (rc) return rc;
   SYG_REQUIRE(n_mfcc >= 1 && n_mfcc <= n_mels && mfcc_rows_per_clip >= n_mfcc, "stft2048_features: need 1 <= n_mfcc <= n_mels "
               "and mfcc_rows_per_clip >= n_mfcc");
-  SYG_REQUIRE(amin > 0.f, "stft2048_features: amin must be strictly positive");
+  SYG_REQUIRE(amin >= 1.17549435e-38f, "stft2048_features: amin must be strictly positive (a normal float)");
   SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft2048_features: ref_is_max must be 0 or 1");
   SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_features: clip too long");
   ContrastPlan cp;

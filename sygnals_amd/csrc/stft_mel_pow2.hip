@@ -142,15 +142,15 @@ __global__ __launch_bounds__(NW * 64) void stft_mel_pow2_kernel(
     float m = red[0];
     for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
     const float ref = mf.ref_is_max ? m : fabsf(mf.ref_value);
-    const float reflog = log10f(fmaxf(mf.amin, ref));
+    const float reflog = syg_log2(fmaxf(mf.amin, ref));
     red[NW] = reflog;
-    red[NW + 1] = (mf.top_db >= 0.f) ? 10.f * (log10f(fmaxf(mf.amin, m)) - reflog) - mf.top_db : -3.4e38f;
+    red[NW + 1] = (mf.top_db >= 0.f) ? SYG_DB_PER_LOG2 * (syg_log2(fmaxf(mf.amin, m)) - reflog) - mf.top_db : -3.4e38f;
   }
   __syncthreads();
   const float reflog = red[NW], flo = red[NW + 1];
   const int nm = n_mels * mf.tp;
   for (int i = tid; i < nm; i += NW * 64)
-    clipmel[i] = fmaxf(10.f * (log10f(fmaxf(mf.amin, clipmel[i])) - reflog), flo);   // 10 (log x - log ref): exact 0 at x == ref
+    clipmel[i] = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(mf.amin, clipmel[i])) - reflog), flo);   // exact 0 at x == ref
   __syncthreads();
   const int ktiles = (mf.n_mfcc + 15) >> 4, ttiles = mf.tp >> 4;
   for (int ot = w; ot < ktiles * ttiles; ot += NW) {
@@ -358,15 +358,15 @@ __global__ __launch_bounds__(512, CLIP ? 4 : SYG_P2_TILE_WAVES) void stft_mel_w1
     float m = red[0];
     for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
     const float ref = mf.ref_is_max ? m : fabsf(mf.ref_value);
-    const float reflog = log10f(fmaxf(mf.amin, ref));
+    const float reflog = syg_log2(fmaxf(mf.amin, ref));
     red[NW] = reflog;
-    red[NW + 1] = (mf.top_db >= 0.f) ? 10.f * (log10f(fmaxf(mf.amin, m)) - reflog) - mf.top_db : -3.4e38f;
+    red[NW + 1] = (mf.top_db >= 0.f) ? SYG_DB_PER_LOG2 * (syg_log2(fmaxf(mf.amin, m)) - reflog) - mf.top_db : -3.4e38f;
   }
   __syncthreads();
   const float reflog = red[NW], flo = red[NW + 1];
   const int nm = n_mels * mf.tp;
   for (int i = tid; i < nm; i += NW * 64)
-    clipmel[i] = fmaxf(10.f * (log10f(fmaxf(mf.amin, clipmel[i])) - reflog), flo);
+    clipmel[i] = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(mf.amin, clipmel[i])) - reflog), flo);
   __syncthreads();
   const int ktiles = (mf.n_mfcc + 15) >> 4, ttiles = mf.tp >> 4;
   for (int ot = w; ot < ktiles * ttiles; ot += NW) {
@@ -387,6 +387,140 @@ __global__ __launch_bounds__(512, CLIP ? 4 : SYG_P2_TILE_WAVES) void stft_mel_w1
         if (mf.lifter) v *= mf.lifter[k];
         mf.out[(b * mf.n_mfcc + k) * T + tcol] = v;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// n_fft = 512 on the wave FFT: FOUR real frames per 1024-point complex transform.  With p = a + i b and q = c + i d (two
+// pairs of windowed 512-sample frames) interleaved as z[2n] = p[n], z[2n + 1] = q[n]:
+//   Z[k] = P[k] + W_1024^k Q[k],  Z[k + 512] = P[k] - W_1024^k Q[k]      (P, Q: the 512-point transforms of p, q)
+// and the real-input splits of P and Q need (k, 512 - k).  A lane of the wave FFT holds Z at k, k + 256, k + 512,
+// k + 768 and at their mirrors 1024 - ..: with S = Z[k] + Z[k + 512], D = Z[k] - Z[k + 512], Sm = Z[512 - k] + Z[1024 - k],
+// Dm = Z[512 - k] - Z[1024 - k] the four POWERS at bin k are
+//   16 |A|^2 = |S + conj Sm|^2   16 |B|^2 = |S - conj Sm|^2   16 |C|^2 = |D - conj Dm|^2   16 |D|^2 = |D + conj Dm|^2
+// -- the twiddle W^k only turns C and D and drops out of their magnitudes.  The pairs (k + 256, k + 768) give bin 256 - k
+// the same way; lane 0's first unit (the self-mirrored groups) supplies bins 0, 128 and 256.
+// A wave owns the frames 4 w .. 4 w + 3 of a 32-frame tile; its four power rows alias its exchange scratch.  Tile form only
+// (the clip form of this frame length is the Stockham kernel above).
+struct W512Lds {
+  static constexpr int FP = 272, PS = FP + 4;
+  static constexpr int SCW = 4 * PS;                                  // per-wave scratch: 1104 floats >= 528 complex
+  static constexpr int O_SC = 0;
+  static constexpr int O_TW2 = O_SC + 8 * SCW;
+  static constexpr int O_TW1 = O_TW2 + wfft::TW2_COMPLEX * 2;
+  static constexpr int TOTAL = O_TW1 + wfft::TW1_COMPLEX * 2;
+  static_assert(SCW >= 2 * wfft::SC_COMPLEX, "the exchange scratch must fit inside the four aliased rows");
+};
+
+__global__ __launch_bounds__(512, SYG_P2_TILE_WAVES) void stft_mel_w512_kernel(
+    const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, const float* __restrict__ win,
+    const float2* __restrict__ tw512, const float* __restrict__ basis_p, int n_mels, int power,
+    float* __restrict__ mel_out, int tiles_per_clip) {
+  typedef W512Lds LM;
+  constexpr int NW = 8, FP = LM::FP, PS = LM::PS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2* sc = reinterpret_cast<float2*>(lds + LM::O_SC + w * LM::SCW);
+  float2* tw2l = reinterpret_cast<float2*>(lds + LM::O_TW2);
+  float2* tw1l = reinterpret_cast<float2*>(lds + LM::O_TW1);
+  float* P = lds + LM::O_SC;                       // row fi at fi * PS: rows 4 w .. 4 w + 3 inside wave w's scratch
+  wfft::Lane lc;
+  wfft::init_lane(lc, lane);
+  const int64_t b = blockIdx.x / tiles_per_clip;
+  const int64_t t0 = (blockIdx.x - b * tiles_per_clip) * 32;
+  const float* yb = y + b * ldy;
+  // element 64 a + lane of z: even lanes carry p = frames (4 w, 4 w + 1), odd lanes q = frames (4 w + 2, 4 w + 3), sample
+  // n = 32 a + lane / 2 of each
+  const int64_t tf = t0 + 4 * w + 2 * (lane & 1);
+  const int nl = lane >> 1;
+  float2 v[16];
+  if (t0 + 4 * w < T) {
+    const int64_t sa = tf * (int64_t)hop - pad, sb = sa + hop;
+    const bool hasa = tf < T, hasb = tf + 1 < T;
+    const int64_t s_first = (t0 + 4 * w) * (int64_t)hop - pad;
+    if (s_first >= 0 && s_first + 3 * (int64_t)hop + 512 <= L && t0 + 4 * w + 3 < T) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const float wv = win[32 * a + nl];
+        v[a] = make_float2(yb[sa + 32 * a + nl] * wv, yb[sb + 32 * a + nl] * wv);
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const int64_t ia = sa + 32 * a + nl, ib = sb + 32 * a + nl;
+        const float wv = win[32 * a + nl];
+        v[a] = make_float2((hasa && ia >= 0 && ia < L) ? yb[ia] * wv : 0.f, (hasb && ib >= 0 && ib < L) ? yb[ib] * wv : 0.f);
+      }
+    }
+  }
+  // tables of the wave FFT from tw512[m] = W_1024^m (the third block of this frame length's twiddle argument)
+  if (tid < 64) tw2l[(tid >> 4) * wfft::TW2_STRIDE + (tid & 15)] = tw512[(16 * (tid >> 4) * (tid & 15)) & 1023];
+  for (int i = tid; i < wfft::TW1_COMPLEX; i += NW * 64) tw1l[i] = tw512[(i & 63) * ((i >> 6) + 1)];
+  __syncthreads();
+  {
+    float* row0 = P + (4 * w) * PS;
+    if (t0 + 4 * w < T) {
+      float2 zk[2][4], zm[2][4], z512;
+      wfft::cfft1024(v, lc, sc, tw1l, tw2l, lane, zk, zm, z512);
+      // (za, zb, mb, ma) = (Z[k], Z[k + 512], Z[512 - k], Z[1024 - k]) -> the four frames' powers at one bin
+      auto four = [&](float2 za, float2 zb, float2 mb, float2 ma, int bin) {
+        const float sx = za.x + zb.x, sy = za.y + zb.y, dx = za.x - zb.x, dy = za.y - zb.y;
+        const float mx = mb.x + ma.x, my = mb.y + ma.y, ex = mb.x - ma.x, ey = mb.y - ma.y;
+        const float ax = sx + mx, ay = sy - my, bx = sx - mx, by = sy + my;
+        const float cx = dx - ex, cy = dy + ey, gx = dx + ex, gy = dy - ey;
+        const float pa = 0.0625f * fmaf(ax, ax, ay * ay), pb = 0.0625f * fmaf(bx, bx, by * by);
+        const float pc = 0.0625f * fmaf(cx, cx, cy * cy), pd = 0.0625f * fmaf(gx, gx, gy * gy);
+        row0[bin] = (power == 2) ? pa : sqrtf(pa);
+        row0[PS + bin] = (power == 2) ? pb : sqrtf(pb);
+        row0[2 * PS + bin] = (power == 2) ? pc : sqrtf(pc);
+        row0[3 * PS + bin] = (power == 2) ? pd : sqrtf(pd);
+      };
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kb = wfft::bin_of(lane, j, 0);                     // 0 .. 127 (lane 0, unit 0: 0 -- overwritten below)
+        four(zk[j][0], zk[j][2], zm[j][2], zm[j][0], kb);
+        four(zk[j][1], zk[j][3], zm[j][3], zm[j][1], 256 - kb);
+      }
+      if (lane == 0) {
+        // unit 0 of lane 0 holds Z at 0, 256, 128, 384 (zk) and 0, 768, 896, 640 (zm), Z[512] apart
+        four(zk[0][0], z512, z512, zk[0][0], 0);
+        four(zk[0][1], zm[0][1], zk[0][1], zm[0][1], 256);
+        four(zk[0][2], zm[0][3], zk[0][3], zm[0][2], 128);
+      }
+      if (lane >= 1 && lane < PS - 256) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) row0[f * PS + 256 + lane] = 0.f;                       // [257, PS): zero weights
+      }
+    } else {
+      for (int k = lane; k < 4 * PS; k += 64) row0[k] = 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- projection: unit = (mel tile, half of the 32 frames)
+  const int n_mt = (n_mels + 15) >> 4;
+  const int n = lane & 15, kk = lane >> 4;
+  for (int u = w; u < 2 * n_mt; u += NW) {
+    const int mt = u >> 1, fh = u & 1;
+    const float* arow = basis_p + (size_t)(16 * mt + n) * FP + 4 * kk;
+    const float* brow = P + (16 * fh + n) * PS + 4 * kk;
+    v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int g = 0; g < FP / 16; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * g);
+      const float4 b4 = *reinterpret_cast<const float4*>(brow + 16 * g);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc2, 0, 0, 0);
+    }
+    acc += acc2;
+    const int64_t t = t0 + 16 * fh + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = 16 * mt + 4 * kk + i;
+      if (m < n_mels && t < T) mel_out[(b * n_mels + m) * T + t] = acc[i];
     }
   }
 }
@@ -445,6 +579,17 @@ extern "C" int syg_stft_mel_pow2_f32(const float* y, int64_t B, int64_t L, int64
     SYG_CHECK_LAUNCH("stft_mel_pow2");
     return SYG_OK;
   }
+  if (n_fft == 512) {
+    const size_t lds = (size_t)W512Lds::TOTAL * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)stft_mel_w512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("stft_mel_pow2: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return SYG_E_LAUNCH; }
+    const int tiles = (int)((T + 31) / 32);
+    // (twiddle: [W_512^k (512) | W_256^k (256) | W_1024^k (1024)]: the wave FFT's tables come from the third block)
+    hipLaunchKernelGGL(stft_mel_w512_kernel, dim3((unsigned)(B * tiles)), dim3(512), lds, (hipStream_t)stream, y, L, ldy, hop,
+                       center ? 256 : 0, T, window, (const float2*)twiddle + 768, basis_p, n_mels, power, mel_out, tiles);
+    SYG_CHECK_LAUNCH("stft_mel_pow2");
+    return SYG_OK;
+  }
   const size_t lds = lds_bytes(n_fft, Fp, 0, 0);
   SYG_REQUIRE(lds <= LDS_LIMIT, "stft_mel_pow2: n_fft=%d needs %zu B of LDS", n_fft, lds);
   auto kern = stft_mel_pow2_kernel<NWAVES, false>;
@@ -478,7 +623,7 @@ extern "C" int syg_stft_mfcc_pow2_f32(const float* y, int64_t B, int64_t L, int6
   if (rc) return rc;
   SYG_REQUIRE(dct && mfcc_out, "stft_mfcc_pow2: null pointer argument");
   SYG_REQUIRE(n_mfcc >= 1 && n_mfcc <= n_mels, "stft_mfcc_pow2: need 1 <= n_mfcc <= n_mels");
-  SYG_REQUIRE(amin > 0.f, "stft_mfcc_pow2: amin must be strictly positive");
+  SYG_REQUIRE(amin >= 1.17549435e-38f, "stft_mfcc_pow2: amin must be strictly positive (a normal float)");
   SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft_mfcc_pow2: ref_is_max must be 0 or 1");
   SYG_REQUIRE(B <= 0x7fffffff, "stft_mfcc_pow2: too many clips");
   const int tiles = (int)((T + 15) / 16);

@@ -161,7 +161,10 @@ def _pow2_front(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fma
     cfg = mel_config(sr, n_fft, n_mels, fmin, fmax)
     bp, Fp = _basis_padded(cfg, n_fft)
     win = window_dev(window, n_fft if win_length is None else win_length, n_fft)
-    return y, B, L, Tn, bp, Fp, win, twiddle_rfft_dev(n_fft)
+    # (n_fft 512: the twiddle block is followed by W_1024^k -- four frames share one 1024-point wave transform)
+    tw = twiddle_rfft_dev(n_fft) if n_fft != 512 else _cached(("twr512+1024",), lambda: _dev(np.concatenate(
+        [T.twiddles(512), T.twiddles(256), T.twiddles(1024)], axis=0)))
+    return y, B, L, Tn, bp, Fp, win, tw
 
 
 def stft_mel_pow2(y: torch.Tensor, sr: float, n_fft: int, hop: int, center: bool = True, window="hann", win_length=None,
