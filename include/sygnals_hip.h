@@ -203,7 +203,8 @@ int syg_mel_dense_f32(const float* P, int64_t B, int64_t T, int F, const float* 
  * 1024 and 256: tests/test_features_manager.py:183-220, cli/features_cmd.py:35): librosa.stft -> |.|^power -> mel
  * filterbank in one launch, no spectrogram in HBM (manager.py:184-187, 198, 219-222).
  *   y .. window   as syg_stft_pow2_c2c_f32;  twiddle [n_fft + n_fft/2] complex (W_nfft^k, then W_{nfft/2}^k), for
- *              n_fft = 512 followed by W_1024^k (1024 entries: four frames share one 1024-point wave transform)
+ *              n_fft = 512 and 256 followed by W_1024^k (1024 entries: four / eight frames share one 1024-point wave
+ *              transform)
  *   basis_p    [16*ceil(n_mels/16), Fp] the dense filterbank, zero padded: Fp = (1 + n_fft/2) rounded up to a multiple
  *              of 16; 16-byte aligned
  *   power      1 (magnitude) or 2 (power)

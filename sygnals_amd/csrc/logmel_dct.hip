@@ -85,7 +85,7 @@ dct_stage:
   }
 }
 
-// The same with the clip's matrix staged in LDS (M * T * 4 bytes <= 96 KiB: every clip of the BASELINE configurations and of
+// The same with the clip's matrix staged in LDS (M * T * 4 bytes <= 144 KiB: every clip of the BASELINE configurations and of
 // the other frame lengths' tile kernels): one read of the mel matrix, the dB matrix written once (the in-place /
 // logmel_out contract) and read back from LDS by the DCT, whose rows wait in registers; 512 threads.  The form above read
 // the matrix from global memory three times, one dependent L2 round trip per DCT step (32 us per 1024 clips at T = 188).
@@ -295,7 +295,7 @@ extern "C" int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const
   if (mfcc_out) SYG_REQUIRE(dct && K >= 1 && K <= M, "logmel_dct: need dct and 1 <= K <= M (K=%d M=%d)", K, M);
   SYG_REQUIRE(B < (int64_t)0x7fffffff, "logmel_dct: batch too large");
   const size_t lds = (size_t)M * (size_t)T * sizeof(float);
-  if (ref_is_max != 2 && lds <= 96 * 1024 && M <= 128) {
+  if (ref_is_max != 2 && lds <= 144 * 1024 && M <= 128) {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)logmel_dct_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("logmel_dct: cannot reserve %zu B of LDS", lds); return SYG_E_LAUNCH; }

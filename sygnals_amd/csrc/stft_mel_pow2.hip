@@ -525,6 +525,139 @@ __global__ __launch_bounds__(512, SYG_P2_TILE_WAVES) void stft_mel_w512_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// n_fft = 256 on the wave FFT: EIGHT real frames per 1024-point complex transform.  Four complex sequences p_r = a_r + i b_r
+// (r = 0 .. 3, two windowed 256-sample frames each) are interleaved as z[4 n + r] = p_r[n]:
+//   Z[k + 256 d] = sum_r (-i)^(r d) W_1024^(r k) P_r[k]          (P_r: the 256-point transform of p_r)
+// so that X_r = W^(r k) P_r[k] is the inverse 4-point transform of the lane's four values Z[k + 256 d] -- U_r / 4 with
+// U_r = sum_d Z[k + 256 d] i^(r d) -- and the mirror bin 256 - k comes from the lane's four mirror values the same way
+// (V_r = sum_d Z[256 - k + 256 d] i^(r d)): P_r[256 - k] = i^r W^(r k) V_r / 4.  The twiddle W^(r k) is common to
+// P_r[k] and conj P_r[256 - k] and drops out of the POWERS:
+//   64 |A_r[k]|^2 = |U_r + (-i)^r conj V_r|^2        64 |B_r[k]|^2 = |U_r - (-i)^r conj V_r|^2
+// Lane 0's first unit (the self-mirrored groups) supplies bins 0 and 128.  A wave owns the frames 8 w .. 8 w + 7 of a
+// 64-frame tile; its eight power rows alias its exchange scratch.  Tile form only.
+struct W256Lds {
+  static constexpr int FP = 144, PS = FP + 4;
+  static constexpr int SCW = 8 * PS;                                  // per-wave scratch: 1184 floats >= 528 complex
+  static constexpr int O_SC = 0;
+  static constexpr int O_TW2 = O_SC + 8 * SCW;
+  static constexpr int O_TW1 = O_TW2 + wfft::TW2_COMPLEX * 2;
+  static constexpr int TOTAL = O_TW1 + wfft::TW1_COMPLEX * 2;
+  static_assert(SCW >= 2 * wfft::SC_COMPLEX, "the exchange scratch must fit inside the eight aliased rows");
+};
+
+__global__ __launch_bounds__(512, SYG_P2_TILE_WAVES) void stft_mel_w256_kernel(
+    const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, const float* __restrict__ win,
+    const float2* __restrict__ tw1024, const float* __restrict__ basis_p, int n_mels, int power,
+    float* __restrict__ mel_out, int tiles_per_clip) {
+  typedef W256Lds LM;
+  constexpr int NW = 8, FP = LM::FP, PS = LM::PS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2* sc = reinterpret_cast<float2*>(lds + LM::O_SC + w * LM::SCW);
+  float2* tw2l = reinterpret_cast<float2*>(lds + LM::O_TW2);
+  float2* tw1l = reinterpret_cast<float2*>(lds + LM::O_TW1);
+  float* P = lds + LM::O_SC;                       // row fi at fi * PS: rows 8 w .. 8 w + 7 inside wave w's scratch
+  wfft::Lane lc;
+  wfft::init_lane(lc, lane);
+  const int64_t b = blockIdx.x / tiles_per_clip;
+  const int64_t t0 = (blockIdx.x - b * tiles_per_clip) * 64;
+  const float* yb = y + b * ldy;
+  // element 64 a + lane of z: sequence r = lane & 3 = frames (8 w + 2 r, 8 w + 2 r + 1), sample n = 16 a + lane / 4
+  const int64_t tf = t0 + 8 * w + 2 * (lane & 3);
+  const int nl = lane >> 2;
+  float2 v[16];
+  if (t0 + 8 * w < T) {
+    const int64_t sa = tf * (int64_t)hop - pad, sb = sa + hop;
+    const bool hasa = tf < T, hasb = tf + 1 < T;
+    const int64_t s_first = (t0 + 8 * w) * (int64_t)hop - pad;
+    if (s_first >= 0 && s_first + 7 * (int64_t)hop + 256 <= L && t0 + 8 * w + 7 < T) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const float wv = win[16 * a + nl];
+        v[a] = make_float2(yb[sa + 16 * a + nl] * wv, yb[sb + 16 * a + nl] * wv);
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const int64_t ia = sa + 16 * a + nl, ib = sb + 16 * a + nl;
+        const float wv = win[16 * a + nl];
+        v[a] = make_float2((hasa && ia >= 0 && ia < L) ? yb[ia] * wv : 0.f, (hasb && ib >= 0 && ib < L) ? yb[ib] * wv : 0.f);
+      }
+    }
+  }
+  if (tid < 64) tw2l[(tid >> 4) * wfft::TW2_STRIDE + (tid & 15)] = tw1024[(16 * (tid >> 4) * (tid & 15)) & 1023];
+  for (int i = tid; i < wfft::TW1_COMPLEX; i += NW * 64) tw1l[i] = tw1024[(i & 63) * ((i >> 6) + 1)];
+  __syncthreads();
+  {
+    float* row0 = P + (8 * w) * PS;
+    if (t0 + 8 * w < T) {
+      float2 zk[2][4], zm[2][4], z512;
+      wfft::cfft1024(v, lc, sc, tw1l, tw2l, lane, zk, zm, z512);
+      // z[d] = Z[k + 256 d], m[d] = Z[256 - k + 256 d]  ->  the eight frames' powers at bin k
+      auto eight = [&](float2 z0, float2 z1, float2 z2, float2 z3, float2 m0, float2 m1, float2 m2, float2 m3, int bin) {
+        float2 F[4], G[4];
+        bfly4(z0, z1, z2, z3, F[0], F[1], F[2], F[3]);          // F[q] = sum_d z[d] (-i)^(d q): U_r = F[(4 - r) & 3]
+        bfly4(m0, m1, m2, m3, G[0], G[1], G[2], G[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float2 U = F[(4 - r) & 3], V = G[(4 - r) & 3];
+          // (-i)^r conj V
+          const float2 Tt = r == 0 ? make_float2(V.x, -V.y) : r == 1 ? make_float2(-V.y, -V.x)
+                          : r == 2 ? make_float2(-V.x, V.y) : make_float2(V.y, V.x);
+          const float ax = U.x + Tt.x, ay = U.y + Tt.y, bx = U.x - Tt.x, by = U.y - Tt.y;
+          const float pa = 0.015625f * fmaf(ax, ax, ay * ay), pb = 0.015625f * fmaf(bx, bx, by * by);
+          row0[(2 * r) * PS + bin] = (power == 2) ? pa : sqrtf(pa);
+          row0[(2 * r + 1) * PS + bin] = (power == 2) ? pb : sqrtf(pb);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kb = wfft::bin_of(lane, j, 0);                     // 0 .. 127 (lane 0, unit 0: 0 -- overwritten below)
+        eight(zk[j][0], zk[j][1], zk[j][2], zk[j][3], zm[j][3], zm[j][2], zm[j][1], zm[j][0], kb);
+      }
+      if (lane == 0) {
+        // unit 0 of lane 0 holds Z at 0, 256, 128, 384 (zk) and 0, 768, 896, 640 (zm), Z[512] apart
+        eight(zk[0][0], zk[0][1], z512, zm[0][1], zk[0][1], z512, zm[0][1], zk[0][0], 0);
+        eight(zk[0][2], zk[0][3], zm[0][3], zm[0][2], zk[0][2], zk[0][3], zm[0][3], zm[0][2], 128);
+      }
+      if (lane >= 1 && lane < PS - 128) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) row0[f * PS + 128 + lane] = 0.f;                       // [129, PS): zero weights
+      }
+    } else {
+      for (int k = lane; k < 8 * PS; k += 64) row0[k] = 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- projection: unit = (mel tile, quarter of the 64 frames)
+  const int n_mt = (n_mels + 15) >> 4;
+  const int n = lane & 15, kk = lane >> 4;
+  for (int u = w; u < 4 * n_mt; u += NW) {
+    const int mt = u >> 2, fq = u & 3;
+    const float* arow = basis_p + (size_t)(16 * mt + n) * FP + 4 * kk;
+    const float* brow = P + (16 * fq + n) * PS + 4 * kk;
+    v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < FP / 16; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * g);
+      const float4 b4 = *reinterpret_cast<const float4*>(brow + 16 * g);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc2, 0, 0, 0);
+    }
+    acc += acc2;
+    const int64_t t = t0 + 16 * fq + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = 16 * mt + 4 * kk + i;
+      if (m < n_mels && t < T) mel_out[(b * n_mels + m) * T + t] = acc[i];
+    }
+  }
+}
+
 size_t w1024_lds_bytes(int n_mels, int tp) {
   const int n_mt = (n_mels + 15) / 16;
   return ((size_t)W1024Lds::O_PART + (size_t)2 * n_mt * 256 + (size_t)n_mels * tp + 8 + 2) * sizeof(float);
@@ -576,6 +709,17 @@ extern "C" int syg_stft_mel_pow2_f32(const float* y, int64_t B, int64_t L, int64
     memset(&mf, 0, sizeof(mf));
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(512), lds, (hipStream_t)stream, y, L, ldy, hop,
                        center ? 512 : 0, T, window, (const float2*)twiddle, basis_p, n_mels, power, mel_out, tiles, mf);
+    SYG_CHECK_LAUNCH("stft_mel_pow2");
+    return SYG_OK;
+  }
+  if (n_fft == 256) {
+    const size_t lds = (size_t)W256Lds::TOTAL * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)stft_mel_w256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("stft_mel_pow2: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return SYG_E_LAUNCH; }
+    const int tiles = (int)((T + 63) / 64);
+    // (twiddle: [W_256^k (256) | W_128^k (128) | W_1024^k (1024)]: the wave FFT's tables come from the third block)
+    hipLaunchKernelGGL(stft_mel_w256_kernel, dim3((unsigned)(B * tiles)), dim3(512), lds, (hipStream_t)stream, y, L, ldy, hop,
+                       center ? 128 : 0, T, window, (const float2*)twiddle + 384, basis_p, n_mels, power, mel_out, tiles);
     SYG_CHECK_LAUNCH("stft_mel_pow2");
     return SYG_OK;
   }

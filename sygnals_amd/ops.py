@@ -161,9 +161,9 @@ def _pow2_front(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fma
     cfg = mel_config(sr, n_fft, n_mels, fmin, fmax)
     bp, Fp = _basis_padded(cfg, n_fft)
     win = window_dev(window, n_fft if win_length is None else win_length, n_fft)
-    # (n_fft 512: the twiddle block is followed by W_1024^k -- four frames share one 1024-point wave transform)
-    tw = twiddle_rfft_dev(n_fft) if n_fft != 512 else _cached(("twr512+1024",), lambda: _dev(np.concatenate(
-        [T.twiddles(512), T.twiddles(256), T.twiddles(1024)], axis=0)))
+    # (n_fft 512 / 256: the twiddle block is followed by W_1024^k -- four / eight frames share one 1024-point wave transform)
+    tw = twiddle_rfft_dev(n_fft) if n_fft not in (256, 512) else _cached(("twr+1024", n_fft), lambda: _dev(np.concatenate(
+        [T.twiddles(n_fft), T.twiddles(n_fft // 2), T.twiddles(1024)], axis=0)))
     return y, B, L, Tn, bp, Fp, win, tw
 
 

@@ -251,6 +251,8 @@ def test_mel_dense_mfma_shapes(ops, n_fft, n_mels, L):
     (512, 200, 64, 30000, False),      # center=False, hop that is not a multiple of 4, 64 mels
     (512, 128, 40, 700, True),         # a clip of 1.4 frames
     (256, 64, 13, 4000, True),         # the CLI's small frame
+    (256, 64, 40, 48000, True),        # tests/test_features_manager.py's other frame length at 1 s @ 48 kHz
+    (256, 100, 64, 12345, False),      # center=False, odd everything
     (1024, 300, 40, 9000, False),      # center=False, hop that does not divide anything
     (64, 16, 8, 1000, True),           # the smallest frame
     (1024, 512, 20, 600, True),        # clip shorter than a frame
@@ -274,7 +276,7 @@ def test_mfcc_batch_other_frame_lengths(ops, n_fft, hop, n_mels, L, center):
     mf1, mel1 = ops.stft_mfcc_pow2(y, sr, n_fft, hop, center, "hann", None, n_mels, n_mfcc, keep_mel=True)
     assert np.array_equal(mf1.cpu().numpy(), got)
     mel_t = ops.stft_mel_pow2(y, sr, n_fft, hop, center, "hann", None, n_mels).cpu().numpy()
-    if n_fft == 512:        # (clip form: LDS Stockham transform; tile form: four frames per wave transform)
+    if n_fft in (256, 512):        # (clip form: LDS Stockham transform; tile form: four / eight frames per wave transform)
         assert peak_rel(mel1.cpu().numpy(), mel_t) <= 2e-6
     else:
         assert np.array_equal(mel1.cpu().numpy(), mel_t)                     # clip form and tile form: same bits

@@ -42,7 +42,7 @@ Tn = 94
 report("C2 a1-a5 STFT->mel->MFCC (one launch)", lambda: ops.mfcc_batch(y, SR, n_mels=40), B * L, B * (4 * L + 4 * 13 * Tn), n=100)
 report("a1 complex STFT 2048/512 (frame-major c64 out)", lambda: ops.stft2048_c2c(y[:256]), 256 * L, 256 * (4 * L + 8 * 1025 * Tn), "256 clips")
 # the other power-of-two frame lengths (the reference's tests: 1024 / 256): one launch, clip-resident
-for nf, hp in ((1024, 256), (512, 128)):
+for nf, hp in ((1024, 256), (512, 128), (256, 64)):
     Tf = 1 + L // hp
     report(f"a1-a5 STFT->mel->MFCC n_fft={nf} hop={hp} (mfcc_batch default, 1024 clips)", lambda: ops.mfcc_batch(y, SR, nf, hp, n_mels=40), B * L,
            B * (4 * L + 4 * 13 * Tf))
