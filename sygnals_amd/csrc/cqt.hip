@@ -32,7 +32,10 @@ __global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restri
   const int64_t b = blockIdx.y;
   const float* xb = x + b * ldx;
   const int tid = threadIdx.x;
-  const bool pair_ok = ((ldx & 1) == 0) && ((((uintptr_t)x) & 7) == 0);
+  // the fast path moves the input run with 16-byte loads (an 8-byte load per lane runs at 0.54-0.70 of that rate --
+  // MI355X_MICROARCH.md, table of load flavours -- and this pass is bound by its 1.3 GB of traffic): tile starts are
+  // multiples of four samples by construction (NF << NL and HALF (2^NL - 1) both are)
+  const bool pair_ok = ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
   for (int j = tid; j < ntaps; j += DEC_NT) hs[j] = taps[j];
   for (int64_t n0 = (int64_t)blockIdx.x * DEC_NBO; n0 < Lout; n0 += (int64_t)gridDim.x * DEC_NBO) {
     // lowest input index used: 2 n0 + half - (ntaps - 1) = 2 n0 - half; mbase = floor(that / 2)
@@ -252,7 +255,9 @@ __global__ __launch_bounds__(DEC_NT, SYG_DEC_WAVES) void decimate2_chain_kernel(
   // neighbours both need then come from that XCD's L2 the second time
   const int64_t per_x = (ntiles + 7) / 8;
   constexpr int NP0 = DC::cnt(0) / 2;
-  constexpr int NR0 = (NP0 + DEC_NT - 1) / DEC_NT;
+  static_assert(NP0 % 2 == 0 && ((DC::NF << NL) % 4) == 0 && ((HALF * ((1 << NL) - 1)) % 4) == 0, "16-byte input runs");
+  constexpr int NQ0 = NP0 / 2;                    // 16-byte pieces (two pairs) of the input run
+  constexpr int NR0 = (NQ0 + DEC_NT - 1) / DEC_NT;
   constexpr int A0OFF = HALF * ((1 << NL) - 1);  // a[0] = 2^NL a[NL] - HALF (2^NL - 1)
 #ifdef SYG_DEC_NOXCD
   auto tile_of = [&](int64_t wg) { return wg; };
@@ -265,13 +270,13 @@ __global__ __launch_bounds__(DEC_NT, SYG_DEC_WAVES) void decimate2_chain_kernel(
   };
   // the input run of the NEXT tile is requested before the levels of the current one are computed (a workgroup
   // without loads in flight for three levels' worth of arithmetic leaves the memory system idle)
-  float2 v[NR0];
+  float4 v[NR0];
   auto request = [&](int64_t tile) {
-    const float2* xp = reinterpret_cast<const float2*>(xb + (tile * ((int64_t)DC::NF << NL) - A0OFF));
+    const float4* xp = reinterpret_cast<const float4*>(xb + (tile * ((int64_t)DC::NF << NL) - A0OFF));
 #pragma unroll
     for (int r = 0; r < NR0; ++r) {
       const int u = tid + r * DEC_NT;
-      if (r + 1 < NR0 || u < NP0) v[r] = xp[u];
+      if (r + 1 < NR0 || u < NQ0) v[r] = xp[u];
     }
   };
   int64_t wg = blockIdx.x;
@@ -291,8 +296,11 @@ __global__ __launch_bounds__(DEC_NT, SYG_DEC_WAVES) void decimate2_chain_kernel(
       if (is_fast(tile)) {
 #pragma unroll
         for (int r = 0; r < NR0; ++r) {
-          const int u = tid + r * DEC_NT;
-          if (r + 1 < NR0 || u < NP0) { E[u] = v[r].x; O[u] = v[r].y; }
+          const int u = tid + r * DEC_NT;               // piece u = pairs 2 u, 2 u + 1
+          if (r + 1 < NR0 || u < NQ0) {
+            reinterpret_cast<float2*>(E)[u] = make_float2(v[r].x, v[r].z);
+            reinterpret_cast<float2*>(O)[u] = make_float2(v[r].y, v[r].w);
+          }
         }
       } else {                                     // a tile at either end of the signal
 #pragma unroll 1
@@ -328,6 +336,7 @@ __global__ __launch_bounds__(DEC_NT, SYG_DEC_WAVES) void decimate2_chain_kernel(
       const int wlo = w0 > vlo ? w0 : vlo, whi = w0 + span < vhi ? w0 + span : vhi;
       float* ybase = reinterpret_cast<float*>(uniform64((int64_t)(uintptr_t)ol.y[s - 1]));
       float* yo = ybase ? ybase + b * uniform64(ol.ld[s - 1]) + a[s] : nullptr;   // (only owned, existing indices are touched)
+      const bool st2 = (((uintptr_t)yo) & 7) == 0;    // (a[s] is even: 8-byte aligned whenever the level's rows are)
 #pragma unroll 1
       for (int pr = tid; pr < npout; pr += DEC_NT) {
         const int nl = 2 * pr;                     // local index of the pair's first output (window starts at pair nl)
@@ -359,8 +368,12 @@ __global__ __launch_bounds__(DEC_NT, SYG_DEC_WAVES) void decimate2_chain_kernel(
         const float v1 = (nl + 1 >= vlo && nl + 1 < vhi) ? a1 * scale : 0.f;
         if (s < NL) { En[pr] = v0; On[pr] = v1; }
         if (yo) {
-          if (nl >= wlo && nl < whi) yo[nl] = v0;
-          if (nl + 1 >= wlo && nl + 1 < whi) yo[nl + 1] = v1;
+          if (st2 && nl >= wlo && nl + 1 < whi) {          // both outputs owned: one 8-byte store
+            *reinterpret_cast<float2*>(yo + nl) = make_float2(v0, v1);
+          } else {
+            if (nl >= wlo && nl < whi) yo[nl] = v0;
+            if (nl + 1 >= wlo && nl + 1 < whi) yo[nl + 1] = v1;
+          }
         }
       }
     }

@@ -20,6 +20,10 @@ B = 1024
 Y = synth_clips(64, 48000, 48000, seed=1); y = ops.to_device_f32(np.tile(Y, (B // 64, 1)))
 CP = T.contrast_plan(np.fft.rfftfreq(2048, 1 / 48000), 48000)
 from sygnals_amd.core.features.manager import feature_block as FB
+stream = None
+if what == "cqt":
+    g = torch.Generator(device="cuda").manual_seed(5)
+    stream = (torch.randn(48000 * 3600, device="cuda", generator=g, dtype=torch.float32) * 0.05).reshape(1, -1)
 y2 = ops.to_device_f32(np.tile(Y, (2048 // 64, 1))) if what.startswith("c4blk") else None
 fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "mel": lambda: ops.stft2048_mel(y, 48000, n_mels=40),
@@ -28,16 +32,18 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "mfcc512": lambda: ops.stft_mfcc_pow2(y, 48000, 512, 128, True, "hann", None, 40, 13),
       "c4blk1": lambda: FB(y2, 48000, one_launch=True),
       "c4blk2": lambda: FB(y2, 48000, one_launch=False),
+      "cqt": lambda: ops.cqt(stream, 48000),
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
-for _ in range(400): fn()
+for _ in range(400 if what != "cqt" else 20): fn()
 torch.cuda.synchronize()
 best = 1e9
 for rep in range(5):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(100): fn()
+    nrep = 100 if what != "cqt" else 10
+    for _ in range(nrep): fn()
     e1.record(); torch.cuda.synchronize()
-    best = min(best, e0.elapsed_time(e1) * 10)
+    best = min(best, e0.elapsed_time(e1) * 1000 / nrep)
 print("US", best)
 '''
 res = {n: [] for n, _ in libs}
