@@ -133,6 +133,22 @@ int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int
                           const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
                           float* mel_out, float* mfcc_out, void* stream);
 
+/* The same chain for TRIANGULAR filterbanks (librosa.filters.mel as manager.py:198 / cepstral.py:106 build it), the mel
+ * projection by SEGMENT SUMS: between two band edges the weights of the rising and of the falling band are affine in
+ * the bin index, so a run of bins contributes a T0 + b T1 (T0 = sum p, T1 = sum i p) -- each wave projects its own
+ * power row, no weight matrix is read and the projection needs no workgroup barrier.
+ *   segtab     device, 16-byte aligned: the piece table of sygnals_amd._tables.pack_mel_segments, [2][2][64][4] words
+ *              (n_segtab = 1024); filterbanks whose pieces do not fit 128 lane slots have no table -- use the matrix form
+ *   other arguments as syg_stft2048_mfcc_f32 (no mel copy: the matrix form stores one)
+ * Needs TWO mel matrices in LDS (the dB + DCT of a clip runs beside the next clip's first tile):
+ * syg_stft2048_mfcc_tri_fits() says whether a shape fits. */
+int syg_stft2048_mfcc_tri_fits(int n_mels, int64_t T, int n_mfcc);
+int syg_stft2048_mfcc_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
+                              int64_t T, const float* window, const float* twiddle, const float* segtab,
+                              int n_segtab, int n_mels, const float* dct, int n_mfcc, const float* lifter,
+                              float amin, float top_db, int ref_is_max, float ref_value, float* mfcc_out,
+                              void* stream);
+
 /* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at
  * manager.py:223 and librosa.feature.mfcc(S=..) at cepstral.py:106-115.

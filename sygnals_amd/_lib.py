@@ -26,6 +26,8 @@ SIGNATURES = {
     "syg_stft2048_mel_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p, _i, _p, _f, _f, _f, _i, _p, _p, _p, _p]),
     "syg_stft2048_c2c_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p]),
     "syg_stft2048_mfcc_fits": (_i, [_i, _l, _i]),
+    "syg_stft2048_mfcc_tri_fits": (_i, [_i, _l, _i]),
+    "syg_stft2048_mfcc_tri_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _i, _i, _p, _i, _p, _f, _f, _i, _f, _p, _p]),
     "syg_stft2048_mfcc_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p, _i, _p, _i, _p, _f, _f, _i, _f, _p, _p, _p]),
     "syg_stft2048_features_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p, _i, _p, _i, _p, _f, _f, _i, _f, _f, _f, _f, _i, _p, _p,
                                        _p, _p, _p, _i, _p]),

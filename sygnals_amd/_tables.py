@@ -164,6 +164,252 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
     return np.ascontiguousarray(wpacked), plan
 
 
+SEG_SLOTS = 128         # lane slots of the segment-sum projection: 2 passes x 64 lanes
+SEG_LEAD_MAX = 4        # window words that may lie before the piece (the kernel's first SEG_LEAD_MAX steps test `lead <= i`)
+
+
+def _distinct_banks(options):
+    """Maximum bipartite matching lane -> LDS bank: options[l] = candidate banks of lane l, in order of preference.
+    Returns one bank per lane; unmatched lanes (more lanes than free banks among their candidates) take their first."""
+    owner = {}
+
+    def augment(u, seen):
+        for b in options[u]:
+            if b in seen:
+                continue
+            seen.add(b)
+            if b not in owner or augment(owner[b], seen):
+                owner[b] = u
+                return True
+        return False
+
+    for u in range(len(options)):
+        augment(u, set())
+    got = {u: b for b, u in owner.items()}
+    return [got.get(u, options[u][0]) for u in range(len(options))]
+
+
+def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None):
+    """Piece table of the fused kernel's per-wave mel projection by SEGMENT SUMS (stft_mel.hip, MODE 6).
+
+    A triangular filterbank is piecewise linear in the bin index: between two neighbouring band edges e[s], e[s+1]
+    (segment s) the only non-zero weights are the rising side of band s and the falling side of band s - 1, both affine
+    in k.  With T0 = sum p[k] and T1 = sum i' p[k] over a run of bins (i' = distance from the run's LAST bin) the run's
+    contribution to band s is aR T0 + bR T1 and to band s - 1 aF T0 + bF T1 -- two sums per run instead of two weights
+    per bin, and no weight matrix.  The bins of a segment are cut at the 16-bin blocks of the kernel's skewed power rows
+    (row_pos: no pad word inside a piece); one lane sums one piece (<= 16 bins), the pieces of a segment sit in
+    neighbouring lanes of one 16-lane row (a "run") and are combined by two segmented scans on the DPP path: rising
+    sums towards the run's last lane, falling sums towards its first lane, so that band s = R(run s, last lane) +
+    F(run s + 1, first lane) meets in neighbouring lanes.  The pieces are spread evenly over the eight 16-lane rows.
+
+    A lane reads a WINDOW of 17 consecutive row words that starts `lead` words before its piece (0 .. SEG_LEAD_MAX, as
+    far as the piece still fits): the 32 lanes that share an LDS access are given windows in distinct banks wherever a
+    matching exists (the piece starts alone collide: segment starts fall anywhere between the block starts, which are
+    17 words apart).
+
+    Returns float32 [2 passes][2][64 lanes][4] (bit patterns for the integers; the kernel keeps the table in LDS and
+    reads two 16-byte words per lane and pass):
+        q0 = (BYTE offset of the window inside a power row | (lead + bins in the piece) << 16 | lead << 24 (idle lane:
+              0 bins, lead 7),
+              band stored by this lane or -1,
+              links of the rising scan, one BYTE per step: 1 = the lane 1 / 2 / 4 / 8 below belongs to the same run,
+              links of the falling scan: the lane 1 / 2 / 4 / 8 above)
+        q1 = (aR, bR, aF, bF)
+    Raises ValueError when the filterbank does not fit the 128 slots / 16-lane runs, or when `basis` (the float32
+    matrix the oracle multiplies by) is not reproduced by the affine pieces to 2e-7 of its largest weight.
+    """
+    F = n_fft // 2 + 1
+    fmax = sr / 2.0 if fmax is None else fmax
+    e = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    d = np.diff(e)
+    if not np.all(d > 0):
+        raise ValueError("band edges must increase")
+    en = 2.0 / (e[2:] - e[:-2])
+    df = sr / n_fft
+    seg = np.searchsorted(e, np.arange(F) * df, side="right") - 1     # e[s] <= f_k < e[s + 1]
+    runs = [[] for _ in range(n_mels + 1)]
+    for blk in range((F + 15) // 16):
+        ks = np.arange(blk * 16, min(blk * 16 + 16, F))
+        for s in np.unique(seg[ks]):
+            if s < 0 or s > n_mels:
+                continue
+            kk = ks[seg[ks] == s]
+            k0, k1 = int(kk[0]), int(kk[-1]) + 1
+            fl = df * (k1 - 1)                       # frequency of the piece's last bin (i' = 0)
+            aR = en[s] * (fl - e[s]) / d[s] if s <= n_mels - 1 else 0.0
+            bR = -en[s] * df / d[s] if s <= n_mels - 1 else 0.0
+            aF = en[s - 1] * (e[s + 1] - fl) / d[s] if s >= 1 else 0.0
+            bF = en[s - 1] * df / d[s] if s >= 1 else 0.0
+            runs[s].append((k0, k1, aR, bR, aF, bF))
+    idle = (0, 0, 0.0, 0.0, 0.0, 0.0)
+    runs = [run if run else [idle] for run in runs]       # a segment without a bin still separates its neighbours
+    if max(len(r) for r in runs) > 16:
+        raise ValueError("a segment spans more than 16 blocks")
+    # runs -> rows of 16 lanes, in order; a run stays inside one row, the idle lanes at a row's end join the run before
+    # them (its rising total then waits in the row's last lane).  How many lanes of each row are used is free: a small
+    # deterministic search over row fillings keeps the one whose windows collide least.
+    n_rows = SEG_SLOTS // 16
+    total = sum(len(r) for r in runs)
+
+    def fill(caps):
+        slots, nxt = [], 0
+        for row in range(n_rows):
+            used = 0
+            while nxt < len(runs) and used + len(runs[nxt]) <= 16 and (used == 0 or used + len(runs[nxt]) <= caps[row]):
+                slots += [(pc, nxt) for pc in runs[nxt]]
+                used += len(runs[nxt]); nxt += 1
+            slots += [(idle, nxt - 1 if used else -2 - row)] * (16 - used)
+        return slots if nxt == len(runs) else None
+
+    def leads_of(n, q):
+        """Leads a piece of n bins at row position q may take: the window holds 17 words, its first SEG_LEAD_MAX words are
+        entered by `lead <= i` alone, so the piece must not end before them."""
+        return [ld for ld in range(max(0, SEG_LEAD_MAX - n), min(SEG_LEAD_MAX, 17 - n) + 1) if q - ld >= 0]
+
+    def windows(slots):
+        """Leads per group of 32 lanes (one LDS access) so that the windows start in distinct banks where a matching
+        exists; returns (window starts, leads, LDS cycles of the 2 x 17 reads)."""
+        start, lead, cycles = [0] * SEG_SLOTS, [0] * SEG_SLOTS, 0
+        for g in range(SEG_SLOTS // 32):
+            lanes = [j for j in range(32 * g, 32 * g + 32) if slots[j][0][1] > slots[j][0][0]]
+            opts = []
+            for j in lanes:
+                k0, k1 = slots[j][0][:2]
+                opts.append([(row_pos(k0) - ld) % 32 for ld in leads_of(k1 - k0, row_pos(k0))])
+            for j, b in zip(lanes, _distinct_banks(opts)):
+                k0, k1 = slots[j][0][:2]
+                lead[j] = next(ld for ld in leads_of(k1 - k0, row_pos(k0)) if (row_pos(k0) - ld) % 32 == b)
+                start[j] = row_pos(k0) - lead[j]
+            for j in range(32 * g, 32 * g + 32):     # idle lanes re-read a neighbour's window (same address: no conflict)
+                if j not in lanes:
+                    start[j] = start[lanes[0]] if lanes else 0
+            st = np.unique([start[j] for j in range(32 * g, 32 * g + 32)])
+            cycles += 17 * int(np.bincount(st % 32, minlength=32).max())
+        return start, lead, cycles
+
+    if total > SEG_SLOTS:
+        raise ValueError(f"filterbank needs {total} lane slots, the projection has {SEG_SLOTS}")
+    best = None
+    rng = np.random.default_rng(12345)
+    base = -(-total // n_rows)
+    trials = [[c] * n_rows for c in range(base, 17)] + [list(rng.integers(max(base - 3, 1), 17, n_rows)) for _ in range(300)]
+    for caps in trials:
+        slots = fill(caps)
+        if slots is None:
+            continue
+        start, lead, cycles = windows(slots)
+        if best is None or cycles < best[0]:
+            best = (cycles, slots, start, lead)
+        if cycles == 17 * (SEG_SLOTS // 32):
+            break
+    if best is None:
+        raise ValueError(f"filterbank needs more than the {SEG_SLOTS} lane slots of the projection")
+    _, slots, start, lead = best
+    run_of = np.array([r for _, r in slots])
+    tab = np.zeros((2, 2, 64, 4), np.float32)
+    ti = tab.view(np.int32)
+    for j, (pc, r) in enumerate(slots):
+        p, l = divmod(j, 64)
+        k0, k1, aR, bR, aF, bF = pc
+        n = k1 - k0
+        ti[p, 0, l, 0] = (4 * start[j]) | (((lead[j] + n) if n else 0) << 16) | ((lead[j] if n else 7) << 24)
+        last = (j + 1 == SEG_SLOTS) or run_of[j + 1] != r
+        ti[p, 0, l, 1] = r if (last and 0 <= r <= n_mels - 1) else -1
+        tab[p, 1, l] = (aR, bR, aF, bF)
+        for i, dd in enumerate((1, 2, 4, 8)):
+            if j - dd >= 0 and (j - dd) // 16 == j // 16 and run_of[j - dd] == r:
+                ti[p, 0, l, 2] |= 1 << (8 * i)
+            if j + dd < SEG_SLOTS and (j + dd) // 16 == j // 16 and run_of[j + dd] == r:
+                ti[p, 0, l, 3] |= 1 << (8 * i)
+    if basis is not None:
+        Wr = segments_weights(tab, n_mels, F)
+        tol = 2e-7 * float(np.max(np.abs(basis)))
+        if Wr.shape != basis.shape or float(np.max(np.abs(Wr - basis))) > tol:
+            raise ValueError("the filterbank is not reproduced by affine pieces")
+    return np.ascontiguousarray(tab)
+
+
+def segments_read_cycles(tab: np.ndarray) -> int:
+    """LDS cycles of one wave's 2 x 17 window reads (ds_read_b32: the 32 lanes of a half wave share a cycle unless two of
+    them address different words of one bank); 68 = conflict-free."""
+    ti = tab.view(np.int32)
+    total = 0
+    for p in range(2):
+        for h in range(2):
+            st = (ti[p, 0, 32 * h:32 * h + 32, 0] & 0xFFFF) // 4
+            for i in range(17):
+                total += int(np.bincount(np.unique(st + i) % 32, minlength=32).max())
+    return total
+
+
+def _seg_slot(tab: np.ndarray, j: int):
+    """Fields of lane slot j: (first bin, bins, band, rising links [4], falling links [4], aR, bR, aF, bF)."""
+    ti = tab.view(np.int32)
+    p, l = divmod(j, 64)
+    w0 = int(ti[p, 0, l, 0])
+    hi = (w0 >> 16) & 0xFF
+    ld = ((w0 >> 24) & 7) if hi else 0
+    pos = (w0 & 0xFFFF) // 4 + ld                     # the piece's first bin sits `lead` words into the window
+    lr, lf = int(ti[p, 0, l, 2]), int(ti[p, 0, l, 3])
+    return (pos - pos // 17, hi - ld, int(ti[p, 0, l, 1]), [(lr >> (8 * i)) & 1 for i in range(4)],
+            [(lf >> (8 * i)) & 1 for i in range(4)], tab[p, 1, l, 0], tab[p, 1, l, 1], tab[p, 1, l, 2], tab[p, 1, l, 3])
+
+
+def segments_weights(tab: np.ndarray, n_mels: int, F: int) -> np.ndarray:
+    """The [n_mels, F] weight matrix a piece table stands for (float64; host check of pack_mel_segments)."""
+    W = np.zeros((n_mels, F))
+    slots = [_seg_slot(tab, j) for j in range(SEG_SLOTS)]
+    for j, (k0, n, _, lr, lf, aR, bR, aF, bF) in enumerate(slots):
+        if n == 0:
+            continue
+        top = j                                   # last lane of the run: stores the run's (rising) band
+        while slots[top][4][0]:
+            top += 1
+        first = j                                 # the lane below the run's first lane stores the falling band
+        while slots[first][3][0]:
+            first -= 1
+        rise = slots[top][2]
+        fall = slots[first - 1][2] if first >= 1 else -1
+        for i in range(n):
+            ip = n - 1 - i
+            if rise >= 0:
+                W[rise, k0 + i] += float(aR) + float(bR) * ip
+            if fall >= 0:
+                W[fall, k0 + i] += float(aF) + float(bF) * ip
+    return W
+
+
+def segments_project(tab: np.ndarray, P: np.ndarray, n_mels: int) -> np.ndarray:
+    """float32 emulation of the kernel's projection of ONE power row P [F] through a piece table: same sums, same order
+    (piece sums by running prefix, segmented scans in steps 1, 2, 4, 8) -- host-side model for the CPU tests."""
+    f32 = np.float32
+    P = np.asarray(P, f32)
+    slots = [_seg_slot(tab, j) for j in range(SEG_SLOTS)]
+    R = np.zeros(SEG_SLOTS, f32); Fv = np.zeros(SEG_SLOTS, f32)
+    for j, (k0, n, _, lr, lf, aR, bR, aF, bF) in enumerate(slots):
+        c = f32(0); t1 = f32(0)
+        for i in range(n):
+            if i > 0:
+                t1 = f32(t1 + c)
+            c = f32(c + P[k0 + i])
+        R[j] = f32(f32(bR) * t1 + f32(f32(aR) * c))         # (an fma in the kernel: one rounding less)
+        Fv[j] = f32(f32(bF) * t1 + f32(f32(aF) * c))
+    for i, dd in enumerate((1, 2, 4, 8)):
+        Rn = R.copy(); Fn = Fv.copy()
+        for j in range(SEG_SLOTS):
+            if slots[j][3][i]:
+                Rn[j] = f32(R[j] + R[j - dd])
+            if slots[j][4][i]:
+                Fn[j] = f32(Fv[j] + Fv[j + dd])
+        R, Fv = Rn, Fn
+    out = np.zeros(n_mels, f32)
+    for j in range(SEG_SLOTS):
+        b = slots[j][2]
+        if b >= 0:
+            out[b] = f32(R[j] + (Fv[j + 1] if j + 1 < SEG_SLOTS else f32(0)))
+    return out
+
+
 def dct_matrix(n_out: int, n_in: int, dct_type: int = 2, norm="ortho") -> np.ndarray:
     """Rows k < n_out of scipy.fft.dct(type=dct_type, norm=norm) as a float32 matrix [n_out, n_in]."""
     import scipy.fft

@@ -20,6 +20,8 @@ extern "C" int syg_abi_version(void) { return SYG_ABI_VERSION; }
 // results by design; build_lib.sh writes them to their own path and the Python binding refuses to load one)
 #if defined(SYG_SOSC_ABL)
 extern "C" int syg_build_variant(void) { return 100 + SYG_SOSC_ABL; }      // sosfilt_clip.hip timing ablations
+#elif defined(SYG_TRIX)
+extern "C" int syg_build_variant(void) { return 200 + SYG_TRIX; }          // stft_mel.hip MODE 6 timing experiments
 #else
 extern "C" int syg_build_variant(void) { return SYG_ABL; }
 #endif

@@ -30,6 +30,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef SYG_TRIX
+#define SYG_TRIX 0   // development experiments on MODE 6 (timing only)
+#endif
 #ifndef SYG_ABL
 #define SYG_ABL 0   // development ablations (tools/ablate.sh); 0 = product build
 #endif
@@ -97,6 +100,7 @@ struct MelPlan {
   int table_off;    // offset (in floats) of the tables inside wpacked
 };
 constexpr int MTAB_INTS = 256;
+constexpr int SEGTAB_WORDS = 2 * 2 * 64 * 4;   // piece table of the segment-sum projection (pack_mel_segments)
 
 struct ContrastPlan {
   int n_rows;
@@ -983,14 +987,126 @@ __device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr
 // (v_log_f32, 1 ulp: ~6e-6 dB at -100 dB; inputs are >= amin, never denormal; exactly 0 when x == ref).
 // Out of line (inlined, its scalars push the tile loop's SGPRs into spills); uni() re-scalarises the arguments.
 typedef __attribute__((address_space(3))) float* lds_fptr;     // (a generic pointer would make every access a flat_*)
+// ----------------------------------------------------------------------------------
+// MODE 6: the mel projection of ONE power row by ONE wave, by segment sums (sygnals_amd/_tables.py: pack_mel_segments).
+// A triangular filterbank is piecewise affine in the bin index, so a run of bins inside one segment (between two band
+// edges) contributes  a T0 + b T1  to the band rising there and  a' T0 + b' T1  to the band falling there, with
+// T0 = sum p, T1 = sum i' p (i' = distance from the run's last bin): two sums per piece, no weight matrix, and nothing a
+// second wave has to see -- the projection needs no workgroup barrier and no partial tiles.
+//   * a lane sums one piece (<= 16 bins inside one 16-bin block of the skewed row: no pad word inside) per pass, two
+//     passes; it reads a window of 17 row words that starts up to 4 words before the piece -- the host picks the leads so
+//     that the 32 lanes of an LDS access start in 32 different banks (piece starts alone collide: 144 instead of 68 LDS
+//     cycles per frame); T0 and T1 come from a running prefix (T1 += c; c += p) under the EXEC mask lead <= i < hi
+//     (v_cmpx), three vector instructions per word and no constants;
+//   * the pieces of a segment sit in neighbouring lanes of one DPP row: rising contributions are summed towards the
+//     run's last lane, falling ones towards its first lane (segmented scans in steps 1, 2, 4, 8; the per-lane link
+//     weights 0 / 1 come with the table), so band s = R(last lane of run s) + F(first lane of run s + 1) meets in
+//     neighbouring lanes (wave_shl:1; the lane after lane 63 of pass 0 is lane 0 of pass 1);
+//   * the lane at a run's end stores the band to the clip's mel matrix column and keeps the clip maximum.
+// Every sum has a fixed order: results do not depend on scheduling.
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108, DPP_WAVE_SHL1 = 0x130;
+// a lane's window: 17 consecutive row words, the piece occupies words [lead, hi) of it; the first TRI_LEAD_MAX steps
+// enter by `lead <= i` from the full mask (the host keeps hi > i there), the rest leave by `i < hi`
+constexpr int TRI_LEAD_MAX = 4;      // == sygnals_amd._tables.SEG_LEAD_MAX
+#define SYG_TRI_HEAD(i) \
+  "s_mov_b64 exec, %[sv]\n\tv_cmpx_ge_i32_e32 vcc, " #i ", %[lead]\n\tv_add_f32_e32 %[t1], %[t1], %[c]\n\tv_add_f32_e32 %[c], %[c], %[p" #i "]\n\t"
+#define SYG_TRI_STEP(i) \
+  "v_cmpx_lt_i32_e32 vcc, " #i ", %[hi]\n\tv_add_f32_e32 %[t1], %[t1], %[c]\n\tv_add_f32_e32 %[c], %[c], %[p" #i "]\n\t"
+__device__ __forceinline__ void tri_piece_sums(const float (&pw)[17], int lead, int hi, float& c, float& t1) {
+  unsigned long long sv;
+  c = 0.f; t1 = 0.f;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      SYG_TRI_HEAD(0) SYG_TRI_HEAD(1) SYG_TRI_HEAD(2) SYG_TRI_HEAD(3)
+      "s_mov_b64 exec, %[sv]\n\t"
+      SYG_TRI_STEP(4) SYG_TRI_STEP(5) SYG_TRI_STEP(6) SYG_TRI_STEP(7) SYG_TRI_STEP(8) SYG_TRI_STEP(9) SYG_TRI_STEP(10)
+      SYG_TRI_STEP(11) SYG_TRI_STEP(12) SYG_TRI_STEP(13) SYG_TRI_STEP(14) SYG_TRI_STEP(15) SYG_TRI_STEP(16)
+      "s_mov_b64 exec, %[sv]\n\t"
+      "s_nop 1"
+      : [c] "+v"(c), [t1] "+v"(t1), [sv] "=&s"(sv)
+      : [lead] "v"(lead), [hi] "v"(hi), [p0] "v"(pw[0]), [p1] "v"(pw[1]), [p2] "v"(pw[2]), [p3] "v"(pw[3]), [p4] "v"(pw[4]),
+        [p5] "v"(pw[5]), [p6] "v"(pw[6]), [p7] "v"(pw[7]), [p8] "v"(pw[8]), [p9] "v"(pw[9]), [p10] "v"(pw[10]),
+        [p11] "v"(pw[11]), [p12] "v"(pw[12]), [p13] "v"(pw[13]), [p14] "v"(pw[14]), [p15] "v"(pw[15]), [p16] "v"(pw[16])
+      : "vcc");
+}
+#undef SYG_TRI_STEP
+#undef SYG_TRI_HEAD
+static_assert(TRI_LEAD_MAX == 4, "tri_piece_sums unrolls four entry steps");
+
+// segl: the piece table in LDS, [2 passes][2][64 lanes] 16-byte words (layout: pack_mel_segments); col: the frame's
+// column of the clip's mel matrix
+__device__ __forceinline__ void tri_project(const float* __restrict__ prow, const float4* __restrict__ segl, int la,
+                                            float* __restrict__ col, int tp, float& cmax) {
+  float4 qa[2], qc[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    qa[p] = segl[(p * 2 + 0) * 64 + la];
+    qc[p] = segl[(p * 2 + 1) * 64 + la];
+  }
+#if SYG_TRIX == 2     // timing experiment (WRONG results): no table reads
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    qa[p] = make_float4(__int_as_float((((la * 17 + p * 531) & 1023) * 4) | ((9 + (la & 7)) << 16) | ((la & 3) << 24)), __int_as_float(la < 20 ? la + 20 * p : -1),
+                        __int_as_float(la & 0x0101), __int_as_float((la >> 1) & 0x0101));
+    qc[p] = make_float4(0.3f, 0.1f, 0.2f, 0.4f);
+  }
+#endif
+  float R[2], F[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const unsigned w0 = (unsigned)__float_as_int(qa[p].x);
+    const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(prow) + (w0 & 0xFFFFu));
+    float pw[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) pw[i] = src[i];
+    float c, t1;
+    tri_piece_sums(pw, (int)(w0 >> 24), (int)((w0 >> 16) & 0xFFu), c, t1);
+    R[p] = fmaf(qc[p].y, t1, qc[p].x * c);
+    F[p] = fmaf(qc[p].w, t1, qc[p].z * c);
+  }
+  // segmented scans: x += link * x(lane -/+ d), d = 1, 2, 4, 8 -- the link bytes become 0.0 / 1.0 and multiply the
+  // neighbour inside the DPP instruction; the four chains (rising / falling of the two passes) are interleaved so that
+  // no instruction reads a register written less than two instructions before (DPP hazard)
+  {
+    const int lr0 = __float_as_int(qa[0].z), lf0 = __float_as_int(qa[0].w);
+    const int lr1 = __float_as_int(qa[1].z), lf1 = __float_as_int(qa[1].w);
+    float t0, t1, t2, t3;
+#define SYG_SCAN_STEP(N, SHR, SHL)                                                                             \
+    "v_cvt_f32_ubyte" #N " %[t0], %[lr0]\n\tv_cvt_f32_ubyte" #N " %[t1], %[lf0]\n\t"                         \
+    "v_cvt_f32_ubyte" #N " %[t2], %[lr1]\n\tv_cvt_f32_ubyte" #N " %[t3], %[lf1]\n\t"                         \
+    "v_fmac_f32_dpp %[r0], %[r0], %[t0] " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                  \
+    "v_fmac_f32_dpp %[f0], %[f0], %[t1] " SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                  \
+    "v_fmac_f32_dpp %[r1], %[r1], %[t2] " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                  \
+    "v_fmac_f32_dpp %[f1], %[f1], %[t3] " SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t"
+                 SYG_SCAN_STEP(0, "row_shr:1", "row_shl:1") SYG_SCAN_STEP(1, "row_shr:2", "row_shl:2")
+                 SYG_SCAN_STEP(2, "row_shr:4", "row_shl:4") SYG_SCAN_STEP(3, "row_shr:8", "row_shl:8")
+                 "s_nop 1"
+                 : [r0] "+v"(R[0]), [f0] "+v"(F[0]), [r1] "+v"(R[1]), [f1] "+v"(F[1]), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                   [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [lr0] "v"(lr0), [lf0] "v"(lf0), [lr1] "v"(lr1), [lf1] "v"(lf1));
+#undef SYG_SCAN_STEP
+  }
+  // the falling total of the next run: one lane up (lane 63 of pass 0: lane 0 of pass 1; of pass 1: none)
+  float n0 = dpp_f<DPP_WAVE_SHL1>(F[0]);
+  const float n1 = dpp_f<DPP_WAVE_SHL1>(F[1]);
+  const float f10 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(F[1])));
+  if (la == 63) n0 = f10;
+  const float v0 = R[0] + n0, v1 = R[1] + n1;
+  const int b0 = __float_as_int(qa[0].y), b1 = __float_as_int(qa[1].y);
+  if (b0 >= 0) { col[b0 * tp] = v0; cmax = fmaxf(cmax, v0); }
+  if (b1 >= 0) { col[b1 * tp] = v1; cmax = fmaxf(cmax, v1); }
+}
+
 template <int WAVES>
-__device__ __noinline__ void clip_dct(int clipmel_addr, MfccArgs mfv, int n_mels_v, int T_v, int b_v, int w_v, int lane) {
+__device__ __noinline__ void clip_dct(int clipmel_addr, int red_addr, int dct_addr, MfccArgs mfv, int n_mels_v, int T_v, int b_v,
+                                      int w_v, int lane) {
   const MfccArgs mf = uni(mfv);
   const int n_mels = uni(n_mels_v), T = uni(T_v), w = uni(w_v);
   const int64_t b = uni(b_v);
   lds_fptr clipmel = (lds_fptr)(uintptr_t)(uint32_t)uni(clipmel_addr);
-  lds_fptr red = clipmel + n_mels * mf.tp;
-  lds_fptr dctl = red + WAVES;
+  lds_fptr red = (lds_fptr)(uintptr_t)(uint32_t)uni(red_addr);          // [WAVES] per-wave maxima of the clip
+  lds_fptr dctl = (lds_fptr)(uintptr_t)(uint32_t)uni(dct_addr);         // [n_mfcc][n_mels] DCT rows, then the lifter
   lds_fptr lifl = dctl + mf.n_mfcc * n_mels;
   // clip maximum: one LDS read per lane (the WAVES per-wave maxima, one per lane of a DPP row) + row reduction
   float m = red[lane & (WAVES - 1)];
@@ -1054,12 +1170,13 @@ __device__ __noinline__ void clip_dct(int clipmel_addr, MfccArgs mfv, int n_mels
 // Per tile: FFT(v) -> rows | barrier A | MFMA -> slab ; fetch the next frame into v | barrier B |
 //           start the DMA of the tile after next ; reduce + store [; statistics | barrier].
 // The DMA therefore runs behind the reduce and the whole next FFT phase, and is drained at barrier A.
-template <int WAVES>
+template <int WAVES, bool SLAB = true>
 struct Lds {
   static constexpr int TILE_T = WAVES;
   static constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
-  static constexpr int SLAB_FLOATS = WAVES * 16 * TILE_T;
-  static constexpr int CPL_FLOATS = 3 * SYG_MAX_BANDS + MTAB_INTS;   // contrast plan + the mel plan's slot / group tables
+  static constexpr int SLAB_FLOATS = SLAB ? WAVES * 16 * TILE_T : 0;    // (MODE 6 projects per wave: no partial tiles)
+  // contrast plan + the mel plan's slot / group tables; MODE 6: the piece table of the segment-sum projection instead
+  static constexpr int CPL_FLOATS = SLAB ? 3 * SYG_MAX_BANDS + MTAB_INTS : SEGTAB_WORDS;
   static constexpr int STAGE_FLOATS = (WAVES - 1) * 512 + NFFT;
   static constexpr int O_SLAB = P_FLOATS;
   static constexpr int O_TW2 = O_SLAB + SLAB_FLOATS;
@@ -1069,7 +1186,7 @@ struct Lds {
   static constexpr int O_STAGE = O_WIN + NFFT;
   static constexpr int TOTAL = O_STAGE + STAGE_FLOATS;
   static_assert(SC_COMPLEX * 2 <= P_STRIDE, "exchange scratch must fit inside a power row");
-  static_assert(O_TW2 % 4 == 0 && O_WIN % 4 == 0 && O_STAGE % 4 == 0, "16-byte aligned LDS sections");
+  static_assert(O_TW2 % 4 == 0 && O_WIN % 4 == 0 && O_STAGE % 4 == 0 && O_CPL % 4 == 0, "16-byte aligned LDS sections");
 };
 
 template <int WAVES, int LOAD, int MODE>
@@ -1079,18 +1196,19 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
     float roll_percent, float bw_p, int smask, float* __restrict__ stats_out, ContrastPlan cplan,
     float* __restrict__ contrast_out, float2* __restrict__ cout, int dma_wide, MfccArgs mf) {
-  typedef Lds<WAVES> LM;
+  constexpr bool TRI = (MODE == 6);       // MODE 3 with the per-wave projection by segment sums (tri_project)
+  typedef Lds<WAVES, !TRI> LM;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr bool COMPLEX_OUT = (MODE == 2);
   // MODE 5 = MODE 1 (statistics / contrast rows) + MODE 3 (clip-resident dB + DCT): config C4's four features from ONE
   // launch -- only samples in, MFCCs + statistics rows + contrast tail means out (the mel matrix never reaches HBM)
   constexpr bool ROWFN = (MODE == 1 || MODE == 5);      // per-frame row functions behind barrier B
-  constexpr bool CLIPM = (MODE == 3 || MODE == 5);      // the clip's mel matrix lives in LDS; epilogue at clip end
+  constexpr bool CLIPM = (MODE == 3 || MODE == 5 || TRI);   // the clip's mel matrix lives in LDS; epilogue at clip end
   // MODE 0 / 3 (mel only): the power rows hold 4 |X|^2 (wave_rfft2048<.., X2>); the factor is taken back -- exactly, a
   // power of two -- where mel values leave the kernel (MODE 0: at the store; MODE 3: the dB conversion works on 4 x mel
   // with 4 x amin and 4 x ref, the optional mel copy is scaled at its store).  MODE 1's statistics need the true powers.
-  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3);
+  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || TRI);
   constexpr float MELSC = X2 ? 0.25f : 1.f;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Pbuf = lds;
@@ -1101,6 +1219,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   float2* winl = reinterpret_cast<float2*>(lds + LM::O_WIN);
   float* stage = lds + LM::O_STAGE;
   float* clipmel = lds + LM::TOTAL;                 // MODE 3: [n_mels][mf.tp], red[WAVES], dct rows, lifter
+  // MODE 6: two mel matrices (the DCT of a clip runs beside the first tile of the next), red[2][WAVES], dct rows, lifter
+  float* tri_red = clipmel + 2 * n_mels * mf.tp;
+  float* tri_dct = tri_red + 2 * WAVES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps frame addressing on the scalar unit
@@ -1132,7 +1253,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
   for (int i = tid; i < NFFT / 2; i += NTHREADS) winl[i] = win2[i];
   if (CLIPM) {
-    float* dctl = clipmel + n_mels * mf.tp + WAVES;
+    float* dctl = TRI ? tri_dct : clipmel + n_mels * mf.tp + WAVES;
     for (int i = tid; i < mf.n_mfcc * n_mels; i += NTHREADS) dctl[i] = mf.dct[i];
     if (mf.lifter != nullptr && tid < mf.n_mfcc) dctl[mf.n_mfcc * n_mels + tid] = mf.lifter[tid];
   }
@@ -1142,16 +1263,21 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // pad words of the skewed rows, the row tails and the slack are read against zero weights: they must
     // hold finite values, so the whole buffer (and the slab behind it) is cleared once
     for (int i = tid; i < LM::P_FLOATS + LM::SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
+    if (TRI) {
+      for (int i = tid; i < SEGTAB_WORDS; i += NTHREADS) cpl[i] = reinterpret_cast<const int*>(wpacked)[i];
+    } else {
 #pragma unroll
-    for (int r = 0; r < SYG_MAX_BANDS; ++r)
-      if (tid == r) { cpl[r] = cplan.lo[r]; cpl[SYG_MAX_BANDS + r] = cplan.hi[r]; cpl[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
-    for (int i = tid; i < MTAB_INTS; i += NTHREADS) mtab[i] = reinterpret_cast<const int*>(wpacked)[plan.table_off + i];
+      for (int r = 0; r < SYG_MAX_BANDS; ++r)
+        if (tid == r) { cpl[r] = cplan.lo[r]; cpl[SYG_MAX_BANDS + r] = cplan.hi[r]; cpl[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
+      for (int i = tid; i < MTAB_INTS; i += NTHREADS) mtab[i] = reinterpret_cast<const int*>(wpacked)[plan.table_off + i];
+    }
   }
   if (LOAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   float cmax = 0.f;       // MODE 3: running maximum of the clip's mel powers produced by this thread
   int64_t pend_b = -1;    // MODE 3: clip whose dB matrix waits for its DCT
+  int cur = 0;            // MODE 6: which of the two mel matrices the current clip fills
   // staged mode: the frame of the NEXT tile is fetched (LDS -> registers) one phase ahead, so that the stage
   // buffer can be refilled behind the FFT phase; direct modes load at the top of the tile loop
   float2 v[16];
@@ -1262,6 +1388,40 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     }
     SETPRIO(0);
     if (COMPLEX_OUT) continue;
+    if (TRI) {
+      // ---- MODE 6: this wave projects its own row (no barrier A, no slab, no combine); the two barriers below only
+      // hand the stage buffer over: every DMA part of the next tile has landed | X1 | fetch the next frame | X2 | refill
+      SETPRIO(3);
+      int la = lane;
+      asm volatile("" : "+v"(la)::"memory");
+      wave_lds_sync();
+      float* cmc = clipmel + cur * (n_mels * mf.tp);
+      tri_project(prow, reinterpret_cast<const float4*>(cpl), la, cmc + (int)t, mf.tp, cmax);
+      const bool clip_done = (t0 + TILE_T >= T);
+      if (clip_done) {
+        const float cm = wave_max(cmax);
+        cmax = 0.f;
+        if (lane == 0) tri_red[cur * WAVES + w] = cm;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                  // X1: the clip's columns of this tile are written too
+      if (LOAD == 2) {
+        have = false;
+        if (tile + 1 < tile_end) fetch(tile + 1);
+        __syncthreads();                                // X2: every wave holds its next frame
+      }
+      if (clip_done) {
+        // dB + DCT of the finished clip by the first waves, beside the other waves' next transform (which fills the
+        // OTHER mel matrix); its entry waits for outstanding memory operations, so the refill is issued behind it
+        if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_TRIX != 1)
+          clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmc, (int)(uintptr_t)(lds_fptr)(tri_red + cur * WAVES),
+                          (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)b, w, lane);
+        cur ^= 1;
+      }
+      if (LOAD == 2 && tile + 2 < tile_end) dma(tile + 2);
+      SETPRIO(0);
+      continue;
+    }
 #if SYG_ABL == 10 || SYG_ABL == 11
     // ablation (WRONG results): free-running waves -- no projection, no slab, no reduce, no workgroup barrier; the
     // stage hand-over is unsynchronised.  Lower bound for a design whose waves never meet (10), or meet once per
@@ -1299,7 +1459,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       {
         const int wd = (w + WAVES - SYG_DCTSHIFT) % WAVES;       // output tile wd is formed by wave (wd + SYG_DCTSHIFT) mod WAVES
         if (wd < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6 && SYG_ABL != 7)
-          clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, wd, lane);
+          clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp),
+                          (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp + WAVES), mf, n_mels, (int)T, (int)pend_b, wd, lane);
       }
       pend_b = -1;
       TICK(10, tdep);
@@ -1467,7 +1628,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   if (CLIPM && pend_b >= 0) {
     __syncthreads();
     if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6)
-      clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, mf, n_mels, (int)T, (int)pend_b, w, lane);
+      clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp),
+                      (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp + WAVES), mf, n_mels, (int)T, (int)pend_b, w, lane);
   }
 #if SYG_ABL == 9
   if (MODE == 3 && lane < 12)
@@ -1477,9 +1639,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
 }
 
-template <int WAVES>
+template <int WAVES, bool SLAB = true>
 constexpr size_t lds_bytes() {
-  return (size_t)Lds<WAVES>::TOTAL * sizeof(float);
+  return (size_t)Lds<WAVES, SLAB>::TOTAL * sizeof(float);
 }
 
 // Workgroups per CU: two of 8 waves or one of 16; each takes a contiguous chunk of tiles.
@@ -1538,16 +1700,16 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   const int64_t total_tiles = B * tiles;
   int wgs = 0, per = 0;
   persistent_grid(total_tiles, WAVES, wgs, per);
-  size_t lds = lds_bytes<WAVES>();
-  if (MODE == 3 || MODE == 5) {
+  size_t lds = lds_bytes<WAVES, MODE != 6>();
+  if (MODE == 3 || MODE == 5 || MODE == 6) {
     // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
     int cw = 0, cper = 0;
     persistent_grid(B, WAVES, cw, cper);
     per = cper * tiles;
     wgs = cw;
     mf.tp = tiles * WAVES;
-    if (X2_MEL && MODE == 3) { mf.amin *= 4.f; mf.ref_value *= 4.f; }     // the clip's mel matrix holds 4 x mel (exact scaling)
-    lds += ((size_t)n_mels * mf.tp + WAVES + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
+    if (X2_MEL && (MODE == 3 || MODE == 6)) { mf.amin *= 4.f; mf.ref_value *= 4.f; }     // the clip's mel matrix holds 4 x mel (exact scaling)
+    lds += ((size_t)(MODE == 6 ? 2 : 1) * ((size_t)n_mels * mf.tp + WAVES) + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
     SYG_REQUIRE(lds <= LDS_LIMIT, "stft2048_mfcc: the clip's mel matrix (%d x %d) does not fit the LDS left over (%zu B > %zu B); "
                 "use syg_stft2048_mel_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
   }
@@ -1562,7 +1724,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   {
     // set at every launch: the attribute belongs to the (function, device) pair, and a per-process "already set"
     // flag would leave a second device without it
-    const size_t cap = (MODE == 3 || MODE == 5) ? LDS_LIMIT : lds_bytes<WAVES>();
+    const size_t cap = (MODE == 3 || MODE == 5 || MODE == 6) ? LDS_LIMIT : lds_bytes<WAVES>();
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
@@ -1684,6 +1846,45 @@ extern "C" int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64
   mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
   mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = n_mfcc;
   return launch<16, 3>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out, 0.f,
+                       0.f, 0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
+}
+
+// MODE 6: syg_stft2048_mfcc_f32 for TRIANGULAR filterbanks, the mel projection by segment sums inside each wave
+// (tri_project; no weight matrix, no workgroup barrier in the projection).  segtab: the piece table of
+// sygnals_amd._tables.pack_mel_segments ([2][2][64][4] words on the device, n_segtab = 1024).  Same results as
+// the matrix form to rounding (both sum in float32; the affine pieces reproduce the float32 weights to 1e-7 of the
+// largest -- checked on the host when the table is built).
+extern "C" int syg_stft2048_mfcc_tri_fits(int n_mels, int64_t T, int n_mfcc) {
+  if (n_mels < 1 || n_mels > 127 || T < 1 || n_mfcc < 1 || n_mfcc > n_mels) return 0;
+  const int64_t tp = ((T + MAXW - 1) / MAXW) * MAXW;
+  const int64_t bytes = (int64_t)lds_bytes<16, false>() + (2 * ((int64_t)n_mels * tp + 16) + (int64_t)n_mfcc * (n_mels + 1)) * 4;
+  return bytes <= (int64_t)LDS_LIMIT ? 1 : 0;
+}
+
+extern "C" int syg_stft2048_mfcc_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
+                                         int64_t T, const float* window, const float* twiddle, const float* segtab,
+                                         int n_segtab, int n_mels, const float* dct, int n_mfcc, const float* lifter,
+                                         float amin, float top_db, int ref_is_max, float ref_value, float* mfcc_out,
+                                         void* stream) {
+  SYG_REQUIRE(segtab && dct && mfcc_out, "stft2048_mfcc_tri: null pointer argument");
+  SYG_REQUIRE(n_segtab == SEGTAB_WORDS, "stft2048_mfcc_tri: the piece table has %d words, this library reads %d "
+              "(sygnals_amd._tables.pack_mel_segments)", n_segtab, SEGTAB_WORDS);
+  SYG_REQUIRE(((uintptr_t)segtab) % 16 == 0, "stft2048_mfcc_tri: the piece table must be 16-byte aligned");
+  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
+  if (rc) return rc;
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= 127 && n_mfcc >= 1 && n_mfcc <= n_mels,
+              "stft2048_mfcc_tri: need 1 <= n_mfcc <= n_mels <= 127 (n_mfcc=%d n_mels=%d)", n_mfcc, n_mels);
+  SYG_REQUIRE(amin >= 1.17549435e-38f, "stft2048_mfcc_tri: amin must be strictly positive (a normal float)");
+  SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft2048_mfcc_tri: ref_is_max must be 0 or 1");
+  SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_mfcc_tri: clip too long");
+  ContrastPlan cp;
+  memset(&cp, 0, sizeof(cp));
+  MelPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  MfccArgs mf;
+  mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
+  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = n_mfcc;
+  return launch<16, 6>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, nullptr, 0.f,
                        0.f, 0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
 }
 

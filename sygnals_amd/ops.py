@@ -115,6 +115,14 @@ class MelConfig:
                 self.wpacked = _dev(wp)
                 self.plan = np.ascontiguousarray(plan, dtype=np.int32)
         self.basis = _dev(basis)
+        # piece table of the per-wave projection by segment sums (MODE 6 of the fused kernel): triangular filterbanks
+        # whose pieces fit 128 lane slots (n_mels = 40 at any usual rate; 64 and more do not)
+        self.segtab = None
+        if n_fft == 2048:
+            try:
+                self.segtab = _dev(T.pack_mel_segments(sr, n_fft, n_mels, fmin, fmax, basis=basis).reshape(-1))
+            except ValueError:
+                pass
 
 
 def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None, waves=None) -> MelConfig:
@@ -305,7 +313,7 @@ class _MfccCall:
     22 ctypes arguments per call costs the host about as much)."""
 
     def __init__(self, B, L, ld, device, sr, hop, center, window, n_mels, n_mfcc, fmin, fmax, lifter, amin, top_db,
-                 ref, dct_type, norm, keep_mel):
+                 ref, dct_type, norm, keep_mel, projection="auto"):
         if amin <= 0:
             raise ValueError("amin must be strictly positive")
         if top_db is not None and top_db < 0:
@@ -328,18 +336,39 @@ class _MfccCall:
         self.device = device
         self.mel_shape = (B, n_mels, Tn) if keep_mel else None
         self.out_shape = (B, K, Tn)
-        self.fn = lib().syg_stft2048_mfcc_f32
-        self.head = (B, L, ld, hop, int(center), Tn, _ptr(self.win), _ptr(self.tw), _ptr(self.cfg.wpacked),
-                     self.cfg.plan.ctypes.data_as(C.c_void_p), n_mels, _ptr(self.dct), K, _ptr(self.lif), float(amin),
-                     float(top_db) if top_db is not None else -1.0, ref_is_max, ref_value)
+        tail = (n_mels, _ptr(self.dct), K, _ptr(self.lif), float(amin), float(top_db) if top_db is not None else -1.0,
+                ref_is_max, ref_value)
+        # projection: "segments" = each wave projects its own power row by segment sums (no weight matrix, no workgroup
+        # barrier in the projection: 133 against 149 us at config C2), "matrix" = block-sparse weights on the matrix
+        # cores; "auto" takes the segment form when the filterbank has a piece table, the staged loads apply (hop <= 512),
+        # no copy of the mel matrix is asked for and the two mel matrices fit the LDS
+        if projection not in ("auto", "matrix", "segments"):
+            raise ValueError("projection must be 'auto', 'matrix' or 'segments'")
+        tri_ok = (self.cfg.segtab is not None and not keep_mel and hop <= 512
+                  and bool(lib().syg_stft2048_mfcc_tri_fits(int(n_mels), int(Tn), K)))
+        if projection == "segments" and not tri_ok:
+            raise SygnalsHipError("stft2048_mfcc: no segment-sum projection for this call (filterbank without a piece table, "
+                                  "keep_mel, hop > 512, or the clip's two mel matrices do not fit the LDS)")
+        self.tri = tri_ok and projection != "matrix"
+        if self.tri:
+            self.fn, self.name = lib().syg_stft2048_mfcc_tri_f32, "syg_stft2048_mfcc_tri_f32"
+            self.head = (B, L, ld, hop, int(center), Tn, _ptr(self.win), _ptr(self.tw), _ptr(self.cfg.segtab),
+                         int(self.cfg.segtab.numel())) + tail
+        else:
+            self.fn, self.name = lib().syg_stft2048_mfcc_f32, "syg_stft2048_mfcc_f32"
+            self.head = (B, L, ld, hop, int(center), Tn, _ptr(self.win), _ptr(self.tw), _ptr(self.cfg.wpacked),
+                         self.cfg.plan.ctypes.data_as(C.c_void_p)) + tail
 
     def __call__(self, y):
         mel = torch.empty(self.mel_shape, dtype=torch.float32, device=self.device) if self.mel_shape else None
         mf = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
-        rc = self.fn(y.data_ptr(), *self.head, mel.data_ptr() if mel is not None else None, mf.data_ptr(),
-                     _stream_ptr())
+        if self.tri:
+            rc = self.fn(y.data_ptr(), *self.head, mf.data_ptr(), _stream_ptr())
+        else:
+            rc = self.fn(y.data_ptr(), *self.head, mel.data_ptr() if mel is not None else None, mf.data_ptr(),
+                         _stream_ptr())
         if rc:
-            check(rc, "syg_stft2048_mfcc_f32")
+            check(rc, self.name)
         return mf, mel
 
 
@@ -348,8 +377,10 @@ _mfcc_calls: dict = {}
 
 def stft2048_mfcc(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann", n_mels: int = 128,
                   n_mfcc: int = 13, fmin: float = 0.0, fmax=None, lifter: float = 0.0, amin: float = 1e-10,
-                  top_db: Optional[float] = 80.0, ref="max", dct_type: int = 2, norm="ortho", keep_mel: bool = False):
+                  top_db: Optional[float] = 80.0, ref="max", dct_type: int = 2, norm="ortho", keep_mel: bool = False,
+                  projection: str = "auto"):
     """One launch: [B, L] clips -> MFCC [B, n_mfcc, T]; the mel matrix of a clip never leaves LDS.
+    projection: "auto" | "segments" | "matrix" -- how a power row becomes mel bands (see _MfccCall).
 
     Returns (mfcc, mel_power | None).  Raises SygnalsHipError when the clip's mel matrix does not fit
     (mfcc_fused_fits) -- mfcc_batch() falls back to the two-launch form by itself.
@@ -362,12 +393,12 @@ def stft2048_mfcc(y: torch.Tensor, sr: float, hop: int = 512, center: bool = Tru
     wkey = window if isinstance(window, str) else _window_key(window, 2048, 2048)
     rkey = "max" if (ref is np.max or ref == "max") else float(ref)
     key = (y.device.index, y.shape[0], y.shape[1], _ld(y), float(sr), hop, bool(center), wkey, n_mels, n_mfcc,
-           float(fmin), fmax, float(lifter), amin, top_db, rkey, dct_type, norm, keep_mel)
+           float(fmin), fmax, float(lifter), amin, top_db, rkey, dct_type, norm, keep_mel, projection)
     call = _mfcc_calls.get(key)
     if call is None:
         require_gpu()
         call = _MfccCall(y.shape[0], y.shape[1], _ld(y), y.device, sr, hop, center, window, n_mels, n_mfcc, fmin,
-                         fmax, lifter, amin, top_db, ref, dct_type, norm, keep_mel)
+                         fmax, lifter, amin, top_db, ref, dct_type, norm, keep_mel, projection)
         if len(_mfcc_calls) > 64:
             _mfcc_calls.clear()
         _mfcc_calls[key] = call

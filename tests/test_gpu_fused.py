@@ -270,6 +270,42 @@ def test_mfcc_one_launch_ragged_and_degenerate(ops):
     assert_parity(mf1.cpu().numpy(), two1.cpu().numpy(), TOL, "fixed reference, no clamp")
 
 
+@pytest.mark.parametrize("sr,hop,n_mels,n_mfcc,L,B", [(48000, 512, 40, 13, 48000, 8), (16000, 160, 40, 13, 5000, 300),
+                                                       (22050, 512, 40, 20, 22050, 37), (48000, 256, 32, 13, 9000, 50),
+                                                       (48000, 512, 40, 13, 3000, 19), (8000, 128, 26, 13, 4001, 21)])
+def test_mfcc_segment_projection_matches_matrix_form_and_oracle(ops, sr, hop, n_mels, n_mfcc, L, B):
+    """syg_stft2048_mfcc_tri_f32 (each wave projects its own row by segment sums, MODE 6) against the matrix form and
+    the oracle: whole tiles and ragged ones, one-tile clips (the DCT of a clip runs beside the next clip's only tile),
+    more clips than workgroups, an all-zero clip, lengths that rule out the 16-byte staged loads."""
+    Y = O.synth_clips(B, L, sr, seed=5)
+    Y[B // 2] = 0.0
+    y = ops.to_device_f32(Y)
+    seg, _ = ops.stft2048_mfcc(y, sr, hop=hop, n_mels=n_mels, n_mfcc=n_mfcc, projection="segments")
+    mat, _ = ops.stft2048_mfcc(y, sr, hop=hop, n_mels=n_mels, n_mfcc=n_mfcc, projection="matrix")
+    assert seg.shape == mat.shape
+    assert_parity(seg.cpu().numpy(), mat.cpu().numpy(), TOL, "segment sums vs matrix form")
+    idx = sorted(set([0, 1, B // 2, B - 1]))
+    ref = np.stack([O.mfcc_manager(Y[i].astype(np.float64), sr, 2048, hop, True, "hann", n_mels, n_mfcc) for i in idx])
+    assert_parity(seg[idx].cpu().numpy(), ref, TOL, "segment sums vs oracle")
+    again, _ = ops.stft2048_mfcc(y, sr, hop=hop, n_mels=n_mels, n_mfcc=n_mfcc, projection="segments")
+    assert torch.equal(seg, again), "fixed summation order: repeated launches give the same bits"
+
+
+def test_mfcc_segment_projection_variants(ops, clips):
+    """Fixed reference / no clamp / lifter / other windows through the segment form; shapes without a piece table or
+    with keep_mel fall back to the matrix form ("auto") or are refused ("segments")."""
+    y = ops.to_device_f32(clips)
+    a, _ = ops.stft2048_mfcc(y, 48000, n_mels=40, ref=1.0, top_db=None, lifter=22.0, window="hamming", projection="segments")
+    b, _ = ops.stft2048_mfcc(y, 48000, n_mels=40, ref=1.0, top_db=None, lifter=22.0, window="hamming", projection="matrix")
+    assert_parity(a.cpu().numpy(), b.cpu().numpy(), TOL, "fixed reference, lifter, hamming")
+    with pytest.raises(Exception, match="no segment-sum projection"):
+        ops.stft2048_mfcc(y, 48000, n_mels=128, projection="segments")
+    with pytest.raises(Exception, match="no segment-sum projection"):
+        ops.stft2048_mfcc(y, 48000, n_mels=40, keep_mel=True, projection="segments")
+    mf, mel = ops.stft2048_mfcc(y, 48000, n_mels=40, keep_mel=True)          # auto: the matrix form stores the copy
+    assert mel is not None and mf.shape == (8, 13, 94)
+
+
 def test_mfcc_one_launch_rejects_oversized_clip(ops):
     y = ops.to_device_f32(np.zeros((2, 160000), np.float32))
     assert not ops.mfcc_fused_fits(128, 313)

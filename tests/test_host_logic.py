@@ -270,3 +270,47 @@ def test_wave_fft_index_model_is_exact_and_conflict_free():
         row = (cl & 7) + 8 * h
         assert all(m.conf(8 * m.x1(row, 4 * (8 * hi + i) + bp), 8, G32, 256) == 1 for i in range(8))
     assert all(m.conf(8 * m.x2(cl, cp, bp), 8, G16, 128) == 1 for cp in range(16))
+
+
+# ---------------------------------------------------------------- segment-sum projection (stft_mel.hip MODE 6): host side
+@pytest.mark.parametrize("sr,n_mels,fmin,fmax", [(48000, 40, 0.0, None), (22050, 40, 0.0, None), (16000, 40, 0.0, None),
+                                                 (44100, 40, 0.0, None), (48000, 40, 300.0, 8000.0), (8000, 26, 50.0, None),
+                                                 (48000, 24, 0.0, None)])
+def test_mel_segment_table_reproduces_the_filterbank(sr, n_mels, fmin, fmax):
+    """pack_mel_segments: the affine pieces stand for exactly the float32 filterbank the oracle multiplies by, the float32
+    model of the kernel's sums (segments_project) agrees with the float64 product, and the windows of the 32 lanes of an
+    LDS access start in 32 different banks."""
+    from sygnals_amd import _tables as T
+    W = T.mel_filterbank(sr, 2048, n_mels, fmin, fmax)
+    tab = T.pack_mel_segments(sr, 2048, n_mels, fmin, fmax, basis=W)
+    assert tab.shape == (2, 2, 64, 4) and tab.dtype == np.float32
+    Wr = T.segments_weights(tab, n_mels, 1025)
+    assert np.abs(Wr - W).max() <= 2e-7 * W.max()
+    rng = np.random.default_rng(sr + n_mels)
+    for P in (rng.random(1025) ** 8 * 100.0, np.ones(1025), np.eye(1025)[640] + 1e-6):
+        ref = W.astype(np.float64) @ P
+        got = T.segments_project(tab, P.astype(np.float32), n_mels)
+        assert np.abs(got - ref).max() <= 1e-6 * ref.max()
+        nz = ref > 1e-9 * ref.max()
+        assert (np.abs(got - ref)[nz] / ref[nz]).max() <= 2e-6
+    assert T.segments_read_cycles(tab) == 68
+    ti = tab.view(np.int32)
+    w0 = ti[:, 0, :, 0]
+    hi, lead = (w0 >> 16) & 0xFF, (w0 >> 24) & 7
+    live = hi > 0
+    assert (lead[live] <= T.SEG_LEAD_MAX).all() and (hi[live] <= 17).all() and (hi[live] >= T.SEG_LEAD_MAX).all()
+    assert (lead[~live] == 7).all()
+    bands = ti[:, 0, :, 1].ravel()
+    assert sorted(bands[bands >= 0].tolist()) == list(range(n_mels))      # every band is stored by exactly one lane
+
+
+def test_mel_segment_table_refuses_what_it_cannot_hold():
+    from sygnals_amd import _tables as T
+    with pytest.raises(ValueError, match="lane slots"):
+        T.pack_mel_segments(48000, 2048, 128)
+    with pytest.raises(ValueError, match="more than 16 blocks"):
+        T.pack_mel_segments(48000, 2048, 4)
+    W = T.mel_filterbank(48000, 2048, 40)
+    W2 = W.copy(); W2[7, 200] += 1e-4                      # not triangular any more
+    with pytest.raises(ValueError, match="not reproduced"):
+        T.pack_mel_segments(48000, 2048, 40, basis=W2)
