@@ -1035,6 +1035,8 @@ static_assert(TRI_LEAD_MAX == 4, "tri_piece_sums unrolls four entry steps");
 
 // segl: the piece table in LDS, [2 passes][2][64 lanes] 16-byte words (layout: pack_mel_segments); col: the frame's
 // column of the clip's mel matrix
+// (measured and dropped: the window words of the table kept in registers across the transform, 148.4 against 144.4 us
+// on one box; both windows read before the first sums: no difference)
 __device__ __forceinline__ void tri_project(const float* __restrict__ prow, const float4* __restrict__ segl, int la,
                                             float* __restrict__ col, int tp, float& cmax) {
   float4 qa[2], qc[2];
@@ -1043,14 +1045,7 @@ __device__ __forceinline__ void tri_project(const float* __restrict__ prow, cons
     qa[p] = segl[(p * 2 + 0) * 64 + la];
     qc[p] = segl[(p * 2 + 1) * 64 + la];
   }
-#if SYG_TRIX == 2     // timing experiment (WRONG results): no table reads
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    qa[p] = make_float4(__int_as_float((((la * 17 + p * 531) & 1023) * 4) | ((9 + (la & 7)) << 16) | ((la & 3) << 24)), __int_as_float(la < 20 ? la + 20 * p : -1),
-                        __int_as_float(la & 0x0101), __int_as_float((la >> 1) & 0x0101));
-    qc[p] = make_float4(0.3f, 0.1f, 0.2f, 0.4f);
-  }
-#endif
+
   float R[2], F[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -1094,15 +1089,15 @@ __device__ __forceinline__ void tri_project(const float* __restrict__ prow, cons
   if (la == 63) n0 = f10;
   const float v0 = R[0] + n0, v1 = R[1] + n1;
   const int b0 = __float_as_int(qa[0].y), b1 = __float_as_int(qa[1].y);
-  if (b0 >= 0) { col[b0 * tp] = v0; cmax = fmaxf(cmax, v0); }
-  if (b1 >= 0) { col[b1 * tp] = v1; cmax = fmaxf(cmax, v1); }
+  if (b0 >= 0) { col[__mul24(b0, tp)] = v0; cmax = fmaxf(cmax, v0); }
+  if (b1 >= 0) { col[__mul24(b1, tp)] = v1; cmax = fmaxf(cmax, v1); }
 }
 
 template <int WAVES>
 __device__ __noinline__ void clip_dct(int clipmel_addr, int red_addr, int dct_addr, MfccArgs mfv, int n_mels_v, int T_v, int b_v,
-                                      int w_v, int lane) {
+                                      int w_v, int lane, int stride_v = WAVES) {
   const MfccArgs mf = uni(mfv);
-  const int n_mels = uni(n_mels_v), T = uni(T_v), w = uni(w_v);
+  const int n_mels = uni(n_mels_v), T = uni(T_v), w = uni(w_v), stride = uni(stride_v);   // output tiles w, w + stride, ...
   const int64_t b = uni(b_v);
   lds_fptr clipmel = (lds_fptr)(uintptr_t)(uint32_t)uni(clipmel_addr);
   lds_fptr red = (lds_fptr)(uintptr_t)(uint32_t)uni(red_addr);          // [WAVES] per-wave maxima of the clip
@@ -1123,7 +1118,7 @@ __device__ __noinline__ void clip_dct(int clipmel_addr, int red_addr, int dct_ad
   // out[k, t] = sum_m dct[k, m] * dB[m, t]
   const int ktiles = (mf.n_mfcc + 15) >> 4, ttiles = mf.tp >> 4;
   const int f = lane & 15, g = lane >> 4;
-  for (int ot = w; ot < ktiles * ttiles; ot += WAVES) {
+  for (int ot = w; ot < ktiles * ttiles; ot += stride) {
     const int kt = ot / ttiles, tq = ot - kt * ttiles;
     const int krow = kt * 16 + f, tcol = tq * 16 + f;
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -1253,6 +1248,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   for (int i = tid; i < 15 * 64; i += NTHREADS) tw1l[i] = twid[2 * (i & 63) * ((i >> 6) + 1)];
   for (int i = tid; i < NFFT / 2; i += NTHREADS) winl[i] = win2[i];
   if (CLIPM) {
+    if (TRI)
+      for (int i = tid; i < 2 * n_mels * mf.tp; i += NTHREADS) clipmel[i] = 0.f;
     float* dctl = TRI ? tri_dct : clipmel + n_mels * mf.tp + WAVES;
     for (int i = tid; i < mf.n_mfcc * n_mels; i += NTHREADS) dctl[i] = mf.dct[i];
     if (mf.lifter != nullptr && tid < mf.n_mfcc) dctl[mf.n_mfcc * n_mels + tid] = mf.lifter[tid];
@@ -1278,6 +1275,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   float cmax = 0.f;       // MODE 3: running maximum of the clip's mel powers produced by this thread
   int64_t pend_b = -1;    // MODE 3: clip whose dB matrix waits for its DCT
   int cur = 0;            // MODE 6: which of the two mel matrices the current clip fills
+  // MODE 6: output tiles of the clip epilogue; waves without a frame in a clip's last tile; whether those waves take the
+  // epilogue of the clip before (at most three output tiles each: it must stay shorter than a transform)
+  const int tri_ndct = ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4);
+  const int tri_idle = TRI ? mf.tp - (int)T : 0;
+  const bool tri_defer = TRI && tri_idle > 0 && (tri_ndct + tri_idle - 1) / tri_idle <= 3;
   // staged mode: the frame of the NEXT tile is fetched (LDS -> registers) one phase ahead, so that the stage
   // buffer can be refilled behind the FFT phase; direct modes load at the top of the tile loop
   float2 v[16];
@@ -1381,7 +1383,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           }
         if (lane == 0) prow[ppos(512)] = fmaf(x512.x, x512.x, x512.y * x512.y);
       }
-    } else if (!COMPLEX_OUT) {
+    } else if (!COMPLEX_OUT && !TRI) {
       for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
 #pragma unroll
       for (int q = 0; q < NEARLY; ++q) apre[q] = wp4w[q * 64 + lane];
@@ -1390,14 +1392,28 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     if (COMPLEX_OUT) continue;
     if (TRI) {
       // ---- MODE 6: this wave projects its own row (no barrier A, no slab, no combine); the two barriers below only
-      // hand the stage buffer over: every DMA part of the next tile has landed | X1 | fetch the next frame | X2 | refill
-      SETPRIO(3);
-      int la = lane;
-      asm volatile("" : "+v"(la)::"memory");
-      wave_lds_sync();
-      float* cmc = clipmel + cur * (n_mels * mf.tp);
-      tri_project(prow, reinterpret_cast<const float4*>(cpl), la, cmc + (int)t, mf.tp, cmax);
+      // hand the stage buffer over: every DMA part of the next tile has landed | X1 | fetch the next frame | X2 | refill.
+      // dB + DCT of a finished clip: when the clip's last tile leaves waves without a frame (tp - T of them), THEY form
+      // the output tiles of the clip BEFORE while the others transform -- the epilogue then costs nothing; otherwise the
+      // first waves form them right behind the clip's last tile, beside the other waves' next transform (which fills
+      // the OTHER mel matrix).  Whatever is pending when the workgroup runs out of tiles is formed behind the loop.
+#ifndef SYG_TRIPRIO
+#define SYG_TRIPRIO 3
+#endif
+      SETPRIO(SYG_TRIPRIO);
+      const bool mine = (t < T);
       const bool clip_done = (t0 + TILE_T >= T);
+      float* cmc = clipmel + cur * (n_mels * mf.tp);
+      if (mine) {
+        int la = lane;
+        asm volatile("" : "+v"(la)::"memory");
+        wave_lds_sync();
+        tri_project(prow, reinterpret_cast<const float4*>(cpl), la, cmc + (int)t, mf.tp, cmax);
+      } else if (tri_defer && pend_b >= 0 && SYG_TRIX != 1) {
+        float* cmp = clipmel + (cur ^ 1) * (n_mels * mf.tp);
+        clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmp, (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES),
+                        (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)pend_b, w - (WAVES - tri_idle), lane, tri_idle);
+      }
       if (clip_done) {
         const float cm = wave_max(cmax);
         cmax = 0.f;
@@ -1411,9 +1427,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         __syncthreads();                                // X2: every wave holds its next frame
       }
       if (clip_done) {
-        // dB + DCT of the finished clip by the first waves, beside the other waves' next transform (which fills the
-        // OTHER mel matrix); its entry waits for outstanding memory operations, so the refill is issued behind it
-        if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_TRIX != 1)
+        // (clip_dct's entry waits for outstanding memory operations, so the refill is issued behind it)
+        if (tri_defer) pend_b = b;
+        else if (w < tri_ndct && SYG_TRIX != 1)
           clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmc, (int)(uintptr_t)(lds_fptr)(tri_red + cur * WAVES),
                           (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)b, w, lane);
         cur ^= 1;
@@ -1625,7 +1641,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
     }
   }
-  if (CLIPM && pend_b >= 0) {
+  if (TRI) {
+    // (deferred epilogue: the last clip's matrix is complete behind X1 of its last tile)
+    if (pend_b >= 0 && w < tri_ndct && SYG_TRIX != 1)
+      clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)(clipmel + (cur ^ 1) * (n_mels * mf.tp)),
+                      (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES), (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels,
+                      (int)T, (int)pend_b, w, lane);
+  } else if (CLIPM && pend_b >= 0) {
     __syncthreads();
     if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6)
       clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp),
