@@ -115,15 +115,16 @@ def launch_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-def mfma_flops_per_launch(ops, B):
+def mfma_flops_per_launch(ops, B, segments):
     """fp32 MFMA flops one launch of the one-launch MFCC kernel issues (zero-weight steps included -- they are issued):
-    the block-sparse filterbank (v_mfma_f32_4x4x1_16b_f32: 16 blocks x 4 x 4 x 1 x 2 = 512 flop per instruction, `steps`
-    instructions per wave and 16-frame tile) + the per-clip dB/DCT epilogue (v_mfma_f32_16x16x4_f32: 2048 flop)."""
+    the per-clip dB/DCT epilogue (v_mfma_f32_16x16x4_f32: 2048 flop) and, in the matrix form of the projection only, the
+    block-sparse filterbank (v_mfma_f32_4x4x1_16b_f32: 16 blocks x 4 x 4 x 1 x 2 = 512 flop per instruction, `steps`
+    instructions per wave and 16-frame tile).  The segment-sum projection (MODE 6) runs on the vector pipe."""
     cfg = ops.mel_config(SR, N_FFT, N_MELS, waves=16)
     waves, steps = int(cfg.plan[1]), int(cfg.plan[2])
     tiles = (T_FRAMES + 15) // 16
     dct_steps = ((N_MFCC + 15) // 16) * tiles * (4 * ((N_MELS + 15) // 16))
-    return B * (tiles * waves * steps * 512 + dct_steps * 2048)
+    return B * ((0 if segments else tiles * waves * steps * 512) + dct_steps * 2048)
 
 
 def main():
@@ -263,7 +264,10 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = max(10, min(a.steps, 100))
         if a.config == "c2" and one_launch:
-            kname = "stft2048_kernel<16,2,3> (16 waves, staged tiles, clip-resident MFCC; the whole step)"
+            segments = ops.mel_config(SR, N_FFT, N_MELS, waves=16).segtab is not None
+            kname = ("stft2048_kernel<16,2,6> (16 waves, staged tiles, per-wave mel projection by segment sums, clip-resident "
+                     "MFCC; the whole step)" if segments else
+                     "stft2048_kernel<16,2,3> (16 waves, staged tiles, clip-resident MFCC; the whole step)")
             kfn = lambda: ops.stft2048_mfcc(y, SR, HOP, True, "hann", N_MELS, N_MFCC)
             kbytes = B * algo_bytes_per_clip(N_MFCC)
         elif a.config == "c2":
@@ -293,13 +297,15 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kname,
                 "kernel_avg_us": round(kdur * 1e6, 2), "algorithmic_bytes_per_launch": kbytes}
         if a.config == "c2" and one_launch:
-            fl = mfma_flops_per_launch(ops, B)
+            fl = mfma_flops_per_launch(ops, B, segments)
             roof["mfma_util"] = {"flops_per_launch": fl, "achieved_tflops": round(fl / kdur / 1e12, 2),
-                                 "peak_tflops": MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_4x4x1_16b_f32 filterbank, v_mfma_f32_16x16x4_f32 DCT)",
+                                 "peak_tflops": MFMA_F32_PEAK_TFLOPS,
+                                 "dtype": "f32 (v_mfma_f32_16x16x4_f32 DCT" + (")" if segments else ", v_mfma_f32_4x4x1_16b_f32 filterbank)"),
                                  "frac": round(fl / kdur / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                 "note": "mel filterbank (block-sparse, four-row groups) + dB/DCT epilogue; the FFT runs on the vector pipe, and "
-                                         "fp32 MFMA shares the SIMD's fp32 lanes with it (tools/ubench/mfma_valu_coexec.hip), so a low "
-                                         "figure here is the goal, not a shortfall"}
+                                 "note": ("dB/DCT epilogue only: FFT and mel projection (segment sums) run on the vector pipe; " if segments else
+                                          "mel filterbank (block-sparse, four-row groups) + dB/DCT epilogue; the FFT runs on the vector pipe, and ")
+                                         + "fp32 MFMA shares the SIMD's fp32 lanes with the vector pipe (tools/ubench/mfma_valu_coexec.hip), "
+                                         "so a low figure here is the goal, not a shortfall"}
 
     if rank == 0:
         samples = n_total * L * a.steps

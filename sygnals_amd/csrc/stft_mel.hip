@@ -1005,6 +1005,7 @@ typedef __attribute__((address_space(3))) float* lds_fptr;     // (a generic poi
 //   * the lane at a run's end stores the band to the clip's mel matrix column and keeps the clip maximum.
 // Every sum has a fixed order: results do not depend on scheduling.
 constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108, DPP_WAVE_SHL1 = 0x130;
+constexpr int DPP_WAVE_ROL1 = 0x134;
 // a lane's window: 17 consecutive row words, the piece occupies words [lead, hi) of it; the first TRI_LEAD_MAX steps
 // enter by `lead <= i` from the full mask (the host keeps hi > i there), the rest leave by `i < hi`
 constexpr int TRI_LEAD_MAX = 4;      // == sygnals_amd._tables.SEG_LEAD_MAX
@@ -1082,15 +1083,18 @@ __device__ __forceinline__ void tri_project(const float* __restrict__ prow, cons
                  : [lr0] "v"(lr0), [lf0] "v"(lf0), [lr1] "v"(lr1), [lf1] "v"(lf1));
 #undef SYG_SCAN_STEP
   }
-  // the falling total of the next run: one lane up (lane 63 of pass 0: lane 0 of pass 1; of pass 1: none)
-  float n0 = dpp_f<DPP_WAVE_SHL1>(F[0]);
-  const float n1 = dpp_f<DPP_WAVE_SHL1>(F[1]);
-  const float f10 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(F[1])));
-  if (la == 63) n0 = f10;
-  const float v0 = R[0] + n0, v1 = R[1] + n1;
+  // the falling total of the next run: one lane up.  Pass 1 rotated left by one lane puts its lane 0 into lane 63, where
+  // the shift of pass 0 finds nothing and keeps it (`old` operand, bound_ctrl off): lane 63 of pass 0 continues in lane 0
+  // of pass 1.  (Lane 63 of pass 1 then sees lane 0 of pass 1: it never stores a band -- the last run is the segment
+  // above the last band.)
+  const int n1i = __builtin_amdgcn_update_dpp(0, __float_as_int(F[1]), DPP_WAVE_ROL1, 0xF, 0xF, false);
+  const int n0i = __builtin_amdgcn_update_dpp(n1i, __float_as_int(F[0]), DPP_WAVE_SHL1, 0xF, 0xF, false);
+  const float v0 = R[0] + __int_as_float(n0i), v1 = R[1] + __int_as_float(n1i);
+  // the table's band word was turned into the band's BYTE offset inside a mel matrix when the workgroup copied it
   const int b0 = __float_as_int(qa[0].y), b1 = __float_as_int(qa[1].y);
-  if (b0 >= 0) { col[__mul24(b0, tp)] = v0; cmax = fmaxf(cmax, v0); }
-  if (b1 >= 0) { col[__mul24(b1, tp)] = v1; cmax = fmaxf(cmax, v1); }
+  char* colb = reinterpret_cast<char*>(col);
+  if (b0 >= 0) { *reinterpret_cast<float*>(colb + b0) = v0; asm("v_max_f32_e32 %0, %0, %1" : "+v"(cmax) : "v"(v0)); }
+  if (b1 >= 0) { *reinterpret_cast<float*>(colb + b1) = v1; asm("v_max_f32_e32 %0, %0, %1" : "+v"(cmax) : "v"(v1)); }
 }
 
 template <int WAVES>
@@ -1261,7 +1265,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // hold finite values, so the whole buffer (and the slab behind it) is cleared once
     for (int i = tid; i < LM::P_FLOATS + LM::SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
     if (TRI) {
-      for (int i = tid; i < SEGTAB_WORDS; i += NTHREADS) cpl[i] = reinterpret_cast<const int*>(wpacked)[i];
+      for (int i = tid; i < SEGTAB_WORDS; i += NTHREADS) {
+        // (word 1 of a lane's first 16 bytes: the band it stores -> that band's byte offset inside a mel matrix)
+        int v = reinterpret_cast<const int*>(wpacked)[i];
+        if ((i & 3) == 1 && ((i >> 8) & 1) == 0 && v >= 0) v *= mf.tp * 4;
+        cpl[i] = v;
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < SYG_MAX_BANDS; ++r)
