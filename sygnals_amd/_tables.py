@@ -166,6 +166,7 @@ def pack_mel_plan(basis: np.ndarray, waves: int = WAVES):
 
 SEG_SLOTS = 128         # lane slots of the segment-sum projection: 2 passes x 64 lanes
 SEG_LEAD_MAX = 4        # window words that may lie before the piece (the kernel's first SEG_LEAD_MAX steps test `lead <= i`)
+SEG_WINDOW = 17         # row words a lane reads per pass
 
 
 def _distinct_banks(options):
@@ -251,20 +252,50 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     n_rows = SEG_SLOTS // 16
     total = sum(len(r) for r in runs)
 
-    def fill(caps):
-        slots, nxt = [], 0
+    lens = [len(r) for r in runs]
+
+    def rows_needed(first):
+        """Rows a greedy packing of runs[first:] takes (a run never straddles a row)."""
+        rows, used = 0, 16
+        for n in lens[first:]:
+            if used + n > 16:
+                rows, used = rows + 1, 0
+            used += n
+        return rows
+
+    def fill(rng):
+        """Rows of 16 lanes, a random feasible number of runs per row (rng None: as many as fit).  Idle lanes go to the
+        row's end (they join the last run: its rising total must reach lane 15) or to the row's start (they join the first
+        run, whose falling total must reach lane 0); with every piece within 7 lanes of where its run's total is read
+        the scans need three steps instead of four (`short`).  Returns (slots, short)."""
+        slots, nxt, short = [], 0, max(lens) <= 8
         for row in range(n_rows):
-            used = 0
-            while nxt < len(runs) and used + len(runs[nxt]) <= 16 and (used == 0 or used + len(runs[nxt]) <= caps[row]):
-                slots += [(pc, nxt) for pc in runs[nxt]]
-                used += len(runs[nxt]); nxt += 1
-            slots += [(idle, nxt - 1 if used else -2 - row)] * (16 - used)
-        return slots if nxt == len(runs) else None
+            first, used, takes = nxt, 0, []
+            while nxt < len(runs) and used + lens[nxt] <= 16:
+                used += lens[nxt]; nxt += 1
+                if rows_needed(nxt) <= n_rows - row - 1:
+                    takes.append((nxt, used))
+            if first == len(runs):
+                slots += [(idle, -2 - row)] * 16
+                continue
+            nxt, used = takes[-1] if rng is None else takes[int(rng.integers(len(takes)))]
+            spare = 16 - used
+            lo = max(0, spare - (8 - lens[first]))                   # idle lanes the row's start cannot take
+            hi = min(spare, 8 - lens[nxt - 1]) if nxt - 1 > first else min(spare, 8 - lens[first])
+            if lo <= hi:
+                at_end = hi if rng is None else int(rng.integers(lo, hi + 1))
+            else:
+                at_end, short = spare, False
+            slots += [(idle, first)] * (spare - at_end)
+            for r in range(first, nxt):
+                slots += [(pc, r) for pc in runs[r]]
+            slots += [(idle, nxt - 1)] * at_end
+        return slots, short
 
     def leads_of(n, q):
         """Leads a piece of n bins at row position q may take: the window holds 17 words, its first SEG_LEAD_MAX words are
         entered by `lead <= i` alone, so the piece must not end before them."""
-        return [ld for ld in range(max(0, SEG_LEAD_MAX - n), min(SEG_LEAD_MAX, 17 - n) + 1) if q - ld >= 0]
+        return [ld for ld in range(max(0, SEG_LEAD_MAX - n), min(SEG_LEAD_MAX, SEG_WINDOW - n) + 1) if q - ld >= 0]
 
     def windows(slots):
         """Leads per group of 32 lanes (one LDS access) so that the windows start in distinct banks where a matching
@@ -284,26 +315,23 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
                 if j not in lanes:
                     start[j] = start[lanes[0]] if lanes else 0
             st = np.unique([start[j] for j in range(32 * g, 32 * g + 32)])
-            cycles += 17 * int(np.bincount(st % 32, minlength=32).max())
+            cycles += SEG_WINDOW * int(np.bincount(st % 32, minlength=32).max())
         return start, lead, cycles
 
     if total > SEG_SLOTS:
         raise ValueError(f"filterbank needs {total} lane slots, the projection has {SEG_SLOTS}")
+    if rows_needed(0) > n_rows:
+        raise ValueError(f"filterbank needs more than the {SEG_SLOTS} lane slots of the projection")
     best = None
     rng = np.random.default_rng(12345)
-    base = -(-total // n_rows)
-    trials = [[c] * n_rows for c in range(base, 17)] + [list(rng.integers(max(base - 3, 1), 17, n_rows)) for _ in range(300)]
-    for caps in trials:
-        slots = fill(caps)
-        if slots is None:
-            continue
+    for trial in range(1500):
+        slots, short = fill(None if trial == 0 else rng)
         start, lead, cycles = windows(slots)
-        if best is None or cycles < best[0]:
-            best = (cycles, slots, start, lead)
-        if cycles == 17 * (SEG_SLOTS // 32):
+        cost = cycles + (0 if short else 4)          # (a fourth scan step costs about as much as two LDS cycles)
+        if best is None or cost < best[0]:
+            best = (cost, slots, start, lead)
+        if cost == SEG_WINDOW * (SEG_SLOTS // 32):
             break
-    if best is None:
-        raise ValueError(f"filterbank needs more than the {SEG_SLOTS} lane slots of the projection")
     _, slots, start, lead = best
     run_of = np.array([r for _, r in slots])
     tab = np.zeros((2, 2, 64, 4), np.float32)
@@ -315,11 +343,14 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
         ti[p, 0, l, 0] = (4 * start[j]) | (((lead[j] + n) if n else 0) << 16) | ((lead[j] if n else 7) << 24)
         last = (j + 1 == SEG_SLOTS) or run_of[j + 1] != r
         ti[p, 0, l, 1] = r if (last and 0 <= r <= n_mels - 1) else -1
+        live = [jj for jj in range(16 * (j // 16), 16 * (j // 16) + 16) if run_of[jj] == r and slots[jj][0][1] > slots[jj][0][0]]
         tab[p, 1, l] = (aR, bR, aF, bF)
         for i, dd in enumerate((1, 2, 4, 8)):
-            if j - dd >= 0 and (j - dd) // 16 == j // 16 and run_of[j - dd] == r:
+            # a link is only set where something non-zero can arrive through it (then a layout whose pieces all lie within
+            # 7 lanes of their totals has no step-8 link, and the kernel skips that step)
+            if j - dd >= 0 and (j - dd) // 16 == j // 16 and run_of[j - dd] == r and live and min(live) <= j - dd:
                 ti[p, 0, l, 2] |= 1 << (8 * i)
-            if j + dd < SEG_SLOTS and (j + dd) // 16 == j // 16 and run_of[j + dd] == r:
+            if j + dd < SEG_SLOTS and (j + dd) // 16 == j // 16 and run_of[j + dd] == r and live and max(live) >= j + dd:
                 ti[p, 0, l, 3] |= 1 << (8 * i)
     if basis is not None:
         Wr = segments_weights(tab, n_mels, F)
@@ -356,26 +387,27 @@ def _seg_slot(tab: np.ndarray, j: int):
 
 
 def segments_weights(tab: np.ndarray, n_mels: int, F: int) -> np.ndarray:
-    """The [n_mels, F] weight matrix a piece table stands for (float64; host check of pack_mel_segments)."""
-    W = np.zeros((n_mels, F))
+    """The [n_mels, F] weight matrix a piece table stands for (float64; host check of pack_mel_segments): the kernel's
+    data flow -- piece sums, the two segmented scans, the neighbour add -- applied to the rows of the identity."""
     slots = [_seg_slot(tab, j) for j in range(SEG_SLOTS)]
+    R = np.zeros((SEG_SLOTS, F)); Fv = np.zeros((SEG_SLOTS, F))
     for j, (k0, n, _, lr, lf, aR, bR, aF, bF) in enumerate(slots):
-        if n == 0:
-            continue
-        top = j                                   # last lane of the run: stores the run's (rising) band
-        while slots[top][4][0]:
-            top += 1
-        first = j                                 # the lane below the run's first lane stores the falling band
-        while slots[first][3][0]:
-            first -= 1
-        rise = slots[top][2]
-        fall = slots[first - 1][2] if first >= 1 else -1
-        for i in range(n):
-            ip = n - 1 - i
-            if rise >= 0:
-                W[rise, k0 + i] += float(aR) + float(bR) * ip
-            if fall >= 0:
-                W[fall, k0 + i] += float(aF) + float(bF) * ip
+        ip = np.arange(n - 1, -1, -1.0)
+        R[j, k0:k0 + n] = float(aR) + float(bR) * ip
+        Fv[j, k0:k0 + n] = float(aF) + float(bF) * ip
+    for i, dd in enumerate((1, 2, 4, 8)):
+        Rn, Fn = R.copy(), Fv.copy()
+        for j in range(SEG_SLOTS):
+            if slots[j][3][i]:
+                Rn[j] += R[j - dd]
+            if slots[j][4][i]:
+                Fn[j] += Fv[j + dd]
+        R, Fv = Rn, Fn
+    W = np.zeros((n_mels, F))
+    for j in range(SEG_SLOTS):
+        b = slots[j][2]
+        if b >= 0:
+            W[b] = R[j] + (Fv[j + 1] if j + 1 < SEG_SLOTS else 0.0)
     return W
 
 

@@ -1038,8 +1038,10 @@ static_assert(TRI_LEAD_MAX == 4, "tri_piece_sums unrolls four entry steps");
 // column of the clip's mel matrix
 // (measured and dropped: the window words of the table kept in registers across the transform, 148.4 against 144.4 us
 // on one box; both windows read before the first sums: no difference)
+// scan8: some lane of the table has a step-8 link (wave-uniform; the host lays the runs out so that three steps suffice
+// where the filterbank allows it)
 __device__ __forceinline__ void tri_project(const float* __restrict__ prow, const float4* __restrict__ segl, int la,
-                                            float* __restrict__ col, int tp, float& cmax) {
+                                            float* __restrict__ col, bool scan8, float& cmax) {
   float4 qa[2], qc[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -1076,11 +1078,17 @@ __device__ __forceinline__ void tri_project(const float* __restrict__ prow, cons
     "v_fmac_f32_dpp %[f1], %[f1], %[t3] " SHL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     asm volatile("s_nop 1\n\t"
                  SYG_SCAN_STEP(0, "row_shr:1", "row_shl:1") SYG_SCAN_STEP(1, "row_shr:2", "row_shl:2")
-                 SYG_SCAN_STEP(2, "row_shr:4", "row_shl:4") SYG_SCAN_STEP(3, "row_shr:8", "row_shl:8")
+                 SYG_SCAN_STEP(2, "row_shr:4", "row_shl:4")
                  "s_nop 1"
                  : [r0] "+v"(R[0]), [f0] "+v"(F[0]), [r1] "+v"(R[1]), [f1] "+v"(F[1]), [t0] "=&v"(t0), [t1] "=&v"(t1),
                    [t2] "=&v"(t2), [t3] "=&v"(t3)
                  : [lr0] "v"(lr0), [lf0] "v"(lf0), [lr1] "v"(lr1), [lf1] "v"(lf1));
+    if (scan8)
+      asm volatile(SYG_SCAN_STEP(3, "row_shr:8", "row_shl:8")
+                   "s_nop 1"
+                   : [r0] "+v"(R[0]), [f0] "+v"(F[0]), [r1] "+v"(R[1]), [f1] "+v"(F[1]), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                     [t2] "=&v"(t2), [t3] "=&v"(t3)
+                   : [lr0] "v"(lr0), [lf0] "v"(lf0), [lr1] "v"(lr1), [lf1] "v"(lf1));
 #undef SYG_SCAN_STEP
   }
   // the falling total of the next run: one lane up.  Pass 1 rotated left by one lane puts its lane 0 into lane 63, where
@@ -1286,6 +1294,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   int cur = 0;            // MODE 6: which of the two mel matrices the current clip fills
   // MODE 6: output tiles of the clip epilogue; waves without a frame in a clip's last tile; whether those waves take the
   // epilogue of the clip before (at most three output tiles each: it must stay shorter than a transform)
+  bool tri_scan8 = false;
+  if (TRI) {
+    const unsigned lk = (unsigned)(cpl[4 * lane + 2] | cpl[4 * lane + 3] | cpl[4 * (128 + lane) + 2] | cpl[4 * (128 + lane) + 3]);
+    tri_scan8 = __builtin_amdgcn_ballot_w64((lk >> 24) != 0) != 0;
+  }
   const int tri_ndct = ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4);
   const int tri_idle = TRI ? mf.tp - (int)T : 0;
   const bool tri_defer = TRI && tri_idle > 0 && (tri_ndct + tri_idle - 1) / tri_idle <= 3;
@@ -1417,7 +1430,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         int la = lane;
         asm volatile("" : "+v"(la)::"memory");
         wave_lds_sync();
-        tri_project(prow, reinterpret_cast<const float4*>(cpl), la, cmc + (int)t, mf.tp, cmax);
+        tri_project(prow, reinterpret_cast<const float4*>(cpl), la, cmc + (int)t, tri_scan8, cmax);
       } else if (tri_defer && pend_b >= 0 && SYG_TRIX != 1) {
         float* cmp = clipmel + (cur ^ 1) * (n_mels * mf.tp);
         clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmp, (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES),

@@ -26,6 +26,7 @@ if what == "cqt":
     stream = (torch.randn(48000 * 3600, device="cuda", generator=g, dtype=torch.float32) * 0.05).reshape(1, -1)
 y2 = ops.to_device_f32(np.tile(Y, (2048 // 64, 1))) if what.startswith("c4blk") else None
 fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
+      "mfcc441": lambda: ops.stft2048_mfcc(y, 44100, 512, True, "hann", 40, 13),       # (a 3-step scan layout of the segment projection)
       "mfccmat": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13, projection="matrix"),
       "mel": lambda: ops.stft2048_mel(y, 48000, n_mels=40),
       "mfcc1024": lambda: ops.stft_mfcc_pow2(y, 48000, 1024, 256, True, "hann", None, 40, 13),
