@@ -149,6 +149,17 @@ int syg_stft2048_mfcc_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy,
                               float amin, float top_db, int ref_is_max, float ref_value, float* mfcc_out,
                               void* stream);
 
+/* syg_stft2048_features_f32 with the segment-sum projection of syg_stft2048_mfcc_tri_f32: BASELINE config C4
+ * (extract_features(["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]), manager.py:289-371) from
+ * one launch, no mel matrix in HBM.  Arguments as syg_stft2048_features_f32 with segtab / n_segtab in place of
+ * wpacked / plan_host and no mel_out; shapes that fit: syg_stft2048_mfcc_tri_fits(). */
+int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                                  const float* window, const float* twiddle, const float* segtab, int n_segtab,
+                                  int n_mels, const float* dct, int n_mfcc, const float* lifter, float amin,
+                                  float top_db, int ref_is_max, float ref_value, float sr, float roll_percent,
+                                  float bw_p, int stats_mask, float* stats_out, const int32_t* cplan_host,
+                                  float* contrast_out, float* mfcc_out, int mfcc_rows_per_clip, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at
  * manager.py:223 and librosa.feature.mfcc(S=..) at cepstral.py:106-115.

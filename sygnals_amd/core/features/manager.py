@@ -298,6 +298,12 @@ def extract_features(y, sr: int, features: List[str], frame_length: int = 2048, 
 
 
 # ------------------------------------------------------------------ config C4: the packed per-clip feature block
+# feature_block's default where the filterbank has a piece table: ONE fused launch with the segment-sum projection
+# (syg_stft2048_features_tri_f32, MODE 7) + the small rows kernel -- 701 against 731 us per 2048 clips for the mel ->
+# feature_block pair on one box
+TRI_FEATURES_DEFAULT = True
+
+
 def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: int = 13, roll_percent: float = 0.85,
                   n_bands: int = 6, fmin_contrast: float = 200.0, quantile: float = 0.02, out=None, one_launch=None):
     """BASELINE config C4 on the device: y [B, L] float32 device clips -> [B, n_mfcc + 2 + (n_bands + 1), T] float32,
@@ -319,26 +325,42 @@ def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: i
     import ctypes as C
     from ..._lib import check, lib
     st = C.c_void_p(ops._stream_ptr())
-    # one_launch=True: everything from ONE fused launch (syg_stft2048_features_f32, the mel matrix never reaches HBM) +
-    # the small rows kernel.  Measured SLOWER than mel -> feature_block at C4's shape (735 vs 724 us per 2048 clips: the
-    # clip epilogue occupies six of the sixteen waves while the others wait at the tile barrier), so it is not the default.
+    # one_launch: everything from ONE fused launch -- samples in; MFCC rows straight into the head of the block,
+    # statistics rows and contrast tail means out (the mel matrix stays in LDS) -- then the small kernel that turns those
+    # into the block's other rows.  With a piece table for the filterbank that launch is syg_stft2048_features_tri_f32
+    # (each wave projects its own row by segment sums; the clip epilogue runs on waves that have no frame), else
+    # syg_stft2048_features_f32 (matrix form: measured SLOWER than the two launches below, 735 vs 724 us per 2048 clips,
+    # because the clip epilogue occupies six of the sixteen waves while the others wait at the tile barrier).
+    # one_launch=None picks the default (TRI_FEATURES_DEFAULT), True insists on one launch (segment form where it applies),
+    # "segments" / "matrix" on that form of it, False on two launches.
+    cfg = ops.mel_config(sr, 2048, n_mels, 0.0, None, waves=16)
+    tri_ok = (cfg.segtab is not None and hop_length <= 512 and ops.fused_waves() == 16
+              and bool(lib().syg_stft2048_mfcc_tri_fits(int(n_mels), int(Tn), int(n_mfcc))))
+    if one_launch not in (None, True, False, "segments", "matrix"):
+        raise ValueError("one_launch must be None, True, False, 'segments' or 'matrix'")
+    if one_launch == "segments" and not tri_ok:
+        raise SygnalsHipError("feature_block: no segment-sum projection for this shape")
+    if one_launch == "matrix":
+        tri_ok = False
     if one_launch is None:
-        one_launch = False
-    if one_launch and not (ops.mfcc_fused_fits(n_mels, Tn, n_mfcc) and ops.fused_waves() == 16):
+        one_launch = tri_ok and TRI_FEATURES_DEFAULT
+    if one_launch and not tri_ok and not (ops.mfcc_fused_fits(n_mels, Tn, n_mfcc) and ops.fused_waves() == 16):
         raise SygnalsHipError("feature_block: the one-launch form needs the clip's mel matrix to fit the LDS (16-wave plan)")
     if one_launch:
-        # ONE fused launch: samples in; MFCC rows straight into the head of the block, statistics rows and contrast tail
-        # means out (the mel matrix stays in LDS) -- then the small kernel that turns those into the block's other rows
-        cfg = ops.mel_config(sr, 2048, n_mels, 0.0, None, waves=16)
         stats = torch.empty((B, 8, Tn), dtype=torch.float32, device=y.device)       # (only the rows read below are written)
         cpv = torch.empty((B, 2, R, Tn), dtype=torch.float32, device=y.device)
-        rc = lib().syg_stft2048_features_f32(ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn,
-                                             ops._ptr(ops.window_dev("hann", 2048, 2048)), ops._ptr(ops.twiddle_dev(2048)),
-                                             ops._ptr(cfg.wpacked), cfg.plan.ctypes.data_as(C.c_void_p), n_mels, ops._ptr(dct),
-                                             n_mfcc, None, 1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), 2.0, 1 | 8,
-                                             ops._ptr(stats), np.ascontiguousarray(cplan, np.int32).ctypes.data_as(C.c_void_p),
-                                             ops._ptr(cpv), None, ops._ptr(out), rows, st)
-        check(rc, "syg_stft2048_features_f32")
+        head = (ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn, ops._ptr(ops.window_dev("hann", 2048, 2048)),
+                ops._ptr(ops.twiddle_dev(2048)))
+        tail = (n_mels, ops._ptr(dct), n_mfcc, None, 1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), 2.0, 1 | 8,
+                ops._ptr(stats), np.ascontiguousarray(cplan, np.int32).ctypes.data_as(C.c_void_p), ops._ptr(cpv))
+        if tri_ok:
+            rc = lib().syg_stft2048_features_tri_f32(*head, ops._ptr(cfg.segtab), int(cfg.segtab.numel()), *tail,
+                                                     ops._ptr(out), rows, st)
+            check(rc, "syg_stft2048_features_tri_f32")
+        else:
+            rc = lib().syg_stft2048_features_f32(*head, ops._ptr(cfg.wpacked), cfg.plan.ctypes.data_as(C.c_void_p), *tail,
+                                                 None, ops._ptr(out), rows, st)
+            check(rc, "syg_stft2048_features_f32")
         rc = lib().syg_feature_block_f32(None, B, n_mels, Tn, None, n_mfcc, 1e-10, 80.0, ops._ptr(stats), float(sr) / 2048.0,
                                          ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out), st)
         check(rc, "syg_feature_block_f32")
@@ -355,6 +377,30 @@ def feature_block_dominant(y, sr, hop_length, n_mels, n_mfcc):
     """(name, callable, feature rows it carries) of the dominant kernel of feature_block (bench.py's roofline leg)."""
     freqs = np.fft.rfftfreq(2048, 1.0 / sr)
     cplan = T.contrast_plan(freqs, sr)
+    B, L = y.shape
+    Tn = ops.num_frames(L, 2048, hop_length, True)
+    cfg = ops.mel_config(sr, 2048, n_mels, 0.0, None, waves=16)
+    from ..._lib import check, lib
+    if (TRI_FEATURES_DEFAULT and cfg.segtab is not None and hop_length <= 512 and ops.fused_waves() == 16
+            and bool(lib().syg_stft2048_mfcc_tri_fits(int(n_mels), int(Tn), int(n_mfcc)))):
+        import ctypes as C
+        R = int(cplan[0])
+        rows = n_mfcc + 2 + R
+        out = torch.empty((B, rows, Tn), dtype=torch.float32, device=y.device)
+        stats = torch.empty((B, 8, Tn), dtype=torch.float32, device=y.device)
+        cpv = torch.empty((B, 2, R, Tn), dtype=torch.float32, device=y.device)
+        dct = ops._cached(("dct", n_mfcc, n_mels, 2, "ortho"), lambda: ops._dev(T.dct_matrix(n_mfcc, n_mels, 2, "ortho")))
+        cph = np.ascontiguousarray(cplan, np.int32)
+        args = (ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn, ops._ptr(ops.window_dev("hann", 2048, 2048)),
+                ops._ptr(ops.twiddle_dev(2048)), ops._ptr(cfg.segtab), int(cfg.segtab.numel()), n_mels, ops._ptr(dct), n_mfcc,
+                None, 1e-10, 80.0, 1, 1.0, float(sr), 0.85, 2.0, 1 | 8, ops._ptr(stats), cph.ctypes.data_as(C.c_void_p),
+                ops._ptr(cpv), ops._ptr(out), rows)
+
+        def run():
+            check(lib().syg_stft2048_features_tri_f32(*args, C.c_void_p(ops._stream_ptr())), "syg_stft2048_features_tri_f32")
+            return out, stats, cpv, cph
+        return ("stft2048_kernel<16,2,7> (16 waves, staged tiles, per-wave mel projection by segment sums, clip-resident MFCC "
+                "+ centroid + rolloff + contrast tail means)", run, n_mfcc + 2 + 2 * R)
     return ("stft2048_kernel<16,2,1> (16 waves, staged tiles, mel + centroid + rolloff + contrast tail means)",
             lambda: ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8, 0.85, 2.0, cplan),
             n_mels + 3 + 2 * int(cplan[0]))

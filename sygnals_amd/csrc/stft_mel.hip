@@ -1183,7 +1183,7 @@ struct Lds {
   static constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
   static constexpr int SLAB_FLOATS = SLAB ? WAVES * 16 * TILE_T : 0;    // (MODE 6 projects per wave: no partial tiles)
   // contrast plan + the mel plan's slot / group tables; MODE 6: the piece table of the segment-sum projection instead
-  static constexpr int CPL_FLOATS = SLAB ? 3 * SYG_MAX_BANDS + MTAB_INTS : SEGTAB_WORDS;
+  static constexpr int CPL_FLOATS = SLAB ? 3 * SYG_MAX_BANDS + MTAB_INTS : SEGTAB_WORDS + 3 * SYG_MAX_BANDS;
   static constexpr int STAGE_FLOATS = (WAVES - 1) * 512 + NFFT;
   static constexpr int O_SLAB = P_FLOATS;
   static constexpr int O_TW2 = O_SLAB + SLAB_FLOATS;
@@ -1203,19 +1203,21 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     const float* __restrict__ wpacked, MelPlan plan, int n_mels, float* __restrict__ mel_out, float binhz,
     float roll_percent, float bw_p, int smask, float* __restrict__ stats_out, ContrastPlan cplan,
     float* __restrict__ contrast_out, float2* __restrict__ cout, int dma_wide, MfccArgs mf) {
-  constexpr bool TRI = (MODE == 6);       // MODE 3 with the per-wave projection by segment sums (tri_project)
+  // MODE 6: MODE 3 with the per-wave projection by segment sums (tri_project); MODE 7: MODE 6 + the per-frame row
+  // functions of MODE 1 (statistics / contrast): config C4's four features from one launch, no mel matrix in HBM
+  constexpr bool TRI = (MODE == 6 || MODE == 7);
   typedef Lds<WAVES, !TRI> LM;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr bool COMPLEX_OUT = (MODE == 2);
   // MODE 5 = MODE 1 (statistics / contrast rows) + MODE 3 (clip-resident dB + DCT): config C4's four features from ONE
   // launch -- only samples in, MFCCs + statistics rows + contrast tail means out (the mel matrix never reaches HBM)
-  constexpr bool ROWFN = (MODE == 1 || MODE == 5);      // per-frame row functions behind barrier B
+  constexpr bool ROWFN = (MODE == 1 || MODE == 5 || MODE == 7);      // per-frame row functions (MODE 1 / 5: behind barrier B)
   constexpr bool CLIPM = (MODE == 3 || MODE == 5 || TRI);   // the clip's mel matrix lives in LDS; epilogue at clip end
   // MODE 0 / 3 (mel only): the power rows hold 4 |X|^2 (wave_rfft2048<.., X2>); the factor is taken back -- exactly, a
   // power of two -- where mel values leave the kernel (MODE 0: at the store; MODE 3: the dB conversion works on 4 x mel
   // with 4 x amin and 4 x ref, the optional mel copy is scaled at its store).  MODE 1's statistics need the true powers.
-  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || TRI);
+  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || MODE == 6);
   constexpr float MELSC = X2 ? 0.25f : 1.f;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Pbuf = lds;
@@ -1223,6 +1225,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   float2* tw2l = reinterpret_cast<float2*>(lds + LM::O_TW2);        // [4][18] complex
   float2* tw1l = reinterpret_cast<float2*>(lds + LM::O_TW1);        // [15][64] complex
   int* cpl = reinterpret_cast<int*>(lds + LM::O_CPL);
+  int* cplc = TRI ? cpl + SEGTAB_WORDS : cpl;        // contrast plan (MODE 6 / 7: behind the piece table)
   float2* winl = reinterpret_cast<float2*>(lds + LM::O_WIN);
   float* stage = lds + LM::O_STAGE;
   float* clipmel = lds + LM::TOTAL;                 // MODE 3: [n_mels][mf.tp], red[WAVES], dct rows, lifter
@@ -1279,12 +1282,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         if ((i & 3) == 1 && ((i >> 8) & 1) == 0 && v >= 0) v *= mf.tp * 4;
         cpl[i] = v;
       }
-    } else {
+    }
+    if (!TRI || ROWFN) {
 #pragma unroll
       for (int r = 0; r < SYG_MAX_BANDS; ++r)
-        if (tid == r) { cpl[r] = cplan.lo[r]; cpl[SYG_MAX_BANDS + r] = cplan.hi[r]; cpl[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
-      for (int i = tid; i < MTAB_INTS; i += NTHREADS) mtab[i] = reinterpret_cast<const int*>(wpacked)[plan.table_off + i];
+        if (tid == r) { cplc[r] = cplan.lo[r]; cplc[SYG_MAX_BANDS + r] = cplan.hi[r]; cplc[2 * SYG_MAX_BANDS + r] = cplan.k[r]; }
     }
+    if (!TRI)
+      for (int i = tid; i < MTAB_INTS; i += NTHREADS) mtab[i] = reinterpret_cast<const int*>(wpacked)[plan.table_off + i];
   }
   if (LOAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1455,6 +1460,24 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmc, (int)(uintptr_t)(lds_fptr)(tri_red + cur * WAVES),
                           (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)b, w, lane);
         cur ^= 1;
+      }
+      if (ROWFN && mine) {
+        // MODE 7: statistics / contrast of this wave's own row, BEHIND the barriers (their duration depends on the data:
+        // a wave that is through starts its next transform, as in MODE 1) with the next frame live in callee-saved
+        // registers.  Out-of-line: their entry waits for every outstanding memory operation, so the stage refill is
+        // issued behind them; statistics first (a wide contrast band parks its lists in the row's low words), the results
+        // wait in lanes and are stored behind the last call.
+        float sres = 0.f;
+        if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
+        if (contrast_out != nullptr) {
+          const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
+          if (lane < cplan.n_rows) {
+            contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = pv.x;
+            contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = pv.y;
+          }
+        }
+        if (stats_out != nullptr && lane < SYG_NSTAT && ((stats_row_mask(smask) >> lane) & 1))
+          stats_out[(b * SYG_NSTAT + lane) * T + t] = sres;
       }
       if (LOAD == 2 && tile + 2 < tile_end) dma(tile + 2);
       SETPRIO(0);
@@ -1638,7 +1661,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
         if (contrast_out != nullptr) {
 #endif
-          const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cpl, cplan.n_rows, cplan.ascending);
+          const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
           pk = pv.x; vl = pv.y;
           if (lane < cplan.n_rows) {
             contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = pk;
@@ -1744,8 +1767,9 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   const int64_t total_tiles = B * tiles;
   int wgs = 0, per = 0;
   persistent_grid(total_tiles, WAVES, wgs, per);
-  size_t lds = lds_bytes<WAVES, MODE != 6>();
-  if (MODE == 3 || MODE == 5 || MODE == 6) {
+  constexpr bool TRI = (MODE == 6 || MODE == 7);
+  size_t lds = lds_bytes<WAVES, !TRI>();
+  if (MODE == 3 || MODE == 5 || TRI) {
     // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
     int cw = 0, cper = 0;
     persistent_grid(B, WAVES, cw, cper);
@@ -1753,7 +1777,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
     wgs = cw;
     mf.tp = tiles * WAVES;
     if (X2_MEL && (MODE == 3 || MODE == 6)) { mf.amin *= 4.f; mf.ref_value *= 4.f; }     // the clip's mel matrix holds 4 x mel (exact scaling)
-    lds += ((size_t)(MODE == 6 ? 2 : 1) * ((size_t)n_mels * mf.tp + WAVES) + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
+    lds += ((size_t)(TRI ? 2 : 1) * ((size_t)n_mels * mf.tp + WAVES) + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
     SYG_REQUIRE(lds <= LDS_LIMIT, "stft2048_mfcc: the clip's mel matrix (%d x %d) does not fit the LDS left over (%zu B > %zu B); "
                 "use syg_stft2048_mel_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
   }
@@ -1768,7 +1792,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   {
     // set at every launch: the attribute belongs to the (function, device) pair, and a per-process "already set"
     // flag would leave a second device without it
-    const size_t cap = (MODE == 3 || MODE == 5 || MODE == 6) ? LDS_LIMIT : lds_bytes<WAVES>();
+    const size_t cap = (MODE == 3 || MODE == 5 || TRI) ? LDS_LIMIT : lds_bytes<WAVES>();
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
@@ -1930,6 +1954,42 @@ extern "C" int syg_stft2048_mfcc_tri_f32(const float* y, int64_t B, int64_t L, i
   mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = n_mfcc;
   return launch<16, 6>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, nullptr, 0.f,
                        0.f, 0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
+}
+
+// MODE 7: syg_stft2048_features_f32 (MODE 5: MFCC rows + statistics rows + contrast tail means from ONE launch) with the
+// segment-sum projection of syg_stft2048_mfcc_tri_f32 -- BASELINE config C4 without a mel matrix in HBM and without
+// the projection's barriers; the clip epilogue runs on the waves that have no frame (see MODE 6).
+extern "C" int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                                             const float* window, const float* twiddle, const float* segtab, int n_segtab,
+                                             int n_mels, const float* dct, int n_mfcc, const float* lifter, float amin,
+                                             float top_db, int ref_is_max, float ref_value, float sr, float roll_percent,
+                                             float bw_p, int stats_mask, float* stats_out, const int32_t* cplan_host,
+                                             float* contrast_out, float* mfcc_out, int mfcc_rows_per_clip, void* stream) {
+  SYG_REQUIRE(segtab && dct && mfcc_out, "stft2048_features_tri: null pointer argument");
+  SYG_REQUIRE(stats_out || contrast_out, "stft2048_features_tri: no statistics requested (use syg_stft2048_mfcc_tri_f32)");
+  SYG_REQUIRE(n_segtab == SEGTAB_WORDS, "stft2048_features_tri: the piece table has %d words, this library reads %d "
+              "(sygnals_amd._tables.pack_mel_segments)", n_segtab, SEGTAB_WORDS);
+  SYG_REQUIRE(((uintptr_t)segtab) % 16 == 0, "stft2048_features_tri: the piece table must be 16-byte aligned");
+  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
+  if (rc) return rc;
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= 127 && n_mfcc >= 1 && n_mfcc <= n_mels && mfcc_rows_per_clip >= n_mfcc,
+              "stft2048_features_tri: need 1 <= n_mfcc <= n_mels <= 127 and mfcc_rows_per_clip >= n_mfcc");
+  SYG_REQUIRE(amin >= 1.17549435e-38f, "stft2048_features_tri: amin must be strictly positive (a normal float)");
+  SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft2048_features_tri: ref_is_max must be 0 or 1");
+  SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_features_tri: clip too long");
+  ContrastPlan cp;
+  rc = parse_contrast_plan(contrast_out, cplan_host, cp);
+  if (rc) return rc;
+  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && stats_mask > 0 &&
+                                 stats_mask < 32, "stft2048_features_tri: invalid statistics parameters");
+  MelPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  MfccArgs mf;
+  mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
+  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = mfcc_rows_per_clip;
+  return launch<16, 7>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, nullptr,
+                       sr / (float)NFFT, roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr,
+                       (hipStream_t)stream, mf);
 }
 
 // MODE 5: the statistics / contrast rows of syg_stft2048_mel_f32 AND the clip-resident MFCC of syg_stft2048_mfcc_f32

@@ -291,6 +291,17 @@ def test_mfcc_segment_projection_matches_matrix_form_and_oracle(ops, sr, hop, n_
     assert torch.equal(seg, again), "fixed summation order: repeated launches give the same bits"
 
 
+@pytest.mark.parametrize("L,hop,center", [(7001, 250, False), (6143, 511, True), (2048, 512, False), (1500, 64, True)])
+def test_mfcc_segment_projection_odd_shapes(ops, L, hop, center):
+    """Hops / lengths that rule out the 16-byte staged loads, center=False, a single frame, a clip shorter than a frame."""
+    Y = O.synth_clips(9, L, 16000, seed=8)
+    y = ops.to_device_f32(Y)
+    seg, _ = ops.stft2048_mfcc(y, 16000, hop=hop, center=center, n_mels=40, projection="segments")
+    ref = np.stack([O.mfcc_manager(c.astype(np.float64), 16000, 2048, hop, center, "hann", 40, 13) for c in Y])
+    assert seg.shape == ref.shape
+    assert_parity(seg.cpu().numpy(), ref, TOL, f"segment sums L={L} hop={hop} center={center}")
+
+
 def test_mfcc_segment_projection_variants(ops, clips):
     """Fixed reference / no clamp / lifter / other windows through the segment form; shapes without a piece table or
     with keep_mel fall back to the matrix form ("auto") or are refused ("segments")."""
@@ -341,9 +352,11 @@ def test_reserved_cus_change_shares_not_results(monkeypatch):
         assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=False), ref2), r
 
 
-def test_c4_features_one_launch_matches_two_launch_and_oracle():
-    """MODE 5 (syg_stft2048_features_f32): MFCC + centroid + rolloff + contrast from ONE fused launch -- the block it
-    builds (with the small rows kernel behind it) equals the mel -> feature_block form and the oracle's columns."""
+@pytest.mark.parametrize("form", ["segments", "matrix"])
+def test_c4_features_one_launch_matches_two_launch_and_oracle(form):
+    """MODE 7 / MODE 5 (syg_stft2048_features_tri_f32 / syg_stft2048_features_f32): MFCC + centroid + rolloff + contrast
+    from ONE fused launch -- the block it builds (with the small rows kernel behind it) equals the mel -> feature_block
+    form and the oracle's columns."""
     from sygnals_amd import ops
     from sygnals_amd.core.features.manager import feature_block
     sr = 48000
@@ -351,7 +364,7 @@ def test_c4_features_one_launch_matches_two_launch_and_oracle():
     Y[5] *= 1e-3
     Y[7][:] = 0.0
     y = ops.to_device_f32(Y)
-    one = feature_block(y, sr, one_launch=True).cpu().numpy()
+    one = feature_block(y, sr, one_launch=form).cpu().numpy()
     two = feature_block(y, sr, one_launch=False).cpu().numpy()
     assert one.shape == two.shape == (20, 22, 94)
     # the statistics / contrast rows come from the same row functions: identical; the MFCC rows differ by the dB form

@@ -32,7 +32,8 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "mfcc1024": lambda: ops.stft_mfcc_pow2(y, 48000, 1024, 256, True, "hann", None, 40, 13),
       "mel1024": lambda: ops.stft_mel_pow2(y, 48000, 1024, 256, True, "hann", None, 40),
       "mfcc512": lambda: ops.stft_mfcc_pow2(y, 48000, 512, 128, True, "hann", None, 40, 13),
-      "c4blk1": lambda: FB(y2, 48000, one_launch=True),
+      "c4blk1": lambda: FB(y2, 48000, one_launch="segments"),
+      "c4blk5": lambda: FB(y2, 48000, one_launch="matrix"),
       "c4blk2": lambda: FB(y2, 48000, one_launch=False),
       "cqt": lambda: ops.cqt(stream, 48000),
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
