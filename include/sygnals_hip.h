@@ -160,6 +160,15 @@ int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t 
                                   float bw_p, int stats_mask, float* stats_out, const int32_t* cplan_host,
                                   float* contrast_out, float* mfcc_out, int mfcc_rows_per_clip, void* stream);
 
+/* frame_length 4096 (librosa.stft + np.abs(.)**2 + melspectrogram, manager.py:184-187, 198, 219-222): samples in, mel power
+ * out, one wave per frame (the 4096-point real transform of syg_welch_f32's wave kernel), the mel projection by segment
+ * sums as in syg_stft2048_mfcc_tri_f32 with a FOUR-pass piece table (pack_mel_segments(..., n_pass=4): 4096 words).
+ *   y [B, L] (row stride ldy), window [4096] device (16-byte aligned), twiddle: W_4096^k for k = 0 .. 4095
+ *   mel_out [B, n_mels, T] */
+int syg_stft_mel_w4096_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                           const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
+                           float* mel_out, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at
  * manager.py:223 and librosa.feature.mfcc(S=..) at cepstral.py:106-115.

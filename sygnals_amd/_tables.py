@@ -190,7 +190,7 @@ def _distinct_banks(options):
     return [got.get(u, options[u][0]) for u in range(len(options))]
 
 
-def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None):
+def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None, n_pass: int = 2):
     """Piece table of the fused kernel's per-wave mel projection by SEGMENT SUMS (stft_mel.hip, MODE 6).
 
     A triangular filterbank is piecewise linear in the bin index: between two neighbouring band edges e[s], e[s+1]
@@ -208,7 +208,8 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     matching exists (the piece starts alone collide: segment starts fall anywhere between the block starts, which are
     17 words apart).
 
-    Returns float32 [2 passes][2][64 lanes][4] (bit patterns for the integers; the kernel keeps the table in LDS and
+    n_pass: passes of 64 lanes (2: the frame-length-2048 kernel, 128 lane slots; 3: the frame-length-4096 kernel).
+    Returns float32 [n_pass][2][64 lanes][4] (bit patterns for the integers; the kernel keeps the table in LDS and
     reads two 16-byte words per lane and pass):
         q0 = (BYTE offset of the window inside a power row | (lead + bins in the piece) << 16 | lead << 24 (idle lane:
               0 bins, lead 7),
@@ -220,6 +221,7 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     matrix the oracle multiplies by) is not reproduced by the affine pieces to 2e-7 of its largest weight.
     """
     F = n_fft // 2 + 1
+    SLOTS = 64 * int(n_pass)
     fmax = sr / 2.0 if fmax is None else fmax
     e = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
     d = np.diff(e)
@@ -249,7 +251,7 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     # runs -> rows of 16 lanes, in order; a run stays inside one row, the idle lanes at a row's end join the run before
     # them (its rising total then waits in the row's last lane).  How many lanes of each row are used is free: a small
     # deterministic search over row fillings keeps the one whose windows collide least.
-    n_rows = SEG_SLOTS // 16
+    n_rows = SLOTS // 16
     total = sum(len(r) for r in runs)
 
     lens = [len(r) for r in runs]
@@ -300,13 +302,15 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     def windows(slots):
         """Leads per group of 32 lanes (one LDS access) so that the windows start in distinct banks where a matching
         exists; returns (window starts, leads, LDS cycles of the 2 x 17 reads)."""
-        start, lead, cycles = [0] * SEG_SLOTS, [0] * SEG_SLOTS, 0
-        for g in range(SEG_SLOTS // 32):
+        start, lead, cycles = [0] * SLOTS, [0] * SLOTS, 0
+        for g in range(SLOTS // 32):
             lanes = [j for j in range(32 * g, 32 * g + 32) if slots[j][0][1] > slots[j][0][0]]
             opts = []
             for j in lanes:
                 k0, k1 = slots[j][0][:2]
                 opts.append([(row_pos(k0) - ld) % 32 for ld in leads_of(k1 - k0, row_pos(k0))])
+                if not opts[-1]:
+                    raise ValueError("a piece at the row's start is shorter than the window's entry steps")
             for j, b in zip(lanes, _distinct_banks(opts)):
                 k0, k1 = slots[j][0][:2]
                 lead[j] = next(ld for ld in leads_of(k1 - k0, row_pos(k0)) if (row_pos(k0) - ld) % 32 == b)
@@ -318,10 +322,10 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
             cycles += SEG_WINDOW * int(np.bincount(st % 32, minlength=32).max())
         return start, lead, cycles
 
-    if total > SEG_SLOTS:
-        raise ValueError(f"filterbank needs {total} lane slots, the projection has {SEG_SLOTS}")
+    if total > SLOTS:
+        raise ValueError(f"filterbank needs {total} lane slots, the projection has {SLOTS}")
     if rows_needed(0) > n_rows:
-        raise ValueError(f"filterbank needs more than the {SEG_SLOTS} lane slots of the projection")
+        raise ValueError(f"filterbank needs more than the {SLOTS} lane slots of the projection")
     best = None
     rng = np.random.default_rng(12345)
     for trial in range(1500):
@@ -330,18 +334,18 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
         cost = cycles + (0 if short else 4)          # (a fourth scan step costs about as much as two LDS cycles)
         if best is None or cost < best[0]:
             best = (cost, slots, start, lead)
-        if cost == SEG_WINDOW * (SEG_SLOTS // 32):
+        if cost == SEG_WINDOW * (SLOTS // 32):
             break
     _, slots, start, lead = best
     run_of = np.array([r for _, r in slots])
-    tab = np.zeros((2, 2, 64, 4), np.float32)
+    tab = np.zeros((int(n_pass), 2, 64, 4), np.float32)
     ti = tab.view(np.int32)
     for j, (pc, r) in enumerate(slots):
         p, l = divmod(j, 64)
         k0, k1, aR, bR, aF, bF = pc
         n = k1 - k0
         ti[p, 0, l, 0] = (4 * start[j]) | (((lead[j] + n) if n else 0) << 16) | ((lead[j] if n else 7) << 24)
-        last = (j + 1 == SEG_SLOTS) or run_of[j + 1] != r
+        last = (j + 1 == SLOTS) or run_of[j + 1] != r
         ti[p, 0, l, 1] = r if (last and 0 <= r <= n_mels - 1) else -1
         live = [jj for jj in range(16 * (j // 16), 16 * (j // 16) + 16) if run_of[jj] == r and slots[jj][0][1] > slots[jj][0][0]]
         tab[p, 1, l] = (aR, bR, aF, bF)
@@ -350,7 +354,7 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
             # 7 lanes of their totals has no step-8 link, and the kernel skips that step)
             if j - dd >= 0 and (j - dd) // 16 == j // 16 and run_of[j - dd] == r and live and min(live) <= j - dd:
                 ti[p, 0, l, 2] |= 1 << (8 * i)
-            if j + dd < SEG_SLOTS and (j + dd) // 16 == j // 16 and run_of[j + dd] == r and live and max(live) >= j + dd:
+            if j + dd < SLOTS and (j + dd) // 16 == j // 16 and run_of[j + dd] == r and live and max(live) >= j + dd:
                 ti[p, 0, l, 3] |= 1 << (8 * i)
     if basis is not None:
         Wr = segments_weights(tab, n_mels, F)
@@ -361,11 +365,11 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
 
 
 def segments_read_cycles(tab: np.ndarray) -> int:
-    """LDS cycles of one wave's 2 x 17 window reads (ds_read_b32: the 32 lanes of a half wave share a cycle unless two of
-    them address different words of one bank); 68 = conflict-free."""
+    """LDS cycles of one wave's n_pass x 17 window reads (ds_read_b32: the 32 lanes of a half wave share a cycle unless
+    two of them address different words of one bank); 34 per pass = conflict-free."""
     ti = tab.view(np.int32)
     total = 0
-    for p in range(2):
+    for p in range(tab.shape[0]):
         for h in range(2):
             st = (ti[p, 0, 32 * h:32 * h + 32, 0] & 0xFFFF) // 4
             for i in range(17):
@@ -389,25 +393,26 @@ def _seg_slot(tab: np.ndarray, j: int):
 def segments_weights(tab: np.ndarray, n_mels: int, F: int) -> np.ndarray:
     """The [n_mels, F] weight matrix a piece table stands for (float64; host check of pack_mel_segments): the kernel's
     data flow -- piece sums, the two segmented scans, the neighbour add -- applied to the rows of the identity."""
-    slots = [_seg_slot(tab, j) for j in range(SEG_SLOTS)]
-    R = np.zeros((SEG_SLOTS, F)); Fv = np.zeros((SEG_SLOTS, F))
+    NS = 64 * tab.shape[0]
+    slots = [_seg_slot(tab, j) for j in range(NS)]
+    R = np.zeros((NS, F)); Fv = np.zeros((NS, F))
     for j, (k0, n, _, lr, lf, aR, bR, aF, bF) in enumerate(slots):
         ip = np.arange(n - 1, -1, -1.0)
         R[j, k0:k0 + n] = float(aR) + float(bR) * ip
         Fv[j, k0:k0 + n] = float(aF) + float(bF) * ip
     for i, dd in enumerate((1, 2, 4, 8)):
         Rn, Fn = R.copy(), Fv.copy()
-        for j in range(SEG_SLOTS):
+        for j in range(NS):
             if slots[j][3][i]:
                 Rn[j] += R[j - dd]
             if slots[j][4][i]:
                 Fn[j] += Fv[j + dd]
         R, Fv = Rn, Fn
     W = np.zeros((n_mels, F))
-    for j in range(SEG_SLOTS):
+    for j in range(NS):
         b = slots[j][2]
         if b >= 0:
-            W[b] = R[j] + (Fv[j + 1] if j + 1 < SEG_SLOTS else 0.0)
+            W[b] = R[j] + (Fv[j + 1] if j + 1 < NS else 0.0)
     return W
 
 
@@ -416,8 +421,9 @@ def segments_project(tab: np.ndarray, P: np.ndarray, n_mels: int) -> np.ndarray:
     (piece sums by running prefix, segmented scans in steps 1, 2, 4, 8) -- host-side model for the CPU tests."""
     f32 = np.float32
     P = np.asarray(P, f32)
-    slots = [_seg_slot(tab, j) for j in range(SEG_SLOTS)]
-    R = np.zeros(SEG_SLOTS, f32); Fv = np.zeros(SEG_SLOTS, f32)
+    NS = 64 * tab.shape[0]
+    slots = [_seg_slot(tab, j) for j in range(NS)]
+    R = np.zeros(NS, f32); Fv = np.zeros(NS, f32)
     for j, (k0, n, _, lr, lf, aR, bR, aF, bF) in enumerate(slots):
         c = f32(0); t1 = f32(0)
         for i in range(n):
@@ -428,17 +434,17 @@ def segments_project(tab: np.ndarray, P: np.ndarray, n_mels: int) -> np.ndarray:
         Fv[j] = f32(f32(bF) * t1 + f32(f32(aF) * c))
     for i, dd in enumerate((1, 2, 4, 8)):
         Rn = R.copy(); Fn = Fv.copy()
-        for j in range(SEG_SLOTS):
+        for j in range(NS):
             if slots[j][3][i]:
                 Rn[j] = f32(R[j] + R[j - dd])
             if slots[j][4][i]:
                 Fn[j] = f32(Fv[j] + Fv[j + dd])
         R, Fv = Rn, Fn
     out = np.zeros(n_mels, f32)
-    for j in range(SEG_SLOTS):
+    for j in range(NS):
         b = slots[j][2]
         if b >= 0:
-            out[b] = f32(R[j] + (Fv[j + 1] if j + 1 < SEG_SLOTS else f32(0)))
+            out[b] = f32(R[j] + (Fv[j + 1] if j + 1 < NS else f32(0)))
     return out
 
 

@@ -211,6 +211,44 @@ def stft_mfcc_pow2(y: torch.Tensor, sr: float, n_fft: int, hop: int, center: boo
     return mf, mel
 
 
+def w4096_segtab(sr, n_mels, fmin=0.0, fmax=None):
+    """Four-pass piece table of the frame-length-4096 kernel for this filterbank on the device, or None."""
+    fmax = sr / 2.0 if fmax is None else fmax
+
+    def build():
+        try:
+            basis = T.mel_filterbank(sr, 4096, n_mels, fmin, fmax)
+            return _dev(T.pack_mel_segments(sr, 4096, n_mels, fmin, fmax, basis=basis, n_pass=4).reshape(-1))
+        except ValueError:
+            return False
+    tab = _cached(("seg4096", float(sr), n_mels, float(fmin), float(fmax)), build)
+    return None if tab is False else tab
+
+
+def stft_mel_w4096(y: torch.Tensor, sr: float, hop: int = 1024, center: bool = True, window="hann", win_length=None,
+                   n_mels: int = 128, fmin: float = 0.0, fmax=None) -> torch.Tensor:
+    """frame_length 4096: [B, L] clips -> mel power [B, n_mels, T] in one launch (one wave per frame, mel by segment
+    sums).  Raises SygnalsHipError when the filterbank has no four-pass piece table."""
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    tab = w4096_segtab(sr, n_mels, fmin, fmax)
+    if tab is None:
+        raise SygnalsHipError("stft_mel_w4096: no piece table for this filterbank (use the generic chain)")
+    B, L = y.shape
+    Tn = num_frames(L, 4096, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    out = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
+    rc = lib().syg_stft_mel_w4096_f32(_ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(window_dev(window, win_length or 4096, 4096)),
+                                      _ptr(twiddle_dev(4096)), _ptr(tab), int(tab.numel()), n_mels, _ptr(out),
+                                      C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_mel_w4096_f32")
+    return out
+
+
 def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
                  win_length: int = 2048, n_mels: int = 128, fmin: float = 0.0, fmax=None,
                  want_stats=False, roll_percent: float = 0.85, bw_p: float = 2.0,
@@ -422,6 +460,9 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
         if fits and fused:
             return stft_mfcc_pow2(y, sr, n_fft, hop, center, window, None, n_mels, n_mfcc, fmin, fmax, lifter)[0]
         return logmel_dct(stft_mel_pow2(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)[1]
+    if n_fft == 4096 and fused is not False and w4096_segtab(sr, n_mels, fmin, fmax) is not None:
+        # frame length 4096: one launch samples -> mel (one wave per frame, mel by segment sums), then dB + DCT
+        return logmel_dct(stft_mel_w4096(y, sr, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)[1]
     if not fused_mel_ok(sr, n_fft, n_mels, fmin, fmax):
         # no fused kernel for this shape: complex STFT (any frame length) -> |X|^2 -> dense mel -> dB + DCT
         if fused:

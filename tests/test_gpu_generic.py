@@ -244,6 +244,32 @@ def test_mel_dense_mfma_shapes(ops, n_fft, n_mels, L):
 
 
 # ---- fused kernel for the other power-of-two frame lengths (stft_mel_pow2.hip): the reference's own tests use 1024 / 256
+@pytest.mark.parametrize("sr,hop,n_mels,L,center", [(48000, 1024, 40, 48000, True), (16000, 1024, 40, 30001, True),
+                                                     (44100, 410, 40, 20000, True), (48000, 2048, 64, 25000, False),
+                                                     (22050, 1024, 128, 22050, True), (48000, 1024, 40, 3000, True)])
+def test_frame_length_4096_fused_mel_and_mfcc(ops, sr, hop, n_mels, L, center):
+    """frame_length 4096 (syg_stft_mel_w4096_f32: one wave per frame, mel by segment sums with a four-pass table) against
+    the float64 oracle: mel power and the MFCCs mfcc_batch builds from it; aligned and unaligned hops, center=False,
+    clips shorter than a frame, more bands."""
+    Y = O.synth_clips(7, L, sr, seed=hop + n_mels)
+    Y[2] *= 1e-3
+    Y[5][:] = 0.0
+    y = ops.to_device_f32(Y)
+    assert ops.w4096_segtab(sr, n_mels) is not None
+    mel = ops.stft_mel_w4096(y, sr, hop, center, "hann", None, n_mels).cpu().numpy()
+    for b in range(len(Y)):
+        P = np.abs(O.stft(Y[b].astype(np.float64), 4096, hop, 4096, "hann", center)) ** 2
+        want = O.melspectrogram(P, sr, 4096, n_mels)
+        assert mel[b].shape == want.shape
+        assert_parity(mel[b], want, TOL, f"mel n_fft=4096 sr={sr} clip {b}")
+    got = ops.mfcc_batch(y, sr, 4096, hop, n_mels, 13, center).cpu().numpy()
+    want = O.mfcc_batch(Y, sr, 4096, hop, n_mels, 13, center)
+    gen = ops.mfcc_batch(y, sr, 4096, hop, n_mels, 13, center, fused=False).cpu().numpy()       # the generic chain
+    for b in range(len(Y)):
+        assert_parity(got[b], want[b], TOL, f"mfcc n_fft=4096 clip {b}")
+        assert_parity(got[b], gen[b], TOL, f"fused vs generic clip {b}")
+
+
 @pytest.mark.parametrize("n_fft,hop,n_mels,L,center", [
     (1024, 256, 40, 48000, True),      # tests/test_features_manager.py:183-220 shape, 1 s @ 48 kHz
     (1024, 256, 128, 16000, True),     # librosa's default n_mels

@@ -52,6 +52,12 @@ for nf, hp in ((1024, 256), (512, 128), (256, 64)):
            lambda: ops.logmel_dct(ops.stft_mel_pow2(y, SR, nf, hp, True, "hann", None, 40), 13), B * L, B * (4 * L + 4 * 13 * Tf))
     report(f"a1-a5 n_fft={nf} hop={hp} generic chain of round 2 (STFT -> |X|^2 -> dense mel -> dB/DCT, 4 launches)",
            lambda: ops.mfcc_batch(y, SR, nf, hp, n_mels=40, fused=False), B * L, B * (4 * L + 4 * 13 * Tf), n=5, warm=2)
+# frame length 4096 (round 3: one wave per frame, mel by segment sums) against the generic chain
+Tf = 1 + L // 1024
+report("a1-a5 STFT->mel->MFCC n_fft=4096 hop=1024 (fused mel kernel + logmel_dct, 1024 clips)", lambda: ops.mfcc_batch(y, SR, 4096, 1024, n_mels=40),
+       B * L, B * (4 * L + 4 * 13 * Tf))
+report("a1-a5 n_fft=4096 hop=1024 generic chain (STFT -> |X|^2 -> dense mel -> dB/DCT, 4 launches)",
+       lambda: ops.mfcc_batch(y, SR, 4096, 1024, n_mels=40, fused=False), B * L, B * (4 * L + 4 * 13 * Tf), n=5, warm=2)
 # C3: band-pass filtfilt then MFCC
 sos = FL.design_butterworth_sos((300.0, 3400.0), SR, 4, "bandpass")
 report("a13 sosfiltfilt order-4 band-pass (C3 filter alone)", lambda: FL.apply_sos_filter_batch(sos, y), B * L, B * 8 * L)
