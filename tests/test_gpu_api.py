@@ -193,6 +193,14 @@ def test_extract_features_like_reference_manager_tests():
                             frame_length=1024, hop_length=256)
     for k in r2:
         assert_parity(d2[k], r2[k], TOL if k != "time" else 1e-12, f"frame 1024: {k}")
+    # frame 4096: MFCC alone takes the fused samples -> mel kernel, with a statistic beside it the generic chain
+    for feats in (["mfcc"], ["mfcc", "spectral_centroid"]):
+        d4 = extract_features(y, sr, feats, frame_length=4096, hop_length=1024, output_format="dict_of_arrays",
+                              feature_params={"mfcc": {"n_mels": 40}})
+        r4 = O.extract_features(y.astype(np.float32).astype(np.float64), sr, feats, frame_length=4096, hop_length=1024,
+                                feature_params={"mfcc": {"n_mels": 40}})
+        for k in r4:
+            assert_parity(d4[k], r4[k], TOL if k != "time" else 1e-12, f"frame 4096 {feats}: {k}")
     # short signals (reference tests/test_features_manager.py:183-220)
     short = extract_features(y[:512], sr, ["spectral_centroid"], frame_length=1024, hop_length=256, output_format="dict_of_arrays")
     assert short["spectral_centroid"].shape == (3,)
