@@ -169,6 +169,16 @@ int syg_stft_mel_w4096_f32(const float* y, int64_t B, int64_t L, int64_t ldy, in
                            const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
                            float* mel_out, void* stream);
 
+/* frame_length 1024 (the reference's own tests and CLI: tests/test_features_manager.py:183-220, cli/features_cmd.py:35),
+ * power 2: samples in, mel power out, free-running waves -- a wave owns two frames per 1024-point complex transform and
+ * projects its two power rows by segment sums (no weight matrix, no workgroup barrier per tile).  segtab: the two-row
+ * table of sygnals_amd._tables.pack_mel_segments_rows(sr, 1024, n_mels, fmin, fmax) (4096 words, 16-byte aligned).
+ * window [1024], twiddle: W_1024^k for k = 0 .. 1023; mel_out [B, n_mels, T].  Other powers and filterbanks without a
+ * table: syg_stft_mel_pow2_f32. */
+int syg_stft_mel_w1024_seg_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                               const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
+                               float* mel_out, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at
  * manager.py:223 and librosa.feature.mfcc(S=..) at cepstral.py:106-115.

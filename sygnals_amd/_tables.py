@@ -190,7 +190,8 @@ def _distinct_banks(options):
     return [got.get(u, options[u][0]) for u in range(len(options))]
 
 
-def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None, n_pass: int = 2):
+def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None, n_pass: int = 2,
+                      row_base: int = 0):
     """Piece table of the fused kernel's per-wave mel projection by SEGMENT SUMS (stft_mel.hip, MODE 6).
 
     A triangular filterbank is piecewise linear in the bin index: between two neighbouring band edges e[s], e[s+1]
@@ -208,7 +209,9 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     matching exists (the piece starts alone collide: segment starts fall anywhere between the block starts, which are
     17 words apart).
 
-    n_pass: passes of 64 lanes (2: the frame-length-2048 kernel, 128 lane slots; 3: the frame-length-4096 kernel).
+    n_pass: passes of 64 lanes (2: the frame-length-2048 kernel, 128 lane slots; 4: the frame-length-4096 kernel).
+    row_base: words in front of bin 0 inside the kernel's row (0: the frame-length-2048 / 4096 kernels; 4 where the first
+    piece may be shorter than the window's entry steps and needs room for its lead).
     Returns float32 [n_pass][2][64 lanes][4] (bit patterns for the integers; the kernel keeps the table in LDS and
     reads two 16-byte words per lane and pass):
         q0 = (BYTE offset of the window inside a power row | (lead + bins in the piece) << 16 | lead << 24 (idle lane:
@@ -222,6 +225,10 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     """
     F = n_fft // 2 + 1
     SLOTS = 64 * int(n_pass)
+
+    def rp(k):
+        return row_pos(k) + row_base
+
     fmax = sr / 2.0 if fmax is None else fmax
     e = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
     d = np.diff(e)
@@ -308,13 +315,13 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
             opts = []
             for j in lanes:
                 k0, k1 = slots[j][0][:2]
-                opts.append([(row_pos(k0) - ld) % 32 for ld in leads_of(k1 - k0, row_pos(k0))])
+                opts.append([(rp(k0) - ld) % 32 for ld in leads_of(k1 - k0, rp(k0))])
                 if not opts[-1]:
                     raise ValueError("a piece at the row's start is shorter than the window's entry steps")
             for j, b in zip(lanes, _distinct_banks(opts)):
                 k0, k1 = slots[j][0][:2]
-                lead[j] = next(ld for ld in leads_of(k1 - k0, row_pos(k0)) if (row_pos(k0) - ld) % 32 == b)
-                start[j] = row_pos(k0) - lead[j]
+                lead[j] = next(ld for ld in leads_of(k1 - k0, rp(k0)) if (rp(k0) - ld) % 32 == b)
+                start[j] = rp(k0) - lead[j]
             for j in range(32 * g, 32 * g + 32):     # idle lanes re-read a neighbour's window (same address: no conflict)
                 if j not in lanes:
                     start[j] = start[lanes[0]] if lanes else 0
@@ -357,11 +364,34 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
             if j + dd < SLOTS and (j + dd) // 16 == j // 16 and run_of[j + dd] == r and live and max(live) >= j + dd:
                 ti[p, 0, l, 3] |= 1 << (8 * i)
     if basis is not None:
-        Wr = segments_weights(tab, n_mels, F)
+        Wr = segments_weights(tab, n_mels, F, row_base)
         tol = 2e-7 * float(np.max(np.abs(basis)))
         if Wr.shape != basis.shape or float(np.max(np.abs(Wr - basis))) > tol:
             raise ValueError("the filterbank is not reproduced by affine pieces")
     return np.ascontiguousarray(tab)
+
+
+def pack_mel_segments_rows(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None, rows: int = 2,
+                           row_words: int = 568, n_pass: int = 2, row_base: int = 4):
+    """Piece table for a wave that projects `rows` power rows of one frame length in ONE call (the frame-length-1024
+    kernel: two frames per transform): the single-row table of pack_mel_segments(..., n_pass) repeated per row, the window
+    offsets moved by the row's offset (row_words words per row) and the band words tagged with the row (band | row << 8).
+    A row's last lane never stores a band (its last run is the segment above the last band), so nothing leaks from one
+    row's passes into the next's.  Returns float32 [rows * n_pass][2][64][4]."""
+    one = pack_mel_segments(sr, n_fft, n_mels, fmin, fmax, basis=basis, n_pass=n_pass, row_base=row_base)
+    if n_mels > 255 or (rows - 1) * row_words * 4 + 0xFFFF // 8 > 0xFFFF:
+        raise ValueError("too many bands / rows for the packed table words")
+    out = np.concatenate([one.copy() for _ in range(rows)], axis=0)
+    oi = out.view(np.int32)
+    for r in range(rows):
+        blk = oi[r * n_pass:(r + 1) * n_pass]
+        w0 = blk[:, 0, :, 0]
+        blk[:, 0, :, 0] = (w0 & ~0xFFFF) | ((w0 & 0xFFFF) + 4 * r * row_words)
+        bw = blk[:, 0, :, 1]
+        blk[:, 0, :, 1] = np.where(bw >= 0, bw | (r << 8), -1)
+        if int(blk[n_pass - 1, 0, 63, 1]) >= 0:
+            raise ValueError("a row's last lane stores a band")
+    return np.ascontiguousarray(out)
 
 
 def segments_read_cycles(tab: np.ndarray) -> int:
@@ -377,24 +407,24 @@ def segments_read_cycles(tab: np.ndarray) -> int:
     return total
 
 
-def _seg_slot(tab: np.ndarray, j: int):
+def _seg_slot(tab: np.ndarray, j: int, row_base: int = 0):
     """Fields of lane slot j: (first bin, bins, band, rising links [4], falling links [4], aR, bR, aF, bF)."""
     ti = tab.view(np.int32)
     p, l = divmod(j, 64)
     w0 = int(ti[p, 0, l, 0])
     hi = (w0 >> 16) & 0xFF
     ld = ((w0 >> 24) & 7) if hi else 0
-    pos = (w0 & 0xFFFF) // 4 + ld                     # the piece's first bin sits `lead` words into the window
+    pos = (w0 & 0xFFFF) // 4 + ld - row_base          # the piece's first bin sits `lead` words into the window
     lr, lf = int(ti[p, 0, l, 2]), int(ti[p, 0, l, 3])
     return (pos - pos // 17, hi - ld, int(ti[p, 0, l, 1]), [(lr >> (8 * i)) & 1 for i in range(4)],
             [(lf >> (8 * i)) & 1 for i in range(4)], tab[p, 1, l, 0], tab[p, 1, l, 1], tab[p, 1, l, 2], tab[p, 1, l, 3])
 
 
-def segments_weights(tab: np.ndarray, n_mels: int, F: int) -> np.ndarray:
+def segments_weights(tab: np.ndarray, n_mels: int, F: int, row_base: int = 0) -> np.ndarray:
     """The [n_mels, F] weight matrix a piece table stands for (float64; host check of pack_mel_segments): the kernel's
     data flow -- piece sums, the two segmented scans, the neighbour add -- applied to the rows of the identity."""
     NS = 64 * tab.shape[0]
-    slots = [_seg_slot(tab, j) for j in range(NS)]
+    slots = [_seg_slot(tab, j, row_base) for j in range(NS)]
     R = np.zeros((NS, F)); Fv = np.zeros((NS, F))
     for j, (k0, n, _, lr, lf, aR, bR, aF, bF) in enumerate(slots):
         ip = np.arange(n - 1, -1, -1.0)
@@ -416,13 +446,13 @@ def segments_weights(tab: np.ndarray, n_mels: int, F: int) -> np.ndarray:
     return W
 
 
-def segments_project(tab: np.ndarray, P: np.ndarray, n_mels: int) -> np.ndarray:
+def segments_project(tab: np.ndarray, P: np.ndarray, n_mels: int, row_base: int = 0) -> np.ndarray:
     """float32 emulation of the kernel's projection of ONE power row P [F] through a piece table: same sums, same order
     (piece sums by running prefix, segmented scans in steps 1, 2, 4, 8) -- host-side model for the CPU tests."""
     f32 = np.float32
     P = np.asarray(P, f32)
     NS = 64 * tab.shape[0]
-    slots = [_seg_slot(tab, j) for j in range(NS)]
+    slots = [_seg_slot(tab, j, row_base) for j in range(NS)]
     R = np.zeros(NS, f32); Fv = np.zeros(NS, f32)
     for j, (k0, n, _, lr, lf, aR, bR, aF, bF) in enumerate(slots):
         c = f32(0); t1 = f32(0)

@@ -47,6 +47,8 @@ def mel_power_batch(y, sr, n_fft, hop, center, window, n_mels, fmin, fmax, power
         return mel
     if power not in (1.0, 2.0):
         raise SygnalsHipError("mel power must be 1.0 or 2.0 on the device")
+    if n_fft == 1024 and power == 2.0 and ops.w1024_segtab(sr, n_mels, fmin, fmax) is not None:
+        return ops.stft_mel_w1024_seg(y, sr, hop, center, window, win_length, n_mels, fmin, fmax)
     if ops.fused_pow2_ok(n_fft, n_mels):
         return ops.stft_mel_pow2(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax, int(power))
     if n_fft == 4096 and power == 2.0 and ops.w4096_segtab(sr, n_mels, fmin, fmax) is not None:
@@ -149,7 +151,10 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 t_stft = Tn
             elif want_mfcc and not (want_stats or want_contrast) and power in (1.0, 2.0) and ops.fused_pow2_ok(frame_length, n_mels):
                 # only the mel spectrogram is needed: fused kernel of the other power-of-two frame lengths
-                mel = ops.stft_mel_pow2(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
+                if frame_length == 1024 and power == 2.0 and ops.w1024_segtab(sr, n_mels, fmin, fmax) is not None:
+                    mel = ops.stft_mel_w1024_seg(yd, sr, hop_length, center, window, None, n_mels, fmin, fmax)
+                else:
+                    mel = ops.stft_mel_pow2(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
                 t_stft = mel.shape[2]
             elif (want_mfcc and not (want_stats or want_contrast) and power == 2.0 and frame_length == 4096
                   and ops.w4096_segtab(sr, n_mels, fmin, fmax) is not None):

@@ -225,6 +225,44 @@ def w4096_segtab(sr, n_mels, fmin=0.0, fmax=None):
     return None if tab is False else tab
 
 
+def w1024_segtab(sr, n_mels, fmin=0.0, fmax=None):
+    """Two-row piece table of the frame-length-1024 segment-sum kernel for this filterbank on the device, or None."""
+    fmax = sr / 2.0 if fmax is None else fmax
+
+    def build():
+        try:
+            basis = T.mel_filterbank(sr, 1024, n_mels, fmin, fmax)
+            return _dev(T.pack_mel_segments_rows(sr, 1024, n_mels, fmin, fmax, basis=basis).reshape(-1))
+        except ValueError:
+            return False
+    tab = _cached(("seg1024", float(sr), n_mels, float(fmin), float(fmax)), build)
+    return None if tab is False else tab
+
+
+def stft_mel_w1024_seg(y: torch.Tensor, sr: float, hop: int = 256, center: bool = True, window="hann", win_length=None,
+                       n_mels: int = 128, fmin: float = 0.0, fmax=None) -> torch.Tensor:
+    """frame_length 1024, power 2: [B, L] clips -> mel power [B, n_mels, T] in one launch, free-running waves (two frames
+    per wave transform, mel by segment sums).  Raises SygnalsHipError when the filterbank has no piece table."""
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    tab = w1024_segtab(sr, n_mels, fmin, fmax)
+    if tab is None:
+        raise SygnalsHipError("stft_mel_w1024_seg: no piece table for this filterbank (use stft_mel_pow2)")
+    B, L = y.shape
+    Tn = num_frames(L, 1024, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    out = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
+    rc = lib().syg_stft_mel_w1024_seg_f32(_ptr(y), B, L, _ld(y), hop, int(center), Tn,
+                                          _ptr(window_dev(window, win_length or 1024, 1024)), _ptr(twiddle_dev(1024)), _ptr(tab),
+                                          int(tab.numel()), n_mels, _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_mel_w1024_seg_f32")
+    return out
+
+
 def stft_mel_w4096(y: torch.Tensor, sr: float, hop: int = 1024, center: bool = True, window="hann", win_length=None,
                    n_mels: int = 128, fmin: float = 0.0, fmax=None) -> torch.Tensor:
     """frame_length 4096: [B, L] clips -> mel power [B, n_mels, T] in one launch (one wave per frame, mel by segment
@@ -459,7 +497,12 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
             raise SygnalsHipError("mfcc_batch: the clip's mel matrix does not fit the LDS of the one-launch form")
         if fits and fused:
             return stft_mfcc_pow2(y, sr, n_fft, hop, center, window, None, n_mels, n_mfcc, fmin, fmax, lifter)[0]
-        return logmel_dct(stft_mel_pow2(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)[1]
+        if n_fft == 1024 and w1024_segtab(sr, n_mels, fmin, fmax) is not None:
+            # free-running waves, mel by segment sums: 0.162 against 0.235 ms per 1024 clips x 1 s for the mel launch
+            mel = stft_mel_w1024_seg(y, sr, hop, center, window, None, n_mels, fmin, fmax)
+        else:
+            mel = stft_mel_pow2(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax)
+        return logmel_dct(mel, n_mfcc, lifter=lifter)[1]
     if n_fft == 4096 and fused is not False and w4096_segtab(sr, n_mels, fmin, fmax) is not None:
         # frame length 4096: one launch samples -> mel (one wave per frame, mel by segment sums), then dB + DCT
         return logmel_dct(stft_mel_w4096(y, sr, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)[1]

@@ -244,6 +244,30 @@ def test_mel_dense_mfma_shapes(ops, n_fft, n_mels, L):
 
 
 # ---- fused kernel for the other power-of-two frame lengths (stft_mel_pow2.hip): the reference's own tests use 1024 / 256
+@pytest.mark.parametrize("sr,hop,n_mels,L,center", [(48000, 256, 40, 48000, True), (16000, 256, 40, 16000, True),
+                                                     (44100, 333, 64, 9000, True), (48000, 512, 80, 20000, False),
+                                                     (22050, 256, 40, 700, True), (16000, 256, 26, 5000, True)])
+def test_frame_length_1024_segment_sum_kernel(ops, sr, hop, n_mels, L, center):
+    """syg_stft_mel_w1024_seg_f32 (free-running waves, two frames per wave transform, mel by segment sums with a two-row
+    table) against the float64 oracle and the dense-matrix kernel: odd frame counts (a pair with one frame), odd hops,
+    center=False, clips shorter than a frame."""
+    Y = O.synth_clips(9, L, sr, seed=hop + n_mels)
+    Y[2] *= 1e-3
+    Y[5][:] = 0.0
+    y = ops.to_device_f32(Y)
+    assert ops.w1024_segtab(sr, n_mels) is not None
+    mel = ops.stft_mel_w1024_seg(y, sr, hop, center, "hann", None, n_mels).cpu().numpy()
+    dense = ops.stft_mel_pow2(y, sr, 1024, hop, center, "hann", None, n_mels).cpu().numpy()
+    assert mel.shape == dense.shape
+    for b in range(len(Y)):
+        P = np.abs(O.stft(Y[b].astype(np.float64), 1024, hop, 1024, "hann", center)) ** 2
+        want = O.melspectrogram(P, sr, 1024, n_mels)
+        assert_parity(mel[b], want, TOL, f"mel n_fft=1024 sr={sr} clip {b}")
+        assert_parity(mel[b], dense[b], TOL, f"segment sums vs dense matrix, clip {b}")
+    again = ops.stft_mel_w1024_seg(y, sr, hop, center, "hann", None, n_mels).cpu().numpy()
+    assert np.array_equal(mel, again)
+
+
 @pytest.mark.parametrize("sr,hop,n_mels,L,center", [(48000, 1024, 40, 48000, True), (16000, 1024, 40, 30001, True),
                                                      (44100, 410, 40, 20000, True), (48000, 2048, 64, 25000, False),
                                                      (22050, 1024, 128, 22050, True), (48000, 1024, 40, 3000, True)])
