@@ -162,7 +162,7 @@ int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t 
 
 /* frame_length 4096 (librosa.stft + np.abs(.)**2 + melspectrogram, manager.py:184-187, 198, 219-222): samples in, mel power
  * out, one wave per frame (the 4096-point real transform of syg_welch_f32's wave kernel), the mel projection by segment
- * sums as in syg_stft2048_mfcc_tri_f32 with a FOUR-pass piece table (pack_mel_segments(..., n_pass=4): 4096 words).
+ * sums as in syg_stft2048_mfcc_tri_f32 with a FOUR-pass piece table (pack_mel_segments(..., n_pass=4): 2048 words).
  *   y [B, L] (row stride ldy), window [4096] device (16-byte aligned), twiddle: W_4096^k for k = 0 .. 4095
  *   mel_out [B, n_mels, T] */
 int syg_stft_mel_w4096_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
@@ -172,12 +172,19 @@ int syg_stft_mel_w4096_f32(const float* y, int64_t B, int64_t L, int64_t ldy, in
 /* frame_length 1024 (the reference's own tests and CLI: tests/test_features_manager.py:183-220, cli/features_cmd.py:35),
  * power 2: samples in, mel power out, free-running waves -- a wave owns two frames per 1024-point complex transform and
  * projects its two power rows by segment sums (no weight matrix, no workgroup barrier per tile).  segtab: the two-row
- * table of sygnals_amd._tables.pack_mel_segments_rows(sr, 1024, n_mels, fmin, fmax) (4096 words, 16-byte aligned).
+ * table of sygnals_amd._tables.pack_mel_segments_rows(sr, 1024, n_mels, fmin, fmax) (2048 words, 16-byte aligned).
  * window [1024], twiddle: W_1024^k for k = 0 .. 1023; mel_out [B, n_mels, T].  Other powers and filterbanks without a
  * table: syg_stft_mel_pow2_f32. */
 int syg_stft_mel_w1024_seg_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                                const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
                                float* mel_out, void* stream);
+
+/* The same for frame_length 512 and 256 (256: the reference's short-signal tests): a wave owns four / eight frames per
+ * transform and projects its four / eight power rows.  segtab: pack_mel_segments_rows(sr, n_fft, n_mels, fmin, fmax,
+ * rows=4, row_words=296 (512) / 160 (256), n_pass=1) (2048 words); twiddle: W_1024^k for k = 0 .. 1023. */
+int syg_stft_mel_wseg_small_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
+                                int64_t T, const float* window, const float* twiddle, const float* segtab,
+                                int n_segtab, int n_mels, float* mel_out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at

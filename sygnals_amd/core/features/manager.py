@@ -47,12 +47,12 @@ def mel_power_batch(y, sr, n_fft, hop, center, window, n_mels, fmin, fmax, power
         return mel
     if power not in (1.0, 2.0):
         raise SygnalsHipError("mel power must be 1.0 or 2.0 on the device")
-    if n_fft == 1024 and power == 2.0 and ops.w1024_segtab(sr, n_mels, fmin, fmax) is not None:
-        return ops.stft_mel_w1024_seg(y, sr, hop, center, window, win_length, n_mels, fmin, fmax)
+    if power == 2.0:
+        mel = ops.stft_mel_segments(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax)
+        if mel is not None:
+            return mel
     if ops.fused_pow2_ok(n_fft, n_mels):
         return ops.stft_mel_pow2(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax, int(power))
-    if n_fft == 4096 and power == 2.0 and ops.w4096_segtab(sr, n_mels, fmin, fmax) is not None:
-        return ops.stft_mel_w4096(y, sr, hop, center, window, win_length, n_mels, fmin, fmax)
     X = ops.stft_any(y, n_fft, hop, center, window, win_length)
     P = ops.cabs_pow(X, int(power))
     cfg = ops.mel_config(sr, n_fft, n_mels, fmin, fmax)
@@ -149,16 +149,13 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
                                                    fmin, fmax, want_stats, roll, bw_p, cplan)
                 t_stft = Tn
-            elif want_mfcc and not (want_stats or want_contrast) and power in (1.0, 2.0) and ops.fused_pow2_ok(frame_length, n_mels):
-                # only the mel spectrogram is needed: fused kernel of the other power-of-two frame lengths
-                if frame_length == 1024 and power == 2.0 and ops.w1024_segtab(sr, n_mels, fmin, fmax) is not None:
-                    mel = ops.stft_mel_w1024_seg(yd, sr, hop_length, center, window, None, n_mels, fmin, fmax)
-                else:
-                    mel = ops.stft_mel_pow2(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
+            elif (want_mfcc and not (want_stats or want_contrast) and power == 2.0 and
+                  (mel := ops.stft_mel_segments(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax)) is not None):
+                # only the mel spectrogram is needed: the segment-sum kernel of this frame length (1024 / 512 / 256 / 4096)
                 t_stft = mel.shape[2]
-            elif (want_mfcc and not (want_stats or want_contrast) and power == 2.0 and frame_length == 4096
-                  and ops.w4096_segtab(sr, n_mels, fmin, fmax) is not None):
-                mel = ops.stft_mel_w4096(yd, sr, hop_length, center, window, None, n_mels, fmin, fmax)
+            elif want_mfcc and not (want_stats or want_contrast) and power in (1.0, 2.0) and ops.fused_pow2_ok(frame_length, n_mels):
+                # ... or the dense-matrix kernel of the other power-of-two frame lengths
+                mel = ops.stft_mel_pow2(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
                 t_stft = mel.shape[2]
             else:
                 X = ops.stft_any(yd, frame_length, hop_length, center, window)

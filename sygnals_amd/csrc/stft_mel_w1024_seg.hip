@@ -123,7 +123,7 @@ __global__ __launch_bounds__(S1_WAVES * 64, SYG_S1_WAVES_PER_SIMD) void stft_mel
 using namespace syg;
 
 // y [B, L] (row stride ldy) -> mel_out [B, n_mels, T], power 2; segtab: the two-row table of
-// sygnals_amd._tables.pack_mel_segments_rows(sr, 1024, n_mels, fmin, fmax, rows=2, row_words=568, row_base=4) (4096 words on the
+// sygnals_amd._tables.pack_mel_segments_rows(sr, 1024, n_mels, fmin, fmax, rows=2, row_words=568, row_base=4) (2048 words on the
 // device, 16-byte aligned); window [1024]; twiddle: W_1024^k, k = 0 .. 1023.
 extern "C" int syg_stft_mel_w1024_seg_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                                           const float* window, const float* twiddle, const float* segtab, int n_segtab,

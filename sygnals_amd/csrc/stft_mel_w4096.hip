@@ -152,7 +152,7 @@ __global__ __launch_bounds__(W4_WAVES * 64) void stft_mel_w4096_kernel(
 using namespace syg;
 
 // y [B, L] (row stride ldy) -> mel_out [B, n_mels, T], power 2, for triangular filterbanks with a four-pass piece table
-// (segtab: 4096 words on the device, 16-byte aligned).  window [4096]; twiddle: W_4096^k, k = 0 .. 4095.
+// (segtab: 2048 words on the device, 16-byte aligned).  window [4096]; twiddle: W_4096^k, k = 0 .. 4095.
 extern "C" int syg_stft_mel_w4096_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                                       const float* window, const float* twiddle, const float* segtab, int n_segtab,
                                       int n_mels, float* mel_out, void* stream) {

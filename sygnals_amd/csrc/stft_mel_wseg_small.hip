@@ -1,0 +1,210 @@
+// Fused STFT -> |X|^2 -> mel for frame_length 512 and 256 (256 is the frame length of the reference's short-signal tests,
+// tests/test_features_manager.py:183-220; librosa.stft + np.abs(.)**2 + melspectrogram as manager.py:184-187, 198, 219-222
+// call them), free-running waves: a wave owns FOUR (512) or EIGHT (256) frames per 1024-point complex transform -- the
+// packings of stft_mel_pow2.hip (stft_mel_w512_kernel / stft_mel_w256_kernel: NF / 2 complex sequences of two real frames
+// each, interleaved; the inter-sequence twiddles drop out of the powers) -- and projects its own power rows onto the mel
+// bands by segment sums (mel_segments.h; one pass of 64 lanes per row, a four-row table, eight rows = two calls).  No
+// weight matrix, no spectrogram in HBM, no workgroup barrier behind the table set-up; the samples of the next group of
+// frames are requested before the current group is transformed.  power = 2 only.
+#include "wave_fft.h"
+
+namespace syg {
+namespace {
+#include "mel_segments.h"
+
+constexpr int SS_WAVES = 8;
+constexpr int SS_BASE = 4;                           // words in front of bin 0 (room for the lead of a short first piece)
+constexpr int SS_SEG_WORDS = 4 * 2 * 64 * 4;         // four rows, one pass each
+template <int NF> struct SmallCfg;
+template <> struct SmallCfg<4> { static constexpr int NFFT = 512, ROW = 296, LOGSEQ = 1; static constexpr float SCALE = 0.0625f; };
+template <> struct SmallCfg<8> { static constexpr int NFFT = 256, ROW = 160, LOGSEQ = 2; static constexpr float SCALE = 0.015625f; };
+
+__device__ __forceinline__ int ss_pos(int k) { return SS_BASE + k + (k >> 4); }      // == _tables.row_pos + row_base
+
+template <int NF>
+__global__ __launch_bounds__(SS_WAVES * 64, 4) void stft_mel_wseg_small_kernel(
+    const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int64_t units_per_clip,
+    int64_t n_units, const float* __restrict__ win, const float2* __restrict__ tw1024,
+    const float4* __restrict__ segtab, int n_mels, float* __restrict__ mel_out) {
+  typedef SmallCfg<NF> CF;
+  constexpr int ROW = CF::ROW, NSEQ = NF / 2, SPA = 64 / NSEQ;       // samples of a sequence per 64 elements of z
+  constexpr int SCW = NF * ROW;
+  static_assert(SCW >= 2 * wfft::SC_COMPLEX, "the exchange scratch must fit inside the rows");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* row0 = lds + w * SCW;
+  float2* sc = reinterpret_cast<float2*>(row0);
+  float2* tw2l = reinterpret_cast<float2*>(lds + SS_WAVES * SCW);
+  float2* tw1l = tw2l + wfft::TW2_COMPLEX;
+  float4* segl = reinterpret_cast<float4*>(tw1l + wfft::TW1_COMPLEX);
+  wfft::Lane lc;
+  wfft::init_lane(lc, lane);
+  if (tid < 64) tw2l[(tid >> 4) * wfft::TW2_STRIDE + (tid & 15)] = tw1024[(16 * (tid >> 4) * (tid & 15)) & 1023];
+  for (int i = tid; i < wfft::TW1_COMPLEX; i += SS_WAVES * 64) tw1l[i] = tw1024[(i & 63) * ((i >> 6) + 1)];
+  for (int i = tid; i < SS_SEG_WORDS / 4; i += SS_WAVES * 64) segl[i] = segtab[i];
+  // element 64 a + lane of z: sequence r = lane % NSEQ = frames (first + 2 r, first + 2 r + 1), sample SPA a + lane / NSEQ
+  const int rs = lane & (NSEQ - 1), nl = lane >> CF::LOGSEQ;
+  float wv[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) wv[a] = win[SPA * a + nl];
+  __syncthreads();
+  unsigned lk = 0;
+  {
+    const int* si = reinterpret_cast<const int*>(segl);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) lk |= (unsigned)(si[4 * (128 * p + lane) + 2] | si[4 * (128 * p + lane) + 3]);
+  }
+  const bool scan8 = __builtin_amdgcn_ballot_w64((lk >> 24) != 0) != 0;
+
+  float2 raw[16];
+  auto fetch = [&](int64_t u) {
+    const int64_t bq = u / units_per_clip;
+    const float* yb = y + bq * ldy;
+    const int64_t tfirst = (u - bq * units_per_clip) * NF, tf = tfirst + 2 * rs;
+    const int64_t sa = tf * (int64_t)hop - pad, sb = sa + hop;
+    const int64_t s_first = tfirst * (int64_t)hop - pad;
+    int ln = nl;
+    asm volatile("" : "+v"(ln));                  // (per-lane addresses are recomputed per group, not hoisted)
+    if (s_first >= 0 && s_first + (NF - 1) * (int64_t)hop + CF::NFFT <= L && tfirst + NF - 1 < T) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) raw[a] = make_float2(yb[sa + SPA * a + ln], yb[sb + SPA * a + ln]);
+    } else {
+      const bool hasa = tf < T, hasb = tf + 1 < T;
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        const int64_t ia = sa + SPA * a + ln, ib = sb + SPA * a + ln;
+        raw[a] = make_float2((hasa && ia >= 0 && ia < L) ? yb[ia] : 0.f, (hasb && ib >= 0 && ib < L) ? yb[ib] : 0.f);
+      }
+    }
+  };
+  const int64_t stride = (int64_t)gridDim.x * SS_WAVES;
+  int64_t u = (int64_t)blockIdx.x * SS_WAVES + w;
+  if (u < n_units) fetch(u);
+  for (; u < n_units; u += stride) {
+    const int64_t b = u / units_per_clip;
+    const int64_t tfirst = (u - b * units_per_clip) * NF;
+    float2 v[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v[a] = make_float2(raw[a].x * wv[a], raw[a].y * wv[a]);
+    if (u + stride < n_units) fetch(u + stride);
+    float2 zk[2][4], zm[2][4], z512;
+    wfft::cfft1024(v, lc, sc, tw1l, tw2l, lane, zk, zm, z512);
+    wave_lds_sync();                                   // the scratch is dead: the rows may be written
+    int lq = lane;
+    asm volatile("" : "+v"(lq));
+    if (NF == 4) {
+      // (za, zb, mb, ma) = (Z[k], Z[k + 512], Z[512 - k], Z[1024 - k]) -> 16 x the four frames' powers at one bin
+      auto four = [&](float2 za, float2 zb, float2 mb, float2 ma, int bin) {
+        const float sx = za.x + zb.x, sy = za.y + zb.y, dx = za.x - zb.x, dy = za.y - zb.y;
+        const float mx = mb.x + ma.x, my = mb.y + ma.y, ex = mb.x - ma.x, ey = mb.y - ma.y;
+        const float ax = sx + mx, ay = sy - my, bx = sx - mx, by = sy + my;
+        const float cx = dx - ex, cy = dy + ey, gx = dx + ex, gy = dy - ey;
+        const int q = ss_pos(bin);
+        row0[q] = fmaf(ax, ax, ay * ay);
+        row0[ROW + q] = fmaf(bx, bx, by * by);
+        row0[2 * ROW + q] = fmaf(cx, cx, cy * cy);
+        row0[3 * ROW + q] = fmaf(gx, gx, gy * gy);
+      };
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kb = wfft::bin_of(lq, j, 0);                       // 0 .. 127 (lane 0, unit 0: 0 -- overwritten below)
+        four(zk[j][0], zk[j][2], zm[j][2], zm[j][0], kb);
+        four(zk[j][1], zk[j][3], zm[j][3], zm[j][1], 256 - kb);
+      }
+      if (lq == 0) {
+        // unit 0 of lane 0 holds Z at 0, 256, 128, 384 (zk) and 0, 768, 896, 640 (zm), Z[512] apart
+        four(zk[0][0], z512, z512, zk[0][0], 0);
+        four(zk[0][1], zm[0][1], zk[0][1], zm[0][1], 256);
+        four(zk[0][2], zm[0][3], zk[0][3], zm[0][2], 128);
+      }
+    } else {
+      // z[d] = Z[k + 256 d], m[d] = Z[256 - k + 256 d]  ->  64 x the eight frames' powers at bin k
+      auto eight = [&](float2 z0, float2 z1, float2 z2, float2 z3, float2 m0, float2 m1, float2 m2, float2 m3, int bin) {
+        float2 F[4], G[4];
+        bfly4(z0, z1, z2, z3, F[0], F[1], F[2], F[3]);          // F[q] = sum_d z[d] (-i)^(d q): U_r = F[(4 - r) & 3]
+        bfly4(m0, m1, m2, m3, G[0], G[1], G[2], G[3]);
+        const int q = ss_pos(bin);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float2 U = F[(4 - r) & 3], V = G[(4 - r) & 3];
+          // (-i)^r conj V
+          const float2 Tt = r == 0 ? make_float2(V.x, -V.y) : r == 1 ? make_float2(-V.y, -V.x)
+                          : r == 2 ? make_float2(-V.x, V.y) : make_float2(V.y, V.x);
+          const float ax = U.x + Tt.x, ay = U.y + Tt.y, bx = U.x - Tt.x, by = U.y - Tt.y;
+          row0[(2 * r) * ROW + q] = fmaf(ax, ax, ay * ay);
+          row0[(2 * r + 1) * ROW + q] = fmaf(bx, bx, by * by);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kb = wfft::bin_of(lq, j, 0);
+        eight(zk[j][0], zk[j][1], zk[j][2], zk[j][3], zm[j][3], zm[j][2], zm[j][1], zm[j][0], kb);
+      }
+      if (lq == 0) {
+        eight(zk[0][0], zk[0][1], z512, zm[0][1], zk[0][1], z512, zm[0][1], zk[0][0], 0);
+        eight(zk[0][2], zk[0][3], zm[0][3], zm[0][2], zk[0][2], zk[0][3], zm[0][3], zm[0][2], 128);
+      }
+    }
+    wave_lds_sync();
+    float* mo = mel_out + (b * n_mels) * T + tfirst;
+    const int left = (int)((T - tfirst < NF) ? T - tfirst : NF);      // frames of this group inside the clip
+#pragma unroll
+    for (int h = 0; h < NF / 4; ++h)
+      tri_project<4>(row0 + 4 * h * ROW, segl, lq, scan8, [&](int bw, float val) {
+        const int band = bw & 255, r = 4 * h + (bw >> 8);             // (the host tags the band word with the row)
+        if (r < left) mo[(int64_t)band * T + r] = CF::SCALE * val;
+      });
+    wave_lds_sync();                                   // the rows are read: the next transform may use the scratch
+  }
+}
+
+template <int NF>
+int launch_small(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T, const float* window,
+                 const float* twiddle, const float* segtab, int n_mels, float* mel_out, hipStream_t st) {
+  typedef SmallCfg<NF> CF;
+  const int64_t upc = (T + NF - 1) / NF, n_units = B * upc;
+  SYG_REQUIRE(n_units < ((int64_t)1 << 40), "stft_mel_wseg_small: too many frames");
+  const int pad = center ? CF::NFFT / 2 : 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const size_t lds = ((size_t)SS_WAVES * NF * CF::ROW + 2 * (wfft::TW2_COMPLEX + wfft::TW1_COMPLEX) + SS_SEG_WORDS) * sizeof(float);
+  int64_t wgs = (n_units + SS_WAVES - 1) / SS_WAVES;
+  const int64_t cap = (int64_t)cus * 2 * 2;            // two workgroups per CU resident, two rounds
+  if (wgs > cap) wgs = cap;
+  auto kern = stft_mel_wseg_small_kernel<NF>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    set_error("stft_mel_wseg_small: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e));
+    return SYG_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(SS_WAVES * 64), lds, st, y, L, ldy, hop, pad, T, upc, n_units, window,
+                     (const float2*)twiddle, (const float4*)segtab, n_mels, mel_out);
+  SYG_CHECK_LAUNCH("stft_mel_wseg_small");
+  return SYG_OK;
+}
+
+}  // namespace
+}  // namespace syg
+
+using namespace syg;
+
+// n_fft = 512 or 256, power 2: y [B, L] (row stride ldy) -> mel_out [B, n_mels, T].  segtab: the four-row table of
+// sygnals_amd._tables.pack_mel_segments_rows(sr, n_fft, n_mels, fmin, fmax, rows=4, row_words=296 (512) / 160 (256),
+// n_pass=1) (2048 words on the device, 16-byte aligned); window [n_fft]; twiddle: W_1024^k, k = 0 .. 1023.
+extern "C" int syg_stft_mel_wseg_small_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
+                                           int64_t T, const float* window, const float* twiddle, const float* segtab,
+                                           int n_segtab, int n_mels, float* mel_out, void* stream) {
+  SYG_REQUIRE(y && window && twiddle && segtab && mel_out, "stft_mel_wseg_small: null pointer argument");
+  SYG_REQUIRE(n_fft == 512 || n_fft == 256, "stft_mel_wseg_small: n_fft must be 512 or 256 (got %d)", n_fft);
+  SYG_REQUIRE(B >= 1 && L >= 1 && ldy >= L, "stft_mel_wseg_small: need B >= 1, L >= 1, ldy >= L");
+  SYG_REQUIRE(hop >= 1, "stft_mel_wseg_small: hop must be >= 1");
+  const int64_t Texp = center ? 1 + L / hop : (L >= n_fft ? 1 + (L - n_fft) / hop : 0);
+  SYG_REQUIRE(T >= 1 && T == Texp, "stft_mel_wseg_small: T=%lld does not match the framing rule (%lld)", (long long)T, (long long)Texp);
+  SYG_REQUIRE(n_segtab == SS_SEG_WORDS, "stft_mel_wseg_small: the piece table has %d words, this library reads %d "
+              "(sygnals_amd._tables.pack_mel_segments_rows)", n_segtab, SS_SEG_WORDS);
+  SYG_REQUIRE(((uintptr_t)segtab) % 16 == 0, "stft_mel_wseg_small: the piece table must be 16-byte aligned");
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= 255, "stft_mel_wseg_small: n_mels must be in [1, 255]");
+  if (n_fft == 512) return launch_small<4>(y, B, L, ldy, hop, center, T, window, twiddle, segtab, n_mels, mel_out, (hipStream_t)stream);
+  return launch_small<8>(y, B, L, ldy, hop, center, T, window, twiddle, segtab, n_mels, mel_out, (hipStream_t)stream);
+}

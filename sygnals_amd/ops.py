@@ -263,6 +263,62 @@ def stft_mel_w1024_seg(y: torch.Tensor, sr: float, hop: int = 256, center: bool 
     return out
 
 
+_SMALL_ROW_WORDS = {512: 296, 256: 160}
+
+
+def wsmall_segtab(sr, n_fft, n_mels, fmin=0.0, fmax=None):
+    """Four-row piece table of the frame-length-512 / 256 segment-sum kernel for this filterbank on the device, or None."""
+    if n_fft not in _SMALL_ROW_WORDS:
+        return None
+    fmax = sr / 2.0 if fmax is None else fmax
+
+    def build():
+        try:
+            basis = T.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+            return _dev(T.pack_mel_segments_rows(sr, n_fft, n_mels, fmin, fmax, basis=basis, rows=4,
+                                                 row_words=_SMALL_ROW_WORDS[n_fft], n_pass=1).reshape(-1))
+        except ValueError:
+            return False
+    tab = _cached(("segsmall", float(sr), n_fft, n_mels, float(fmin), float(fmax)), build)
+    return None if tab is False else tab
+
+
+def stft_mel_wseg_small(y: torch.Tensor, sr: float, n_fft: int, hop: int, center: bool = True, window="hann", win_length=None,
+                        n_mels: int = 128, fmin: float = 0.0, fmax=None) -> torch.Tensor:
+    """frame_length 512 / 256, power 2: [B, L] clips -> mel power [B, n_mels, T] in one launch, free-running waves (four /
+    eight frames per wave transform, mel by segment sums).  Raises SygnalsHipError without a piece table."""
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    tab = wsmall_segtab(sr, n_fft, n_mels, fmin, fmax)
+    if tab is None:
+        raise SygnalsHipError("stft_mel_wseg_small: no piece table for this frame length / filterbank (use stft_mel_pow2)")
+    B, L = y.shape
+    Tn = num_frames(L, n_fft, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    out = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device)
+    rc = lib().syg_stft_mel_wseg_small_f32(_ptr(y), B, L, _ld(y), n_fft, hop, int(center), Tn,
+                                           _ptr(window_dev(window, win_length or n_fft, n_fft)), _ptr(twiddle_dev(1024)),
+                                           _ptr(tab), int(tab.numel()), n_mels, _ptr(out), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_mel_wseg_small_f32")
+    return out
+
+
+def stft_mel_segments(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax):
+    """Mel power by one of the segment-sum kernels of the other frame lengths (1024, 512, 256, 4096), or None when the
+    frame length / filterbank has none."""
+    if n_fft == 1024 and w1024_segtab(sr, n_mels, fmin, fmax) is not None:
+        return stft_mel_w1024_seg(y, sr, hop, center, window, win_length, n_mels, fmin, fmax)
+    if n_fft in _SMALL_ROW_WORDS and wsmall_segtab(sr, n_fft, n_mels, fmin, fmax) is not None:
+        return stft_mel_wseg_small(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax)
+    if n_fft == 4096 and w4096_segtab(sr, n_mels, fmin, fmax) is not None:
+        return stft_mel_w4096(y, sr, hop, center, window, win_length, n_mels, fmin, fmax)
+    return None
+
+
 def stft_mel_w4096(y: torch.Tensor, sr: float, hop: int = 1024, center: bool = True, window="hann", win_length=None,
                    n_mels: int = 128, fmin: float = 0.0, fmax=None) -> torch.Tensor:
     """frame_length 4096: [B, L] clips -> mel power [B, n_mels, T] in one launch (one wave per frame, mel by segment
@@ -500,6 +556,9 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
         if n_fft == 1024 and w1024_segtab(sr, n_mels, fmin, fmax) is not None:
             # free-running waves, mel by segment sums: 0.162 against 0.235 ms per 1024 clips x 1 s for the mel launch
             mel = stft_mel_w1024_seg(y, sr, hop, center, window, None, n_mels, fmin, fmax)
+        elif wsmall_segtab(sr, n_fft, n_mels, fmin, fmax) is not None:
+            # the same for 512 / 256: 0.265 against 0.334 ms, 0.330 against 0.356 ms
+            mel = stft_mel_wseg_small(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax)
         else:
             mel = stft_mel_pow2(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax)
         return logmel_dct(mel, n_mfcc, lifter=lifter)[1]

@@ -268,6 +268,31 @@ def test_frame_length_1024_segment_sum_kernel(ops, sr, hop, n_mels, L, center):
     assert np.array_equal(mel, again)
 
 
+@pytest.mark.parametrize("n_fft,sr,hop,n_mels,L,center", [(512, 48000, 128, 40, 48000, True), (256, 48000, 64, 40, 24000, True),
+                                                           (512, 16000, 100, 40, 7000, True), (256, 16000, 64, 40, 5001, False),
+                                                           (256, 22050, 33, 40, 3000, True), (512, 8000, 128, 26, 300, True),
+                                                           (256, 8000, 64, 26, 100, True)])
+def test_frame_lengths_512_256_segment_sum_kernel(ops, n_fft, sr, hop, n_mels, L, center):
+    """syg_stft_mel_wseg_small_f32 (free-running waves, four / eight frames per wave transform, mel by segment sums with a
+    four-row table) against the float64 oracle and the dense-matrix kernel: frame counts that are no multiple of the
+    group, odd hops, center=False, clips shorter than a frame."""
+    Y = O.synth_clips(9, L, sr, seed=hop + n_mels)
+    Y[2] *= 1e-3
+    Y[5][:] = 0.0
+    y = ops.to_device_f32(Y)
+    assert ops.wsmall_segtab(sr, n_fft, n_mels) is not None
+    mel = ops.stft_mel_wseg_small(y, sr, n_fft, hop, center, "hann", None, n_mels).cpu().numpy()
+    dense = ops.stft_mel_pow2(y, sr, n_fft, hop, center, "hann", None, n_mels).cpu().numpy()
+    assert mel.shape == dense.shape
+    for b in range(len(Y)):
+        P = np.abs(O.stft(Y[b].astype(np.float64), n_fft, hop, n_fft, "hann", center)) ** 2
+        want = O.melspectrogram(P, sr, n_fft, n_mels)
+        assert_parity(mel[b], want, TOL, f"mel n_fft={n_fft} sr={sr} clip {b}")
+        assert_parity(mel[b], dense[b], TOL, f"segment sums vs dense matrix, clip {b}")
+    again = ops.stft_mel_wseg_small(y, sr, n_fft, hop, center, "hann", None, n_mels).cpu().numpy()
+    assert np.array_equal(mel, again)
+
+
 @pytest.mark.parametrize("sr,hop,n_mels,L,center", [(48000, 1024, 40, 48000, True), (16000, 1024, 40, 30001, True),
                                                      (44100, 410, 40, 20000, True), (48000, 2048, 64, 25000, False),
                                                      (22050, 1024, 128, 22050, True), (48000, 1024, 40, 3000, True)])

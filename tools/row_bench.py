@@ -56,6 +56,11 @@ report("a1-a3 n_fft=1024 hop=256 mel only: segment-sum kernel (free-running wave
        B * L, B * (4 * L + 4 * 40 * (1 + L // 256)))
 report("a1-a3 n_fft=1024 hop=256 mel only: dense-matrix tile kernel", lambda: ops.stft_mel_pow2(y, SR, 1024, 256, True, "hann", None, 40),
        B * L, B * (4 * L + 4 * 40 * (1 + L // 256)))
+for nf, hp in ((512, 128), (256, 64)):
+    report(f"a1-a3 n_fft={nf} hop={hp} mel only: segment-sum kernel (free-running waves)", lambda: ops.stft_mel_wseg_small(y, SR, nf, hp, True, "hann", None, 40),
+           B * L, B * (4 * L + 4 * 40 * (1 + L // hp)))
+    report(f"a1-a3 n_fft={nf} hop={hp} mel only: dense-matrix tile kernel", lambda: ops.stft_mel_pow2(y, SR, nf, hp, True, "hann", None, 40),
+           B * L, B * (4 * L + 4 * 40 * (1 + L // hp)))
 # frame length 4096 (round 3: one wave per frame, mel by segment sums) against the generic chain
 Tf = 1 + L // 1024
 report("a1-a5 STFT->mel->MFCC n_fft=4096 hop=1024 (fused mel kernel + logmel_dct, 1024 clips)", lambda: ops.mfcc_batch(y, SR, 4096, 1024, n_mels=40),
