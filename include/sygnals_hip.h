@@ -86,6 +86,7 @@ const char* syg_last_error(void);
 #define SYG_SM_FLATNESS 4
 #define SYG_SM_ROLLOFF 8    /* also POWER_SUM, ROLLOFF_MARGIN */
 #define SYG_SM_DOMINANT 16
+#define SYG_SM_NO_MARGIN 32 /* with SYG_SM_ROLLOFF: the ROLLOFF_MARGIN row is not computed (callers that only read the bin) */
 
 int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                          const float* window, const float* twiddle, const float* wpacked,

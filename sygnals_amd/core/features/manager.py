@@ -359,7 +359,7 @@ def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: i
         cpv = torch.empty((B, 2, R, Tn), dtype=torch.float32, device=y.device)
         head = (ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn, ops._ptr(ops.window_dev("hann", 2048, 2048)),
                 ops._ptr(ops.twiddle_dev(2048)))
-        tail = (n_mels, ops._ptr(dct), n_mfcc, None, 1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), 2.0, 1 | 8,
+        tail = (n_mels, ops._ptr(dct), n_mfcc, None, 1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), 2.0, 1 | 8 | 32,
                 ops._ptr(stats), np.ascontiguousarray(cplan, np.int32).ctypes.data_as(C.c_void_p), ops._ptr(cpv))
         if tri_ok:
             rc = lib().syg_stft2048_features_tri_f32(*head, ops._ptr(cfg.segtab), int(cfg.segtab.numel()), *tail,
@@ -401,7 +401,7 @@ def feature_block_dominant(y, sr, hop_length, n_mels, n_mfcc):
         cph = np.ascontiguousarray(cplan, np.int32)
         args = (ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn, ops._ptr(ops.window_dev("hann", 2048, 2048)),
                 ops._ptr(ops.twiddle_dev(2048)), ops._ptr(cfg.segtab), int(cfg.segtab.numel()), n_mels, ops._ptr(dct), n_mfcc,
-                None, 1e-10, 80.0, 1, 1.0, float(sr), 0.85, 2.0, 1 | 8, ops._ptr(stats), cph.ctypes.data_as(C.c_void_p),
+                None, 1e-10, 80.0, 1, 1.0, float(sr), 0.85, 2.0, 1 | 8 | 32, ops._ptr(stats), cph.ctypes.data_as(C.c_void_p),
                 ops._ptr(cpv), ops._ptr(out), rows)
 
         def run():

@@ -407,7 +407,7 @@ typedef __attribute__((address_space(1))) float* gptr;
 __device__ __forceinline__ int stats_row_mask(int smask) {
   return ((smask & 1) ? (1 << SYG_STAT_CENTROID) | (1 << SYG_STAT_MAG_SUM) : 0) | ((smask & 2) ? (1 << SYG_STAT_BANDWIDTH) : 0) |
          ((smask & 4) ? (1 << SYG_STAT_FLATNESS) : 0) | ((smask & 16) ? (1 << SYG_STAT_DOMINANT_BIN) : 0) |
-         ((smask & 8) ? (1 << SYG_STAT_ROLLOFF_BIN) | (1 << SYG_STAT_POWER_SUM) | (1 << SYG_STAT_ROLLOFF_MARGIN) : 0);
+         ((smask & 8) ? (1 << SYG_STAT_ROLLOFF_BIN) | (1 << SYG_STAT_POWER_SUM) | ((smask & 32) ? 0 : (1 << SYG_STAT_ROLLOFF_MARGIN)) : 0);
 }
 __device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
   float res = 0.f;
@@ -493,22 +493,34 @@ __device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, flo
     // The running sum never decreases (powers are >= 0), so the number of a lane's sums below the threshold IS the
     // position of its first hit; the decision margin is the distance of the threshold to the nearest running sum on
     // either side (the sum in front of bin 0 excepted).
+    // (SYG_SM_NO_MARGIN: callers that do not read the margin row -- the C4 block -- skip its three instructions per bin.)
     const float thr = roll_percent * tot_p;
     float c = wave_excl_scan(psum, lane);
-    float mg = (lane > 0) ? fabsf(c - thr) : 3.4e38f;
     int below = 0;
+    float mgw = 0.f;
+    if (smask & 32) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      c += p[i];
-      below += (c < thr) ? 1 : 0;
+      for (int i = 0; i < 16; ++i) {
+        c += p[i];
+        below += (c < thr) ? 1 : 0;
+      }
+      c += p[16];
+      below += (last && c < thr) ? 1 : 0;
+    } else {
+      float mg = (lane > 0) ? fabsf(c - thr) : 3.4e38f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        c += p[i];
+        below += (c < thr) ? 1 : 0;
+        mg = fminf(mg, fabsf(c - thr));
+      }
+      c += p[16];
+      below += (last && c < thr) ? 1 : 0;
       mg = fminf(mg, fabsf(c - thr));
+      mgw = wave_min(mg);
     }
-    c += p[16];
-    below += (last && c < thr) ? 1 : 0;
-    mg = fminf(mg, fabsf(c - thr));
     const int rb = (below < (last ? 17 : 16)) ? 16 * lane + below : 0x7fffffff;
     int rbmin = wave_min_i(rb);
-    const float mgw = wave_min(mg);
     if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
     SYG_PUT(SYG_STAT_ROLLOFF_BIN, (float)rbmin);
     SYG_PUT(SYG_STAT_POWER_SUM, tot_p);
@@ -1761,7 +1773,7 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
   rc = parse_contrast_plan(contrast_out, cplan_host, cp);
   if (rc) return rc;
   if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f &&
-                                 stats_mask > 0 && stats_mask < 32 && T < ((int64_t)1 << 27),
+                                 (stats_mask & 31) != 0 && stats_mask > 0 && stats_mask < 64 && T < ((int64_t)1 << 27),
                              "stft2048_mel: invalid statistics parameters");
   const bool extra = (stats_out != nullptr) || (contrast_out != nullptr);
   const int load = load_mode();
@@ -1872,8 +1884,8 @@ extern "C" int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t 
   ContrastPlan cp;
   rc = parse_contrast_plan(contrast_out, cplan_host, cp);
   if (rc) return rc;
-  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && stats_mask > 0 &&
-                                 stats_mask < 32, "stft2048_features_tri: invalid statistics parameters");
+  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && (stats_mask & 31) != 0 &&
+                                 stats_mask > 0 && stats_mask < 64, "stft2048_features_tri: invalid statistics parameters");
   MelPlan plan;
   memset(&plan, 0, sizeof(plan));
   MfccArgs mf;
@@ -1911,8 +1923,8 @@ extern "C" int syg_stft2048_features_f32(const float* y, int64_t B, int64_t L, i
   ContrastPlan cp;
   rc = parse_contrast_plan(contrast_out, cplan_host, cp);
   if (rc) return rc;
-  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && stats_mask > 0 &&
-                                 stats_mask < 32, "stft2048_features: invalid statistics parameters");
+  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && (stats_mask & 31) != 0 &&
+                                 stats_mask > 0 && stats_mask < 64, "stft2048_features: invalid statistics parameters");
   MfccArgs mf;
   mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
   mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = mfcc_rows_per_clip;
