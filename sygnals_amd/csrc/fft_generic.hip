@@ -407,7 +407,11 @@ __global__ __launch_bounds__(COLS_NT) void fft_cols_kernel(const float2* __restr
     if (KFAST) { k = idx & (n - 1); c = idx >> ln; }
     else { c = idx & (CB - 1); k = idx >> cb_log; }
     float2 v = r[c * LP + k];
-    if (bign > 0) v = cmul(v, four_step_twiddle(((c0 + c) * (int64_t)k) % bign, bign));
+    if (bign > 0) {
+      int64_t e = (c0 + c) * (int64_t)k;
+      if (e >= bign) e %= bign;                                // (column * k < bign in a four-step split: never taken there)
+      v = cmul(v, four_step_twiddle(e, bign));
+    }
     v.x *= scale; v.y *= scale;
     if (inverse) v.y = -v.y;
     op[(c0 + c) * out_bs + (int64_t)k * out_es] = v;
@@ -598,6 +602,8 @@ extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t
   if (in_bs == 1 && (out_es == 1 || out_bs == 1) && n <= COLS_MAXN && n >= 8) {
     int cb_log = 4;                                            // 16 columns = 128-byte runs
     while (cb_log > 2 && ((int64_t)n << cb_log) > 4096) --cb_log;
+    // (two workgroups per CU hide too little: above 40 KB of LDS take 8 columns, see fft_mixed.hip)
+    if (cb_log == 4 && (size_t)2 * ((size_t)(n + COLS_PAD) << 4) * sizeof(float2) > 40 * 1024) cb_log = 3;
     if (batch % (1 << cb_log) == 0) {
       const bool kfast = out_es == 1;
       const void* fn = kfast ? (const void*)fft_cols_kernel<true> : (const void*)fft_cols_kernel<false>;

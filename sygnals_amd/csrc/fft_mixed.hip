@@ -176,7 +176,8 @@ __global__ __launch_bounds__(MCOLS_NT) void fft_mixed_cols_kernel(const float2* 
     else { c = idx & (CB - 1); k = idx >> cb_log; }
     float2 v = r[c * LP + k];
     if (bign > 0) {
-      const int64_t e = ((c0 + c) * (int64_t)k) % bign;
+      int64_t e = (c0 + c) * (int64_t)k;
+      if (e >= bign) e %= bign;                                // (column * k < bign in a four-step split: never taken there)
       double sn, cs;
       sincospi(-2.0 * (double)e / (double)bign, &sn, &cs);
       v = cmul(v, make_float2((float)cs, (float)sn));
@@ -223,6 +224,9 @@ extern "C" int syg_fft_mixed_strided_c2c_f32(const float* in, float* out, int64_
   if (in_bs == 1 && (out_es == 1 || out_bs == 1) && n <= 1024 && n >= 8) {
     int cb_log = 4;                                            // 16 columns = 128-byte runs
     while (cb_log > 2 && (((int64_t)n << cb_log) > 4096 || batch % (1 << cb_log) != 0)) --cb_log;
+    // two workgroups per CU hide too little: above 40 KB of LDS take 8 columns (64-byte runs) -- 758 -> 646 us for the two
+    // passes of 1024 x 48000 (200 x 240), 1145 -> 760 us for 1024 x 65536 (256 x 256); 4 columns are slower again
+    if (cb_log == 4 && (size_t)2 * ((size_t)(n + MCOLS_PAD) << 4) * sizeof(float2) > 40 * 1024) cb_log = 3;
     if (((int64_t)n << cb_log) <= 4096 && batch % (1 << cb_log) == 0) {
       const bool kfast = out_es == 1;
       const void* fn = kfast ? (const void*)fft_mixed_cols_kernel<true> : (const void*)fft_mixed_cols_kernel<false>;

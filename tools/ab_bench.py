@@ -25,6 +25,7 @@ if what == "cqt":
     g = torch.Generator(device="cuda").manual_seed(5)
     stream = (torch.randn(48000 * 3600, device="cuda", generator=g, dtype=torch.float32) * 0.05).reshape(1, -1)
 y2 = ops.to_device_f32(np.tile(Y, (2048 // 64, 1))) if what.startswith("c4blk") else None
+XC = torch.randn((1024, 48000 if what == "fft48k" else 65536, 2), dtype=torch.float32, device="cuda") if what.startswith("fft") else None
 fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "mfcc441": lambda: ops.stft2048_mfcc(y, 44100, 512, True, "hann", 40, 13),       # (a 3-step scan layout of the segment projection)
       "mfccmat": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13, projection="matrix"),
@@ -36,14 +37,16 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "c4blk5": lambda: FB(y2, 48000, one_launch="matrix"),
       "c4blk2": lambda: FB(y2, 48000, one_launch=False),
       "cqt": lambda: ops.cqt(stream, 48000),
+      "fft48k": lambda: ops.fft_any(XC),                      # 1024 x 48000 complex, mixed radix 200 x 240
+      "fft64k": lambda: ops.fft_pow2_any(XC),                 # 1024 x 65536 complex, four-step 256 x 256
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
-for _ in range(400 if what != "cqt" else 20): fn()
+for _ in range(400 if what != "cqt" and not what.startswith("fft") else 20): fn()
 torch.cuda.synchronize()
 best = 1e9
 for rep in range(5):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    nrep = 100 if what != "cqt" else 10
+    nrep = 100 if what != "cqt" and not what.startswith("fft") else 10
     for _ in range(nrep): fn()
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) * 1000 / nrep)
