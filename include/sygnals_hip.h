@@ -201,6 +201,10 @@ int syg_stft_mel_wseg_small_f32(const float* y, int64_t B, int64_t L, int64_t ld
 int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const float* dct, int K,
                        const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
                        float* logmel_out, float* mfcc_out, void* stream);
+/* MFCCs alone (librosa.feature.mfcc(S=power_to_db(S_mel, ref=np.max)), cepstral.py:106-115 behind manager.py:223): as above,
+ * but the dB matrix is written nowhere when the clip's matrix fits the LDS; `mel` is scratch for the call. */
+int syg_mel_mfcc_f32(float* mel, int64_t B, int M, int64_t T, const float* dct, int K, const float* lifter, float amin,
+                     float top_db, int ref_is_max, float ref_value, float* mfcc_out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Generic batched power-of-two FFT in LDS (n = 2^k, 2 <= n <= 8192): scipy.fft.fft /

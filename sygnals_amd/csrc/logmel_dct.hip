@@ -89,7 +89,10 @@ dct_stage:
 // the other frame lengths' tile kernels): one read of the mel matrix, the dB matrix written once (the in-place /
 // logmel_out contract) and read back from LDS by the DCT, whose rows wait in registers; 512 threads.  The form above read
 // the matrix from global memory three times, one dependent L2 round trip per DCT step (32 us per 1024 clips at T = 188).
+// STORE_DB = false (syg_mel_mfcc_f32): the dB matrix only exists in LDS -- callers that want the MFCCs alone save its
+// M * T * 4 bytes of HBM writes per clip (at T = 751 frames three times the bytes of the MFCCs).
 constexpr int NTL = 512;
+template <bool STORE_DB>
 __global__ __launch_bounds__(NTL) void logmel_dct_lds_kernel(float* __restrict__ mel, int M, int64_t T,
                                                              const float* __restrict__ dct, int K,
                                                              const float* __restrict__ lifter, float amin, float top_db,
@@ -134,12 +137,13 @@ __global__ __launch_bounds__(NTL) void logmel_dct_lds_kernel(float* __restrict__
       q.z = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, q.z)) - reflog), flo);
       q.w = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, q.w)) - reflog), flo);
       reinterpret_cast<float4*>(db)[i] = q;
-      reinterpret_cast<float4*>(dst)[i] = q;
+      if (STORE_DB) reinterpret_cast<float4*>(dst)[i] = q;
     }
   } else {
     for (int i = tid; i < n; i += NTL) {
       const float v = fmaxf(SYG_DB_PER_LOG2 * (syg_log2(fmaxf(amin, db[i])) - reflog), flo);
-      db[i] = v; dst[i] = v;
+      db[i] = v;
+      if (STORE_DB) dst[i] = v;
     }
   }
   if (mfcc == nullptr) return;
@@ -297,10 +301,10 @@ extern "C" int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const
   const size_t lds = (size_t)M * (size_t)T * sizeof(float);
   if (ref_is_max != 2 && lds <= 144 * 1024 && M <= 128) {
     if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)logmel_dct_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)logmel_dct_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("logmel_dct: cannot reserve %zu B of LDS", lds); return SYG_E_LAUNCH; }
     }
-    hipLaunchKernelGGL(logmel_dct_lds_kernel, dim3((unsigned)B), dim3(NTL), lds, (hipStream_t)stream, mel, M, T, dct, K,
+    hipLaunchKernelGGL(logmel_dct_lds_kernel<true>, dim3((unsigned)B), dim3(NTL), lds, (hipStream_t)stream, mel, M, T, dct, K,
                        lifter, amin, top_db, ref_is_max, ref_value, logmel_out, mfcc_out);
     SYG_CHECK_LAUNCH("logmel_dct");
     return SYG_OK;
@@ -309,4 +313,28 @@ extern "C" int syg_logmel_dct_f32(float* mel, int64_t B, int M, int64_t T, const
                      lifter, amin, top_db, ref_is_max, ref_value, logmel_out, mfcc_out);
   SYG_CHECK_LAUNCH("logmel_dct");
   return SYG_OK;
+}
+
+// MFCCs alone from a mel power matrix: power_to_db(ref, amin, top_db) + DCT rows (+ lifter) as syg_logmel_dct_f32, but the
+// dB matrix is not written anywhere when the clip's matrix fits the LDS (M * T * 4 <= 144 KiB, M <= 128).  Larger clips take
+// syg_logmel_dct_f32's in-place form: `mel` is scratch for this call either way (callers pass a temporary).
+extern "C" int syg_mel_mfcc_f32(float* mel, int64_t B, int M, int64_t T, const float* dct, int K, const float* lifter,
+                                float amin, float top_db, int ref_is_max, float ref_value, float* mfcc_out, void* stream) {
+  SYG_REQUIRE(mel && mfcc_out && dct, "mel_mfcc: null pointer argument");
+  SYG_REQUIRE(B >= 1 && M >= 1 && T >= 1 && B < (int64_t)0x7fffffff, "mel_mfcc: need B, M, T >= 1");
+  SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "mel_mfcc: ref_is_max must be 0 or 1");
+  SYG_REQUIRE(amin >= 1.17549435e-38f, "mel_mfcc: amin must be a positive normal float (>= 1.17549435e-38)");
+  SYG_REQUIRE(K >= 1 && K <= M, "mel_mfcc: need 1 <= K <= M (K=%d M=%d)", K, M);
+  const size_t lds = (size_t)M * (size_t)T * sizeof(float);
+  if (lds <= 144 * 1024 && M <= 128) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)logmel_dct_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("mel_mfcc: cannot reserve %zu B of LDS", lds); return SYG_E_LAUNCH; }
+    }
+    hipLaunchKernelGGL(logmel_dct_lds_kernel<false>, dim3((unsigned)B), dim3(NTL), lds, (hipStream_t)stream, mel, M, T, dct, K,
+                       lifter, amin, top_db, ref_is_max, ref_value, (float*)nullptr, mfcc_out);
+    SYG_CHECK_LAUNCH("mel_mfcc");
+    return SYG_OK;
+  }
+  return syg_logmel_dct_f32(mel, B, M, T, dct, K, lifter, amin, top_db, ref_is_max, ref_value, nullptr, mfcc_out, stream);
 }

@@ -433,6 +433,32 @@ def logmel_dct(mel: torch.Tensor, n_mfcc: Optional[int] = 13, dct_type: int = 2,
     return (logmel if keep_mel else mel), mf
 
 
+def mel_mfcc(mel: torch.Tensor, n_mfcc: int = 13, dct_type: int = 2, norm="ortho", lifter: float = 0.0, amin: float = 1e-10,
+             top_db: Optional[float] = 80.0, ref="max") -> torch.Tensor:
+    """MFCC [B, K, T] from a mel POWER matrix [B, M, T] that the caller no longer needs (it is scratch for the call): dB +
+    DCT as logmel_dct, without writing the dB matrix to HBM."""
+    require_gpu()
+    B, M, Tn = mel.shape
+    if amin <= 0:
+        raise ValueError("amin must be strictly positive")
+    if top_db is not None and top_db < 0:
+        raise ValueError("top_db must be non-negative")
+    K = int(n_mfcc)
+    dct = _cached(("dct", K, M, dct_type, norm), lambda: _dev(T.dct_matrix(K, M, dct_type, norm)))
+    lw = T.lifter_weights(K, float(lifter))
+    lif = _dev(lw) if lw is not None else None
+    mf = torch.empty((B, K, Tn), dtype=torch.float32, device=mel.device)
+    if (isinstance(ref, str) and ref == "max") or ref is np.max:
+        ref_is_max, ref_value = 1, 1.0
+    else:
+        ref_is_max, ref_value = 0, float(ref)
+    rc = lib().syg_mel_mfcc_f32(_ptr(mel), B, M, Tn, _ptr(dct), K, _ptr(lif), float(amin),
+                                float(top_db) if top_db is not None else -1.0, ref_is_max, ref_value, _ptr(mf),
+                                C.c_void_p(_stream_ptr()))
+    check(rc, "syg_mel_mfcc_f32")
+    return mf
+
+
 def mfcc_fused_fits(n_mels: int, n_frames: int, n_mfcc: int = 13) -> bool:
     """True when the clip's mel matrix + DCT rows fit the LDS left beside the fused kernel's buffers (the library
     owns the formula: syg_stft2048_mfcc_fits)."""
@@ -561,24 +587,23 @@ def mfcc_batch(y: torch.Tensor, sr: float, n_fft: int = 2048, hop: int = 512, n_
             mel = stft_mel_wseg_small(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax)
         else:
             mel = stft_mel_pow2(y, sr, n_fft, hop, center, window, None, n_mels, fmin, fmax)
-        return logmel_dct(mel, n_mfcc, lifter=lifter)[1]
+        return mel_mfcc(mel, n_mfcc, lifter=lifter)
     if n_fft == 4096 and fused is not False and w4096_segtab(sr, n_mels, fmin, fmax) is not None:
         # frame length 4096: one launch samples -> mel (one wave per frame, mel by segment sums), then dB + DCT
-        return logmel_dct(stft_mel_w4096(y, sr, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)[1]
+        return mel_mfcc(stft_mel_w4096(y, sr, hop, center, window, None, n_mels, fmin, fmax), n_mfcc, lifter=lifter)
     if not fused_mel_ok(sr, n_fft, n_mels, fmin, fmax):
         # no fused kernel for this shape: complex STFT (any frame length) -> |X|^2 -> dense mel -> dB + DCT
         if fused:
             raise SygnalsHipError(f"mfcc_batch: no fused kernel for n_fft={n_fft}, n_mels={n_mels}")
         P = cabs_pow(stft_any(y, n_fft, hop, center, window), 2)
         mel = mel_dense(P, mel_config(sr, n_fft, n_mels, fmin, fmax).basis)
-        return logmel_dct(mel, n_mfcc, lifter=lifter)[1]
+        return mel_mfcc(mel, n_mfcc, lifter=lifter)
     if fused is None:
         fused = mfcc_fused_fits(n_mels, num_frames(y.shape[1], 2048, hop, center), n_mfcc) and y.shape[0] >= 128
     if fused:
         return stft2048_mfcc(y, sr, hop, center, window, n_mels, n_mfcc, fmin, fmax, lifter)[0]
     mel, _, _ = stft2048_mel(y, sr, hop, center, window, 2048, n_mels, fmin, fmax)
-    _, mf = logmel_dct(mel, n_mfcc, lifter=lifter)
-    return mf
+    return mel_mfcc(mel, n_mfcc, lifter=lifter)
 
 
 # ------------------------------------------------------------------ generic pow2 kernels

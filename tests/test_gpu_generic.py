@@ -268,6 +268,22 @@ def test_frame_length_1024_segment_sum_kernel(ops, sr, hop, n_mels, L, center):
     assert np.array_equal(mel, again)
 
 
+@pytest.mark.parametrize("M,T,K,lifter", [(40, 188, 13, 0.0), (40, 751, 13, 22.0), (128, 94, 20, 0.0), (40, 1203, 13, 0.0), (7, 5, 7, 0.0)])
+def test_mel_mfcc_equals_logmel_dct_without_touching_hbm_db(ops, M, T, K, lifter):
+    """syg_mel_mfcc_f32: the MFCCs of syg_logmel_dct_f32, bit for bit, without the dB matrix in HBM (clips that fit the LDS;
+    the 40 x 1203 case takes the in-place form)."""
+    rng = np.random.default_rng(M + T)
+    mel = (rng.random((6, M, T)) ** 6 * 50.0).astype(np.float32)
+    mel[3] = 0.0
+    a = ops.to_device_f32(mel.reshape(6, -1)).reshape(6, M, T)
+    b = a.clone()
+    _, want = ops.logmel_dct(a, K, lifter=lifter)
+    got = ops.mel_mfcc(b, K, lifter=lifter)
+    assert torch.equal(got, want)
+    ref = np.stack([O.mfcc(S=O.power_to_db(m.astype(np.float64), ref=np.max), n_mfcc=K, lifter=lifter) for m in mel])
+    assert_parity(got.cpu().numpy(), ref, TOL, "mel_mfcc vs oracle")
+
+
 @pytest.mark.parametrize("n_fft,sr,hop,n_mels,L,center", [(512, 48000, 128, 40, 48000, True), (256, 48000, 64, 40, 24000, True),
                                                            (512, 16000, 100, 40, 7000, True), (256, 16000, 64, 40, 5001, False),
                                                            (256, 22050, 33, 40, 3000, True), (512, 8000, 128, 26, 300, True),
