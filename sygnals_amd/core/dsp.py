@@ -291,6 +291,15 @@ def analytic_batch(x):
     return ops.analytic_signal(x)
 
 
+def envelope_batch(x):
+    """Rows of the device tensor x [B, n] -> |analytic signal| [B, n] (the packing, masking and |.| passes folded into the
+    transforms where the length has a two-kernel plan)."""
+    if x.shape[1] == 0:
+        raise ValueError("envelope_batch: empty input")
+    env = ops.analytic_fused(x, True) if (x.dtype == ops.torch.float32 and x.is_cuda) else None
+    return env if env is not None else ops.cabs_pow(ops.analytic_signal(x), 1)
+
+
 def amplitude_envelope(y, method: str = "hilbert", frame_length: Optional[int] = None,
                        hop_length: Optional[int] = None) -> np.ndarray:
     y = np.asarray(y)
@@ -299,7 +308,7 @@ def amplitude_envelope(y, method: str = "hilbert", frame_length: Optional[int] =
     if method == "hilbert":
         if y.size == 0:
             raise ValueError("N must be positive.")
-        env = ops.cabs_pow(analytic_batch(ops.to_device_f32(y[None, :])), 1)
+        env = envelope_batch(ops.to_device_f32(y[None, :]))
         return env[0].cpu().numpy().astype(np.float64)
     if method == "rms":
         if frame_length is None or hop_length is None:

@@ -51,6 +51,23 @@ __device__ __forceinline__ void bfly4(float2 a0, float2 a1, float2 a2, float2 a3
   o3 = make_float2(t1.x - t3.y, t1.y + t3.x);
 }
 
+// Fused ends of the strided transforms (syg_fft_*_strided_ex_f32): a REAL input array (imaginary part 0: no packing pass),
+// the analytic-signal weights of scipy.signal.hilbert applied to the loaded element (its index inside the row is its
+// frequency bin: 1 at 0 and n / 2, 2 below n / 2, 0 above: no masking pass), magnitudes as the output (no |.| pass).
+constexpr int SYG_FFT_REAL_IN = 1, SYG_FFT_ABS_OUT = 2;
+__device__ __forceinline__ float2 fft_load(const float2* __restrict__ in, int64_t idx, int64_t k, int flags, int64_t mask_n) {
+  float2 v = (flags & SYG_FFT_REAL_IN) ? make_float2(reinterpret_cast<const float*>(in)[idx], 0.f) : in[idx];
+  if (mask_n > 0) {
+    const float h = (k == 0 || 2 * k == mask_n) ? 1.f : (2 * k < mask_n ? 2.f : 0.f);
+    v.x *= h; v.y *= h;
+  }
+  return v;
+}
+__device__ __forceinline__ void fft_store(float2* __restrict__ out, int64_t idx, float2 v, int flags) {
+  if (flags & SYG_FFT_ABS_OUT) reinterpret_cast<float*>(out)[idx] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
+  else out[idx] = v;
+}
+
 // In-register forward 16-point DFT, natural order in and out (radix-4 x radix-4).
 __device__ __forceinline__ void dft16(float2 (&v)[16]) {
   constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;

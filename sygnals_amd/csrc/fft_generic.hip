@@ -325,16 +325,16 @@ __global__ __launch_bounds__(256) void welch_final2_kernel(const double* __restr
 // multiplied by the four-step twiddle W_bign^(b*k) (conjugated for the inverse).
 __global__ void fft_pow2_strided_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n, int inverse,
                                         const float2* __restrict__ tw, int64_t in_os, int64_t in_bs, int64_t in_es,
-                                        int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale) {
+                                        int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale,
+                                        int flags, int64_t mask_n) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* x = reinterpret_cast<float2*>(lds);
   float2* y = x + n;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int64_t b = blockIdx.x, o = blockIdx.y;
-  const float2* ip = in + o * in_os + b * in_bs;
-  float2* op = out + o * out_os + b * out_bs;
+  const int64_t ibase = o * in_os, irow = b * in_bs, obase = o * out_os + b * out_bs;
   for (int i = tid; i < n; i += nt) {
-    float2 v = ip[(int64_t)i * in_es];
+    float2 v = fft_load(in, ibase + irow + (int64_t)i * in_es, irow + (int64_t)i * in_es, flags, mask_n);
     if (inverse) v.y = -v.y;
     x[i] = v;
   }
@@ -350,7 +350,7 @@ __global__ void fft_pow2_strided_kernel(const float2* __restrict__ in, float2* _
     }
     v.x *= scale; v.y *= scale;
     if (inverse) v.y = -v.y;
-    op[(int64_t)k * out_es] = v;
+    fft_store(out, obase + (int64_t)k * out_es, v, flags);
   }
 }
 
@@ -380,19 +380,19 @@ __global__ __launch_bounds__(COLS_NT) void fft_cols_kernel(const float2* __restr
                                                            int n, int cb_log, int inverse,
                                                            const float2* __restrict__ tw, int64_t in_os, int64_t in_es,
                                                            int64_t out_os, int64_t out_bs, int64_t out_es,
-                                                           int64_t bign, float scale) {
+                                                           int64_t bign, float scale, int flags, int64_t mask_n) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int CB = 1 << cb_log, LP = n + COLS_PAD;
   float2* x = reinterpret_cast<float2*>(lds);
   float2* y = x + CB * LP;
   const int tid = threadIdx.x;
   const int64_t c0 = (int64_t)blockIdx.x << cb_log, o = blockIdx.y;
-  const float2* ip = in + o * in_os + c0;
-  float2* op = out + o * out_os;
+  const int64_t ibase = o * in_os, obase = o * out_os;
   const int total = n << cb_log;
   for (int idx = tid; idx < total; idx += COLS_NT) {
     const int c = idx & (CB - 1), e = idx >> cb_log;
-    float2 v = ip[(int64_t)e * in_es + c];
+    const int64_t pos = (int64_t)e * in_es + c0 + c;           // position inside the row (= the bin, for the analytic weights)
+    float2 v = fft_load(in, ibase + pos, pos, flags, mask_n);
     if (inverse) v.y = -v.y;
     x[c * LP + e] = v;
   }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(COLS_NT) void fft_cols_kernel(const float2* __restr
     }
     v.x *= scale; v.y *= scale;
     if (inverse) v.y = -v.y;
-    op[(c0 + c) * out_bs + (int64_t)k * out_es] = v;
+    fft_store(out, obase + (c0 + c) * out_bs + (int64_t)k * out_es, v, flags);
   }
 }
 
@@ -590,15 +590,16 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
   return welch_combine((const float*)work, B, nblk, F, nseg, scale, psd_out, st);
 }
 
-extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t outer, int64_t batch, int n,
+extern "C" int syg_fft_pow2_strided_ex_f32(const float* in, float* out, int64_t outer, int64_t batch, int n,
                                             int inverse, const float* twiddle, int64_t in_os, int64_t in_bs,
                                             int64_t in_es, int64_t out_os, int64_t out_bs, int64_t out_es,
-                                            int64_t bign, float scale, void* stream) {
+                                            int64_t bign, float scale, int flags, int64_t mask_n, void* stream) {
   SYG_REQUIRE(in && out && twiddle, "fft_pow2_strided: null pointer argument");
   SYG_REQUIRE(is_pow2(n) && n <= MAX_N, "fft_pow2_strided: n must be a power of two in [2, %d] (got %d)", MAX_N, n);
   SYG_REQUIRE(batch >= 1 && batch < (int64_t)0x7fffffff && outer >= 1 && outer <= 65535,
               "fft_pow2_strided: bad batch/outer");
   SYG_REQUIRE(in != out, "fft_pow2_strided: in-place operation is not supported");
+  SYG_REQUIRE(flags >= 0 && flags <= 3 && mask_n >= 0, "fft_pow2_strided: bad flags / mask length");
   if (in_bs == 1 && (out_es == 1 || out_bs == 1) && n <= COLS_MAXN && n >= 8) {
     int cb_log = 4;                                            // 16 columns = 128-byte runs
     while (cb_log > 2 && ((int64_t)n << cb_log) > 4096) --cb_log;
@@ -614,11 +615,11 @@ extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t
       if (kfast)
         hipLaunchKernelGGL(fft_cols_kernel<true>, grid, dim3(COLS_NT), lds, (hipStream_t)stream, (const float2*)in,
                            (float2*)out, n, cb_log, inverse, (const float2*)twiddle, in_os, in_es, out_os, out_bs,
-                           out_es, bign, scale);
+                           out_es, bign, scale, flags, mask_n);
       else
         hipLaunchKernelGGL(fft_cols_kernel<false>, grid, dim3(COLS_NT), lds, (hipStream_t)stream, (const float2*)in,
                            (float2*)out, n, cb_log, inverse, (const float2*)twiddle, in_os, in_es, out_os, out_bs,
-                           out_es, bign, scale);
+                           out_es, bign, scale, flags, mask_n);
       SYG_CHECK_LAUNCH("fft_pow2_strided(cols)");
       return SYG_OK;
     }
@@ -628,9 +629,17 @@ extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t
   if (rc) return rc;
   hipLaunchKernelGGL(fft_pow2_strided_kernel, dim3((unsigned)batch, (unsigned)outer), dim3(fft_threads(n)), lds,
                      (hipStream_t)stream, (const float2*)in, (float2*)out, n, inverse, (const float2*)twiddle, in_os,
-                     in_bs, in_es, out_os, out_bs, out_es, bign, scale);
+                     in_bs, in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n);
   SYG_CHECK_LAUNCH("fft_pow2_strided");
   return SYG_OK;
+}
+
+extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t outer, int64_t batch, int n, int inverse,
+                                            const float* twiddle, int64_t in_os, int64_t in_bs, int64_t in_es,
+                                            int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale,
+                                            void* stream) {
+  return syg_fft_pow2_strided_ex_f32(in, out, outer, batch, n, inverse, twiddle, in_os, in_bs, in_es, out_os, out_bs, out_es,
+                                     bign, scale, 0, 0, stream);
 }
 
 extern "C" int syg_cmul_c64(const float* a, const float* b, float* out, int64_t na, int64_t nb, int conj_b,

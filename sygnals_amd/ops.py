@@ -1189,9 +1189,64 @@ def rfft_conv(x: torch.Tensor, k: torch.Tensor, reverse_k: bool = False) -> torc
     return fft_any(za, True).view(B, M)[:, : n + m - 1]
 
 
+FFT_REAL_IN, FFT_ABS_OUT = 1, 2
+
+
+def _strided_ex(kind, x, out, outer, batch, n, inverse, strides, bign=0, scale=1.0, flags=0, mask_n=0):
+    in_os, in_bs, in_es, out_os, out_bs, out_es = strides
+    fn = lib().syg_fft_pow2_strided_ex_f32 if kind == "pow2" else lib().syg_fft_mixed_strided_ex_f32
+    rc = fn(_ptr(x), _ptr(out), outer, batch, n, int(inverse), _ptr(twiddle_dev(n)), in_os, in_bs, in_es, out_os, out_bs,
+            out_es, bign, float(scale), int(flags), int(mask_n), C.c_void_p(_stream_ptr()))
+    check(rc, "syg_fft_%s_strided_ex_f32" % kind)
+
+
+def analytic_fused(x: torch.Tensor, magnitude: bool):
+    """scipy.signal.hilbert of the rows of x [B, n] (float32, contiguous) with the packing, masking and |.| passes folded
+    into the transforms' loads and stores: complex [B, n, 2], or the envelope [B, n] when magnitude.  Returns None where
+    the length has no two-kernel plan (powers of two up to 2^26 and 7-smooth lengths that split into two factors <= 8192;
+    other lengths go through Bluestein in analytic_signal)."""
+    B, n = x.shape
+    if n < 2 or B > MAX_ROWS:
+        return None
+    if is_pow2(n):
+        kind = "pow2"
+        if n <= MAX_LDS_FFT:
+            n1, n2 = n, 1
+        else:
+            n1 = 1 << ((n.bit_length() - 1) // 2)
+            n2 = n // n1
+            if n2 > MAX_LDS_FFT:
+                return None
+    elif _is_smooth(n) and smooth_split(n) is not None:
+        kind = "mixed"
+        n1, n2 = smooth_split(n)
+    else:
+        return None
+    x = x.contiguous()
+    X = torch.empty((B, n, 2), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, n) if magnitude else (B, n, 2), dtype=torch.float32, device=x.device)
+    oflag = FFT_ABS_OUT if magnitude else 0
+    if n2 == 1:
+        # (one transform per row: the ROW is the outer index, so that an element's position inside the row is its bin)
+        _strided_ex(kind, x, X, B, 1, n, False, (n, 0, 1, n, 0, 1), flags=FFT_REAL_IN)
+        _strided_ex(kind, X, out, B, 1, n, True, (n, 0, 1, n, 0, 1), scale=1.0 / n, flags=oflag, mask_n=n)
+        return out
+    tmp = torch.empty_like(X)
+    # forward: step A reads the REAL rows; inverse: step A weights the spectrum as it loads it, step B stores |.|
+    _strided_ex(kind, x, tmp, B, n2, n1, False, (n, 1, n2, n, n1, 1), bign=n, flags=FFT_REAL_IN)
+    _strided_ex(kind, tmp, X, B, n1, n2, False, (n, 1, n1, n, 1, n1))
+    _strided_ex(kind, X, tmp, B, n2, n1, True, (n, 1, n2, n, n1, 1), bign=n, mask_n=n)
+    _strided_ex(kind, tmp, out, B, n1, n2, True, (n, 1, n1, n, 1, n1), scale=1.0 / n, flags=oflag)
+    return out
+
+
 def analytic_signal(x: torch.Tensor) -> torch.Tensor:
     """scipy.signal.hilbert of the rows of x [B, n] -> complex [B, n, 2] (exact length-n transforms)."""
     B, n = x.shape
+    if x.dtype == torch.float32 and x.is_cuda:
+        fused = analytic_fused(x, False)
+        if fused is not None:
+            return fused
     X = fft_any(pack_rows(x, n, cplx=True))
     rc = lib().syg_analytic_mask_c64(_ptr(X), B, n, C.c_void_p(_stream_ptr()))
     check(rc, "syg_analytic_mask_c64")

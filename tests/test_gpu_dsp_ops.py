@@ -186,6 +186,33 @@ def test_analytic_and_periodogram_batch_vs_oracle():
                 np.testing.assert_allclose(f, wf, rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("n", [2, 16, 250, 4096, 6000, 8192, 16384, 48000, 65536, 44100])
+def test_fused_analytic_signal_and_envelope(n):
+    """syg_fft_*_strided_ex_f32: real input, analytic weights at the inverse's load, |.| at its store -- the analytic signal
+    and the envelope of the three-pass chain (pack -> mask -> |.|), against the oracle and against the unfused chain; odd
+    and even lengths, one-launch and four-step sizes, powers of two and 7-smooth lengths."""
+    from sygnals_amd import ops
+    from sygnals_amd.core.dsp import envelope_batch
+    rng = np.random.default_rng(n)
+    X = (rng.normal(0, 0.5, (5, n)) + 0.2).astype(np.float32)
+    xd = ops.to_device_f32(X)
+    a = ops.analytic_fused(xd, False)
+    e = ops.analytic_fused(xd, True)
+    assert a is not None and e is not None and a.shape == (5, n, 2) and e.shape == (5, n)
+    chain = ops.fft_any(ops.pack_rows(xd, n, cplx=True))
+    from sygnals_amd._lib import lib, check
+    import ctypes as C
+    check(lib().syg_analytic_mask_c64(ops._ptr(chain), 5, n, C.c_void_p(ops._stream_ptr())), "mask")
+    chain = ops.fft_any(chain, True).cpu().numpy().astype(np.float64)
+    a = a.cpu().numpy().astype(np.float64); e = e.cpu().numpy().astype(np.float64)
+    for b in range(5):
+        want = O.hilbert_transform(X[b].astype(np.float64))
+        assert peak_rel(a[b, :, 0] + 1j * a[b, :, 1], want) <= TOL, n
+        assert peak_rel(e[b], np.abs(want)) <= TOL, n
+        assert peak_rel(a[b, :, 0] + 1j * a[b, :, 1], chain[b, :, 0] + 1j * chain[b, :, 1]) <= 2e-6, n
+    assert np.array_equal(envelope_batch(xd).cpu().numpy(), e.astype(np.float32))
+
+
 # ---------------------------------------------------------------- properties at sizes beyond the direct-sum oracle
 def test_long_convolution_properties():
     """2^20-sample rows against a 4097-tap kernel (four-step FFT of 2^20 complex points):

@@ -111,8 +111,8 @@ if want("f-3 convolution autocorrelation Hilbert periodogram"):
     report("f-3 convolution, 1023-tap shared kernel, mode=same, 1024 clips", lambda: D.convolve_batch(y, kern, "same"), B * L, B * 8 * L)
     report("f-3 autocorrelation (full), 1024 clips", lambda: D.convolve_batch(y, y, "full", correlate=True), B * L, B * (4 * L + 4 * (2 * L - 1)))
     y65 = torch.randn((1024, 65536), dtype=torch.float32, device=y.device)
-    report("f-3 Hilbert envelope, 1024 rows x 65536", lambda: ops.cabs_pow(D.analytic_batch(y65), 1), 1024 * 65536, 1024 * 8 * 65536)
-    report("f-3 Hilbert envelope, 1024 clips x 48000 (mixed radix 200 x 240)", lambda: ops.cabs_pow(D.analytic_batch(y), 1), B * L, B * 8 * L, n=5, warm=2)
+    report("f-3 Hilbert envelope, 1024 rows x 65536", lambda: D.envelope_batch(y65), 1024 * 65536, 1024 * 8 * 65536)
+    report("f-3 Hilbert envelope, 1024 clips x 48000 (mixed radix 200 x 240)", lambda: D.envelope_batch(y), B * L, B * 8 * L, n=5, warm=2)
     report("f-3 periodogram, 1024 clips x 48000 (mixed radix 200 x 240)", lambda: D.periodogram_batch(y, fs=SR), B * L, B * (4 * L + 4 * (L // 2 + 1)), n=5, warm=2)
 out = os.environ.get("ROWS_OUT", "gpurun_out/rows_r03.json")
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
