@@ -237,17 +237,20 @@ int syg_fft_mixed_strided_c2c_f32(const float* in, float* out, int64_t outer, in
  * and dsp.py:565-636 call it, without its three element-wise passes):
  *   flags & 1 (SYG_FFT_REAL_IN)   `in` is a REAL array (same element indexing), imaginary part 0
  *   flags & 2 (SYG_FFT_ABS_OUT)   `out` is a REAL array that receives |result|
+ *   flags & 4 (SYG_FFT_PAIR_IN)   `in` is a REAL array read as the complex sequence (x[2 p], x[2 p + 1]), zero from sample
+ *                                 in_valid on; in_os is then the row stride in floats (the packed real-input transform of
+ *                                 syg_rconv_spectrum_c64's convolutions without a packing pass)
  *   mask_n > 0                    every loaded element is multiplied by the analytic-signal weight of its position p inside
  *                                 the row (the row is a length-mask_n spectrum): 1 at p = 0 and 2 p = mask_n, 2 for
  *                                 2 p < mask_n, 0 above */
 int syg_fft_pow2_strided_ex_f32(const float* in, float* out, int64_t outer, int64_t batch, int n, int inverse,
                                 const float* twiddle, int64_t in_os, int64_t in_bs, int64_t in_es, int64_t out_os,
                                 int64_t out_bs, int64_t out_es, int64_t bign, float scale, int flags, int64_t mask_n,
-                                void* stream);
+                                int64_t in_valid, void* stream);
 int syg_fft_mixed_strided_ex_f32(const float* in, float* out, int64_t outer, int64_t batch, int n, int inverse,
                                  const float* twiddle, int64_t in_os, int64_t in_bs, int64_t in_es, int64_t out_os,
                                  int64_t out_bs, int64_t out_es, int64_t bign, float scale, int flags, int64_t mask_n,
-                                 void* stream);
+                                 int64_t in_valid, void* stream);
 
 /* out[i] = a[i] * b[i mod nb] (complex64; conj_b != 0 multiplies by conj(b)); may be in place. */
 int syg_cmul_c64(const float* a, const float* b, float* out, int64_t na, int64_t nb, int conj_b, void* stream);

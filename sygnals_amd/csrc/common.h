@@ -54,11 +54,23 @@ __device__ __forceinline__ void bfly4(float2 a0, float2 a1, float2 a2, float2 a3
 // Fused ends of the strided transforms (syg_fft_*_strided_ex_f32): a REAL input array (imaginary part 0: no packing pass),
 // the analytic-signal weights of scipy.signal.hilbert applied to the loaded element (its index inside the row is its
 // frequency bin: 1 at 0 and n / 2, 2 below n / 2, 0 above: no masking pass), magnitudes as the output (no |.| pass).
-constexpr int SYG_FFT_REAL_IN = 1, SYG_FFT_ABS_OUT = 2;
-__device__ __forceinline__ float2 fft_load(const float2* __restrict__ in, int64_t idx, int64_t k, int flags, int64_t mask_n) {
-  float2 v = (flags & SYG_FFT_REAL_IN) ? make_float2(reinterpret_cast<const float*>(in)[idx], 0.f) : in[idx];
+constexpr int SYG_FFT_REAL_IN = 1, SYG_FFT_ABS_OUT = 2, SYG_FFT_PAIR_IN = 4;
+// element at position pos of the row that starts at element offset ibase.  PAIR_IN: `in` is a real array whose row (in_valid
+// samples, zero beyond) is read as the complex sequence (x[2 p], x[2 p + 1]) -- the packed form of a real-input transform of
+// twice the length (rfft_conv) without its packing pass; ibase is then the row's offset in FLOATS.
+__device__ __forceinline__ float2 fft_load(const float2* __restrict__ in, int64_t ibase, int64_t pos, int flags, int64_t mask_n,
+                                           int64_t in_valid) {
+  float2 v;
+  if (flags & SYG_FFT_PAIR_IN) {
+    const float* r = reinterpret_cast<const float*>(in) + ibase;
+    v = make_float2(2 * pos < in_valid ? r[2 * pos] : 0.f, 2 * pos + 1 < in_valid ? r[2 * pos + 1] : 0.f);
+  } else if (flags & SYG_FFT_REAL_IN) {
+    v = make_float2(reinterpret_cast<const float*>(in)[ibase + pos], 0.f);
+  } else {
+    v = in[ibase + pos];
+  }
   if (mask_n > 0) {
-    const float h = (k == 0 || 2 * k == mask_n) ? 1.f : (2 * k < mask_n ? 2.f : 0.f);
+    const float h = (pos == 0 || 2 * pos == mask_n) ? 1.f : (2 * pos < mask_n ? 2.f : 0.f);
     v.x *= h; v.y *= h;
   }
   return v;

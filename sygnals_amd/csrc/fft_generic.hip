@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void welch_final2_kernel(const double* __restr
 __global__ void fft_pow2_strided_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n, int inverse,
                                         const float2* __restrict__ tw, int64_t in_os, int64_t in_bs, int64_t in_es,
                                         int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale,
-                                        int flags, int64_t mask_n) {
+                                        int flags, int64_t mask_n, int64_t in_valid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* x = reinterpret_cast<float2*>(lds);
   float2* y = x + n;
@@ -334,7 +334,7 @@ __global__ void fft_pow2_strided_kernel(const float2* __restrict__ in, float2* _
   const int64_t b = blockIdx.x, o = blockIdx.y;
   const int64_t ibase = o * in_os, irow = b * in_bs, obase = o * out_os + b * out_bs;
   for (int i = tid; i < n; i += nt) {
-    float2 v = fft_load(in, ibase + irow + (int64_t)i * in_es, irow + (int64_t)i * in_es, flags, mask_n);
+    float2 v = fft_load(in, ibase, irow + (int64_t)i * in_es, flags, mask_n, in_valid);
     if (inverse) v.y = -v.y;
     x[i] = v;
   }
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(COLS_NT) void fft_cols_kernel(const float2* __restr
                                                            int n, int cb_log, int inverse,
                                                            const float2* __restrict__ tw, int64_t in_os, int64_t in_es,
                                                            int64_t out_os, int64_t out_bs, int64_t out_es,
-                                                           int64_t bign, float scale, int flags, int64_t mask_n) {
+                                                           int64_t bign, float scale, int flags, int64_t mask_n, int64_t in_valid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int CB = 1 << cb_log, LP = n + COLS_PAD;
   float2* x = reinterpret_cast<float2*>(lds);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(COLS_NT) void fft_cols_kernel(const float2* __restr
   for (int idx = tid; idx < total; idx += COLS_NT) {
     const int c = idx & (CB - 1), e = idx >> cb_log;
     const int64_t pos = (int64_t)e * in_es + c0 + c;           // position inside the row (= the bin, for the analytic weights)
-    float2 v = fft_load(in, ibase + pos, pos, flags, mask_n);
+    float2 v = fft_load(in, ibase, pos, flags, mask_n, in_valid);
     if (inverse) v.y = -v.y;
     x[c * LP + e] = v;
   }
@@ -593,13 +593,13 @@ extern "C" int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, 
 extern "C" int syg_fft_pow2_strided_ex_f32(const float* in, float* out, int64_t outer, int64_t batch, int n,
                                             int inverse, const float* twiddle, int64_t in_os, int64_t in_bs,
                                             int64_t in_es, int64_t out_os, int64_t out_bs, int64_t out_es,
-                                            int64_t bign, float scale, int flags, int64_t mask_n, void* stream) {
+                                            int64_t bign, float scale, int flags, int64_t mask_n, int64_t in_valid, void* stream) {
   SYG_REQUIRE(in && out && twiddle, "fft_pow2_strided: null pointer argument");
   SYG_REQUIRE(is_pow2(n) && n <= MAX_N, "fft_pow2_strided: n must be a power of two in [2, %d] (got %d)", MAX_N, n);
   SYG_REQUIRE(batch >= 1 && batch < (int64_t)0x7fffffff && outer >= 1 && outer <= 65535,
               "fft_pow2_strided: bad batch/outer");
   SYG_REQUIRE(in != out, "fft_pow2_strided: in-place operation is not supported");
-  SYG_REQUIRE(flags >= 0 && flags <= 3 && mask_n >= 0, "fft_pow2_strided: bad flags / mask length");
+  SYG_REQUIRE(flags >= 0 && flags <= 7 && (flags & 5) != 5 && mask_n >= 0 && in_valid >= 0, "fft_pow2_strided: bad flags / mask length");
   if (in_bs == 1 && (out_es == 1 || out_bs == 1) && n <= COLS_MAXN && n >= 8) {
     int cb_log = 4;                                            // 16 columns = 128-byte runs
     while (cb_log > 2 && ((int64_t)n << cb_log) > 4096) --cb_log;
@@ -615,11 +615,11 @@ extern "C" int syg_fft_pow2_strided_ex_f32(const float* in, float* out, int64_t 
       if (kfast)
         hipLaunchKernelGGL(fft_cols_kernel<true>, grid, dim3(COLS_NT), lds, (hipStream_t)stream, (const float2*)in,
                            (float2*)out, n, cb_log, inverse, (const float2*)twiddle, in_os, in_es, out_os, out_bs,
-                           out_es, bign, scale, flags, mask_n);
+                           out_es, bign, scale, flags, mask_n, in_valid);
       else
         hipLaunchKernelGGL(fft_cols_kernel<false>, grid, dim3(COLS_NT), lds, (hipStream_t)stream, (const float2*)in,
                            (float2*)out, n, cb_log, inverse, (const float2*)twiddle, in_os, in_es, out_os, out_bs,
-                           out_es, bign, scale, flags, mask_n);
+                           out_es, bign, scale, flags, mask_n, in_valid);
       SYG_CHECK_LAUNCH("fft_pow2_strided(cols)");
       return SYG_OK;
     }
@@ -629,7 +629,7 @@ extern "C" int syg_fft_pow2_strided_ex_f32(const float* in, float* out, int64_t 
   if (rc) return rc;
   hipLaunchKernelGGL(fft_pow2_strided_kernel, dim3((unsigned)batch, (unsigned)outer), dim3(fft_threads(n)), lds,
                      (hipStream_t)stream, (const float2*)in, (float2*)out, n, inverse, (const float2*)twiddle, in_os,
-                     in_bs, in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n);
+                     in_bs, in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n, in_valid);
   SYG_CHECK_LAUNCH("fft_pow2_strided");
   return SYG_OK;
 }
@@ -639,7 +639,7 @@ extern "C" int syg_fft_pow2_strided_c2c_f32(const float* in, float* out, int64_t
                                             int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign, float scale,
                                             void* stream) {
   return syg_fft_pow2_strided_ex_f32(in, out, outer, batch, n, inverse, twiddle, in_os, in_bs, in_es, out_os, out_bs, out_es,
-                                     bign, scale, 0, 0, stream);
+                                     bign, scale, 0, 0, 0, stream);
 }
 
 extern "C" int syg_cmul_c64(const float* a, const float* b, float* out, int64_t na, int64_t nb, int conj_b,

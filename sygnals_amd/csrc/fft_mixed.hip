@@ -111,7 +111,7 @@ __device__ __forceinline__ float2* block_fft_mixed(float2* x, float2* y, int N, 
 __global__ void fft_mixed_strided_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n, Radices rd,
                                          int inverse, const float2* __restrict__ tw, int64_t in_os, int64_t in_bs,
                                          int64_t in_es, int64_t out_os, int64_t out_bs, int64_t out_es, int64_t bign,
-                                         float scale, int flags, int64_t mask_n) {
+                                         float scale, int flags, int64_t mask_n, int64_t in_valid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* x = reinterpret_cast<float2*>(lds);
   float2* y = x + n;
@@ -119,7 +119,7 @@ __global__ void fft_mixed_strided_kernel(const float2* __restrict__ in, float2* 
   const int64_t b = blockIdx.x, o = blockIdx.y;
   const int64_t ibase = o * in_os, irow = b * in_bs, obase = o * out_os + b * out_bs;
   for (int i = tid; i < n; i += nt) {
-    float2 v = fft_load(in, ibase + irow + (int64_t)i * in_es, irow + (int64_t)i * in_es, flags, mask_n);
+    float2 v = fft_load(in, ibase, irow + (int64_t)i * in_es, flags, mask_n, in_valid);
     if (inverse) v.y = -v.y;
     x[i] = v;
   }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(MCOLS_NT) void fft_mixed_cols_kernel(const float2* 
                                                                   const float2* __restrict__ tw, int64_t in_os,
                                                                   int64_t in_es, int64_t out_os, int64_t out_bs,
                                                                   int64_t out_es, int64_t bign, float scale, int flags,
-                                                                  int64_t mask_n) {
+                                                                  int64_t mask_n, int64_t in_valid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int CB = 1 << cb_log, LP = n + MCOLS_PAD;
   float2* x = reinterpret_cast<float2*>(lds);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(MCOLS_NT) void fft_mixed_cols_kernel(const float2* 
   for (int idx = tid; idx < total; idx += MCOLS_NT) {
     const int c = idx & (CB - 1), e = idx >> cb_log;
     const int64_t pos = (int64_t)e * in_es + c0 + c;           // position inside the row (= the bin, for the analytic weights)
-    float2 v = fft_load(in, ibase + pos, pos, flags, mask_n);
+    float2 v = fft_load(in, ibase, pos, flags, mask_n, in_valid);
     if (inverse) v.y = -v.y;
     x[c * LP + e] = v;
   }
@@ -211,12 +211,12 @@ extern "C" int syg_fft_mixed_plan(int64_t n, int32_t* radices_host, int max_pass
 extern "C" int syg_fft_mixed_strided_ex_f32(const float* in, float* out, int64_t outer, int64_t batch, int n,
                                              int inverse, const float* twiddle, int64_t in_os, int64_t in_bs,
                                              int64_t in_es, int64_t out_os, int64_t out_bs, int64_t out_es,
-                                             int64_t bign, float scale, int flags, int64_t mask_n, void* stream) {
+                                             int64_t bign, float scale, int flags, int64_t mask_n, int64_t in_valid, void* stream) {
   SYG_REQUIRE(in && out && twiddle, "fft_mixed: null pointer argument");
   SYG_REQUIRE(n >= 2 && n <= MIX_MAXN, "fft_mixed: n must be in [2, %d] (got %d)", MIX_MAXN, n);
   SYG_REQUIRE(batch >= 1 && batch < (int64_t)0x7fffffff && outer >= 1 && outer <= 65535, "fft_mixed: bad batch/outer");
   SYG_REQUIRE(in != out, "fft_mixed: in-place operation is not supported");
-  SYG_REQUIRE(flags >= 0 && flags <= 3 && mask_n >= 0, "fft_mixed: bad flags / mask length");
+  SYG_REQUIRE(flags >= 0 && flags <= 7 && (flags & 5) != 5 && mask_n >= 0 && in_valid >= 0, "fft_mixed: bad flags / mask length");
   Radices rd;
   int32_t rr[MAXPASS];
   rd.n = syg_fft_mixed_plan(n, rr, MAXPASS);
@@ -240,11 +240,11 @@ extern "C" int syg_fft_mixed_strided_ex_f32(const float* in, float* out, int64_t
       if (kfast)
         hipLaunchKernelGGL(fft_mixed_cols_kernel<true>, grid, dim3(MCOLS_NT), clds, (hipStream_t)stream,
                            (const float2*)in, (float2*)out, n, rd, cb_log, inverse, (const float2*)twiddle, in_os,
-                           in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n);
+                           in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n, in_valid);
       else
         hipLaunchKernelGGL(fft_mixed_cols_kernel<false>, grid, dim3(MCOLS_NT), clds, (hipStream_t)stream,
                            (const float2*)in, (float2*)out, n, rd, cb_log, inverse, (const float2*)twiddle, in_os,
-                           in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n);
+                           in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n, in_valid);
       SYG_CHECK_LAUNCH("fft_mixed(cols)");
       return SYG_OK;
     }
@@ -259,7 +259,7 @@ extern "C" int syg_fft_mixed_strided_ex_f32(const float* in, float* out, int64_t
   nt = nt < 64 ? 64 : (nt > 1024 ? 1024 : ((nt + 63) / 64) * 64);
   hipLaunchKernelGGL(fft_mixed_strided_kernel, dim3((unsigned)batch, (unsigned)outer), dim3(nt), lds,
                      (hipStream_t)stream, (const float2*)in, (float2*)out, n, rd, inverse, (const float2*)twiddle,
-                     in_os, in_bs, in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n);
+                     in_os, in_bs, in_es, out_os, out_bs, out_es, bign, scale, flags, mask_n, in_valid);
   SYG_CHECK_LAUNCH("fft_mixed");
   return SYG_OK;
 }
@@ -269,5 +269,5 @@ extern "C" int syg_fft_mixed_strided_c2c_f32(const float* in, float* out, int64_
                                              int64_t in_es, int64_t out_os, int64_t out_bs, int64_t out_es,
                                              int64_t bign, float scale, void* stream) {
   return syg_fft_mixed_strided_ex_f32(in, out, outer, batch, n, inverse, twiddle, in_os, in_bs, in_es, out_os, out_bs, out_es,
-                                      bign, scale, 0, 0, stream);
+                                      bign, scale, 0, 0, 0, stream);
 }

@@ -1182,21 +1182,59 @@ def rfft_conv(x: torch.Tensor, k: torch.Tensor, reverse_k: bool = False) -> torc
         raise ValueError("k must have one row or one row per row of x")
     M = conv_fft_len(n + m - 1)
     H = M // 2
-    za = fft_any(pack_rows(x, M).view(B, H, 2))
+    za = fft_pair_rows(x, H)
+    if za is None:
+        za = fft_any(pack_rows(x, M).view(B, H, 2))
     zb = fft_any(pack_rows(k, M, reverse=reverse_k).view(Bk, H, 2))
     rc = lib().syg_rconv_spectrum_c64(_ptr(za), _ptr(zb), B, Bk, H, _ptr(za), C.c_void_p(_stream_ptr()))
     check(rc, "syg_rconv_spectrum_c64")
     return fft_any(za, True).view(B, M)[:, : n + m - 1]
 
 
-FFT_REAL_IN, FFT_ABS_OUT = 1, 2
+FFT_REAL_IN, FFT_ABS_OUT, FFT_PAIR_IN = 1, 2, 4
 
 
-def _strided_ex(kind, x, out, outer, batch, n, inverse, strides, bign=0, scale=1.0, flags=0, mask_n=0):
+def _two_kernel_plan(n: int):
+    """(kind, n1, n2) of the one- or two-launch plan of a length-n complex transform, or None (Bluestein lengths)."""
+    if n < 2:
+        return None
+    if is_pow2(n):
+        if n <= MAX_LDS_FFT:
+            return "pow2", n, 1
+        n1 = 1 << ((n.bit_length() - 1) // 2)
+        return ("pow2", n1, n // n1) if n // n1 <= MAX_LDS_FFT else None
+    if _is_smooth(n) and smooth_split(n) is not None:
+        n1, n2 = smooth_split(n)
+        return "mixed", n1, n2
+    return None
+
+
+def fft_pair_rows(x: torch.Tensor, H: int):
+    """Forward transform of length H of the rows of the REAL tensor x [B, n] read as the complex sequences
+    (x[2 p], x[2 p + 1]), zero beyond n -- pack_rows(x, 2 H) folded into the first pass's load.  None without a plan."""
+    B, n = x.shape
+    plan = _two_kernel_plan(H)
+    if plan is None or B > MAX_ROWS or x.dtype != torch.float32 or not x.is_cuda or n > 2 * H:
+        return None
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    kind, n1, n2 = plan
+    ld = x.stride(0)
+    out = torch.empty((B, H, 2), dtype=torch.float32, device=x.device)
+    if n2 == 1:
+        _strided_ex(kind, x, out, B, 1, H, False, (ld, 0, 1, H, 0, 1), flags=FFT_PAIR_IN, in_valid=n)
+        return out
+    tmp = torch.empty_like(out)
+    _strided_ex(kind, x, tmp, B, n2, n1, False, (ld, 1, n2, H, n1, 1), bign=H, flags=FFT_PAIR_IN, in_valid=n)
+    _strided_ex(kind, tmp, out, B, n1, n2, False, (H, 1, n1, H, 1, n1))
+    return out
+
+
+def _strided_ex(kind, x, out, outer, batch, n, inverse, strides, bign=0, scale=1.0, flags=0, mask_n=0, in_valid=0):
     in_os, in_bs, in_es, out_os, out_bs, out_es = strides
     fn = lib().syg_fft_pow2_strided_ex_f32 if kind == "pow2" else lib().syg_fft_mixed_strided_ex_f32
     rc = fn(_ptr(x), _ptr(out), outer, batch, n, int(inverse), _ptr(twiddle_dev(n)), in_os, in_bs, in_es, out_os, out_bs,
-            out_es, bign, float(scale), int(flags), int(mask_n), C.c_void_p(_stream_ptr()))
+            out_es, bign, float(scale), int(flags), int(mask_n), int(in_valid), C.c_void_p(_stream_ptr()))
     check(rc, "syg_fft_%s_strided_ex_f32" % kind)
 
 
@@ -1206,22 +1244,10 @@ def analytic_fused(x: torch.Tensor, magnitude: bool):
     the length has no two-kernel plan (powers of two up to 2^26 and 7-smooth lengths that split into two factors <= 8192;
     other lengths go through Bluestein in analytic_signal)."""
     B, n = x.shape
-    if n < 2 or B > MAX_ROWS:
+    plan = _two_kernel_plan(n)
+    if plan is None or B > MAX_ROWS:
         return None
-    if is_pow2(n):
-        kind = "pow2"
-        if n <= MAX_LDS_FFT:
-            n1, n2 = n, 1
-        else:
-            n1 = 1 << ((n.bit_length() - 1) // 2)
-            n2 = n // n1
-            if n2 > MAX_LDS_FFT:
-                return None
-    elif _is_smooth(n) and smooth_split(n) is not None:
-        kind = "mixed"
-        n1, n2 = smooth_split(n)
-    else:
-        return None
+    kind, n1, n2 = plan
     x = x.contiguous()
     X = torch.empty((B, n, 2), dtype=torch.float32, device=x.device)
     out = torch.empty((B, n) if magnitude else (B, n, 2), dtype=torch.float32, device=x.device)
