@@ -341,7 +341,8 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
         cost = cycles + (0 if short else 4)          # (a fourth scan step costs about as much as two LDS cycles)
         if best is None or cost < best[0]:
             best = (cost, slots, start, lead)
-        if cost == SEG_WINDOW * (SLOTS // 32):
+        ideal = SEG_WINDOW * (SLOTS // 32)
+        if cost == ideal or (trial >= 300 and cost <= ideal + 4):     # (conflict-free with a fourth scan step is as good)
             break
     _, slots, start, lead = best
     run_of = np.array([r for _, r in slots])
