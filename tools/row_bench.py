@@ -90,7 +90,7 @@ if want("a10 complex FFT"):
     report("a10 complex FFT n=6000 (2^4 3 5^3) x 8192 signals", lambda: ops.fft_any(x6k), 8192 * 6000, 2 * 8 * 8192 * 6000, n=10, warm=3)
     del xf, x48, x6k
 # C5: ONE 1-hour stream (172.8 M samples), generated on the device: noise + a slow chirp + tones (tone phases in float64)
-if want("C5 a14 Welch") or want("C5 a15 CQT"):
+if want("C5 a14 Welch") or want("C5 a15 CQT") or want("C5 both"):
     Ls = 48000 * 3600
     g = torch.Generator(device="cuda").manual_seed(5)
     stream = torch.randn(Ls, device="cuda", generator=g, dtype=torch.float32) * 0.05
@@ -104,6 +104,24 @@ if want("C5 a14 Welch") or want("C5 a15 CQT"):
            "input read in its own pass (CQT separate)", n=5, warm=2)
     report("C5 a15 CQT 84 bins hop 512, one 1-hour stream", lambda: ops.cqt(stream, SR), Ls, 4 * Ls + 8 * 84 * (1 + Ls // 512),
            "input read in its own pass (Welch separate)", n=3, warm=1)
+    # C5 as ONE configuration: the same stream through both, Welch on a second HIP stream beside the CQT (the Welch wave
+    # kernel holds two waves per SIMD in 190-245 registers and is bound by vector issue; the CQT's decimation chain waits on
+    # memory and its octave products on the matrix pipe: they share the CUs)
+    if want("C5 both"):
+        side = ops._side_stream(stream.device)
+        def both():
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                w = D.welch_batch(stream, fs=SR, nperseg=4096)
+            c = ops.cqt(stream, SR)
+            main.wait_stream(side)
+            return w, c
+        report("C5 both: Welch on a second stream beside the CQT, one 1-hour stream", both, Ls,
+               4 * Ls + 4 * 2049 + 8 * 84 * (1 + Ls // 512), "the stream is read by both; algorithmic bytes counted once", n=3, warm=1)
+        def serial():
+            return D.welch_batch(stream, fs=SR, nperseg=4096), ops.cqt(stream, SR)
+        report("C5 both, one after the other on one stream", serial, Ls, 4 * Ls + 4 * 2049 + 8 * 84 * (1 + Ls // 512), "", n=3, warm=1)
     del stream
 # f-3: FFT-backed 1-D operations on the 1024-clip batch
 if want("f-3 convolution autocorrelation Hilbert periodogram"):
