@@ -378,3 +378,35 @@ def test_c4_features_one_launch_matches_two_launch_and_oracle(form):
         want = np.stack([ref[f"mfcc_{i}"] for i in range(13)])
         assert_parity(one[b, :13], want, TOL, f"MODE 5 mfcc clip {b}")
         assert_parity(one[b, 13], ref["spectral_centroid"], TOL, f"MODE 5 centroid clip {b}")
+
+
+def test_mfcc_projection_forms_agree_on_random_shapes(ops):
+    """Thirty seeded random calls of the one-launch MFCC: whatever form "auto" picks (segment sums where the filterbank,
+    the hop and the LDS allow it) agrees with the matrix form at the parity gate; degenerate clips included."""
+    rng = np.random.default_rng(77)
+    seg = 0
+    for _ in range(30):
+        sr = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
+        n_mels = int(rng.choice([20, 26, 32, 40, 44]))
+        hop = int(rng.choice([128, 160, 256, 400, 512, 441]))
+        center = bool(rng.random() < 0.8)
+        B = int(rng.integers(1, 40))
+        tmax = 96 if n_mels <= 40 else 80
+        L = int(rng.integers(2048 if not center else 1, hop * (tmax - 2)))
+        n_mfcc = int(rng.integers(1, min(n_mels, 20) + 1))
+        Y = (rng.normal(0, 0.3, (B, L)) * rng.random((B, 1)) ** 3).astype(np.float32)
+        if B > 2:
+            Y[1] = 0.0
+        y = ops.to_device_f32(Y)
+        Tn = ops.num_frames(L, 2048, hop, center)
+        if not ops.mfcc_fused_fits(n_mels, Tn, n_mfcc):
+            continue
+        kw = dict(hop=hop, center=center, n_mels=n_mels, n_mfcc=n_mfcc, lifter=float(rng.choice([0.0, 22.0])),
+                  top_db=(None if rng.random() < 0.2 else 80.0), ref=("max" if rng.random() < 0.7 else 1.0))
+        a, _ = ops.stft2048_mfcc(y, sr, projection="auto", **kw)
+        m, _ = ops.stft2048_mfcc(y, sr, projection="matrix", **kw)
+        assert a.shape == m.shape == (B, n_mfcc, Tn)
+        assert_parity(a.cpu().numpy(), m.cpu().numpy(), TOL, f"sr={sr} n_mels={n_mels} hop={hop} L={L} B={B} {kw}")
+        key = [k for k in ops._mfcc_calls if k[4] == float(sr) and k[8] == n_mels and k[-1] == "auto" and k[2] == L and k[5] == hop]
+        seg += any(ops._mfcc_calls[k].tri for k in key)
+    assert seg >= 8

@@ -391,3 +391,30 @@ def test_mfcc_other_frame_length_long_clip_two_launch(ops):
     want = O.mfcc_batch(Y, sr, n_fft, hop, n_mels, 13)
     for b in range(2):
         assert_parity(got[b], want[b], TOL, "long clip")
+
+
+def test_segment_kernels_random_shapes_against_the_generic_chain(ops):
+    """Forty seeded random shapes (frame length, rate, bands, hop -- also above the frame length --, clip length, center)
+    through the segment-sum mel kernels of the other frame lengths against the generic chain (complex STFT -> |X|^2 ->
+    dense filterbank); shapes whose filterbank has no piece table must say so (None), not fail."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    for _ in range(40):
+        n_fft = int(rng.choice([256, 512, 1024, 4096]))
+        sr = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
+        n_mels = int(rng.choice([20, 26, 40, 48]))
+        hop = int(rng.integers(1, 2 * n_fft)) if rng.random() < 0.3 else int(rng.choice([n_fft // 4, n_fft // 2, n_fft // 8]))
+        center = bool(rng.random() < 0.7)
+        L = int(rng.integers(n_fft if not center else 1, 6 * n_fft))
+        B = int(rng.integers(1, 7))
+        Y = (rng.normal(0, 0.3, (B, L)) * rng.random((B, 1))).astype(np.float32)
+        y = ops.to_device_f32(Y)
+        mel = ops.stft_mel_segments(y, sr, n_fft, hop, center, "hann", None, n_mels, 0.0, None)
+        if mel is None:
+            continue
+        P = ops.cabs_pow(ops.stft_any(y, n_fft, hop, center, "hann"), 2)
+        want = ops.mel_dense(P, ops.mel_config(sr, n_fft, n_mels, 0.0, None).basis).cpu().numpy()
+        assert mel.shape == want.shape, (n_fft, sr, n_mels, hop, center, L)
+        assert_parity(mel.cpu().numpy(), want, TOL, f"n_fft={n_fft} sr={sr} n_mels={n_mels} hop={hop} center={center} L={L}")
+        done += 1
+    assert done >= 15
