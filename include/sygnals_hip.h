@@ -182,7 +182,7 @@ int syg_stft_mel_w1024_seg_f32(const float* y, int64_t B, int64_t L, int64_t ldy
 
 /* The same for frame_length 512 and 256 (256: the reference's short-signal tests): a wave owns four / eight frames per
  * transform and projects its four / eight power rows.  segtab: pack_mel_segments_rows(sr, n_fft, n_mels, fmin, fmax,
- * rows=4, row_words=296 (512) / 160 (256), n_pass=1) (2048 words); twiddle: W_1024^k for k = 0 .. 1023. */
+ * rows=4, row_words=296 (512) / 160 (256), n_pass=1, block=16 (512) / 8 (256)) (2048 words); twiddle: W_1024^k for k = 0 .. 1023. */
 int syg_stft_mel_wseg_small_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
                                 int64_t T, const float* window, const float* twiddle, const float* segtab,
                                 int n_segtab, int n_mels, float* mel_out, void* stream);

@@ -191,7 +191,7 @@ def _distinct_banks(options):
 
 
 def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None, n_pass: int = 2,
-                      row_base: int = 0):
+                      row_base: int = 0, block: int = 16, window: int = None):
     """Piece table of the fused kernel's per-wave mel projection by SEGMENT SUMS (stft_mel.hip, MODE 6).
 
     A triangular filterbank is piecewise linear in the bin index: between two neighbouring band edges e[s], e[s+1]
@@ -210,6 +210,8 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     17 words apart).
 
     n_pass: passes of 64 lanes (2: the frame-length-2048 kernel, 128 lane slots; 4: the frame-length-4096 kernel).
+    block / window: the rows are cut at `block`-bin boundaries (16, or 8 for the frame-length-256 kernel, whose lanes then
+    read windows of 9 words instead of 17: window = block + 1).
     row_base: words in front of bin 0 inside the kernel's row (0: the frame-length-2048 / 4096 kernels; 4 where the first
     piece may be shorter than the window's entry steps and needs room for its lead).
     Returns float32 [n_pass][2][64 lanes][4] (bit patterns for the integers; the kernel keeps the table in LDS and
@@ -225,6 +227,9 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     """
     F = n_fft // 2 + 1
     SLOTS = 64 * int(n_pass)
+    if block not in (8, 16):
+        raise ValueError("block must be 8 or 16")
+    WIN = block + 1 if window is None else int(window)
 
     def rp(k):
         return row_pos(k) + row_base
@@ -238,8 +243,8 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     df = sr / n_fft
     seg = np.searchsorted(e, np.arange(F) * df, side="right") - 1     # e[s] <= f_k < e[s + 1]
     runs = [[] for _ in range(n_mels + 1)]
-    for blk in range((F + 15) // 16):
-        ks = np.arange(blk * 16, min(blk * 16 + 16, F))
+    for blk in range((F + block - 1) // block):
+        ks = np.arange(blk * block, min(blk * block + block, F))
         for s in np.unique(seg[ks]):
             if s < 0 or s > n_mels:
                 continue
@@ -304,7 +309,7 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
     def leads_of(n, q):
         """Leads a piece of n bins at row position q may take: the window holds 17 words, its first SEG_LEAD_MAX words are
         entered by `lead <= i` alone, so the piece must not end before them."""
-        return [ld for ld in range(max(0, SEG_LEAD_MAX - n), min(SEG_LEAD_MAX, SEG_WINDOW - n) + 1) if q - ld >= 0]
+        return [ld for ld in range(max(0, SEG_LEAD_MAX - n), min(SEG_LEAD_MAX, WIN - n) + 1) if q - ld >= 0]
 
     def windows(slots):
         """Leads per group of 32 lanes (one LDS access) so that the windows start in distinct banks where a matching
@@ -326,7 +331,7 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
                 if j not in lanes:
                     start[j] = start[lanes[0]] if lanes else 0
             st = np.unique([start[j] for j in range(32 * g, 32 * g + 32)])
-            cycles += SEG_WINDOW * int(np.bincount(st % 32, minlength=32).max())
+            cycles += WIN * int(np.bincount(st % 32, minlength=32).max())
         return start, lead, cycles
 
     if total > SLOTS:
@@ -341,7 +346,7 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
         cost = cycles + (0 if short else 4)          # (a fourth scan step costs about as much as two LDS cycles)
         if best is None or cost < best[0]:
             best = (cost, slots, start, lead)
-        ideal = SEG_WINDOW * (SLOTS // 32)
+        ideal = WIN * (SLOTS // 32)
         if cost == ideal or (trial >= 300 and cost <= ideal + 4):     # (conflict-free with a fourth scan step is as good)
             break
     _, slots, start, lead = best
@@ -373,13 +378,13 @@ def pack_mel_segments(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fma
 
 
 def pack_mel_segments_rows(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0, fmax=None, basis=None, rows: int = 2,
-                           row_words: int = 568, n_pass: int = 2, row_base: int = 4):
+                           row_words: int = 568, n_pass: int = 2, row_base: int = 4, block: int = 16):
     """Piece table for a wave that projects `rows` power rows of one frame length in ONE call (the frame-length-1024
     kernel: two frames per transform): the single-row table of pack_mel_segments(..., n_pass) repeated per row, the window
     offsets moved by the row's offset (row_words words per row) and the band words tagged with the row (band | row << 8).
     A row's last lane never stores a band (its last run is the segment above the last band), so nothing leaks from one
     row's passes into the next's.  Returns float32 [rows * n_pass][2][64][4]."""
-    one = pack_mel_segments(sr, n_fft, n_mels, fmin, fmax, basis=basis, n_pass=n_pass, row_base=row_base)
+    one = pack_mel_segments(sr, n_fft, n_mels, fmin, fmax, basis=basis, n_pass=n_pass, row_base=row_base, block=block)
     if n_mels > 255 or (rows - 1) * row_words * 4 + 0xFFFF // 8 > 0xFFFF:
         raise ValueError("too many bands / rows for the packed table words")
     out = np.concatenate([one.copy() for _ in range(rows)], axis=0)
@@ -395,7 +400,7 @@ def pack_mel_segments_rows(sr: float, n_fft: int, n_mels: int, fmin: float = 0.0
     return np.ascontiguousarray(out)
 
 
-def segments_read_cycles(tab: np.ndarray) -> int:
+def segments_read_cycles(tab: np.ndarray, window: int = 17) -> int:
     """LDS cycles of one wave's n_pass x 17 window reads (ds_read_b32: the 32 lanes of a half wave share a cycle unless
     two of them address different words of one bank); 34 per pass = conflict-free."""
     ti = tab.view(np.int32)
@@ -403,7 +408,7 @@ def segments_read_cycles(tab: np.ndarray) -> int:
     for p in range(tab.shape[0]):
         for h in range(2):
             st = (ti[p, 0, 32 * h:32 * h + 32, 0] & 0xFFFF) // 4
-            for i in range(17):
+            for i in range(window):
                 total += int(np.bincount(np.unique(st + i) % 32, minlength=32).max())
     return total
 

@@ -43,6 +43,22 @@ __device__ __forceinline__ void tri_piece_sums(const float (&pw)[17], int lead, 
         [p11] "v"(pw[11]), [p12] "v"(pw[12]), [p13] "v"(pw[13]), [p14] "v"(pw[14]), [p15] "v"(pw[15]), [p16] "v"(pw[16])
       : "vcc");
 }
+// the same for a window of 9 words (pieces of <= 8 bins: the frame-length-256 kernel cuts its rows at 8-bin blocks)
+__device__ __forceinline__ void tri_piece_sums(const float (&pw)[9], int lead, int hi, float& c, float& t1) {
+  unsigned long long sv;
+  c = 0.f; t1 = 0.f;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      SYG_TRI_HEAD(0) SYG_TRI_HEAD(1) SYG_TRI_HEAD(2) SYG_TRI_HEAD(3)
+      "s_mov_b64 exec, %[sv]\n\t"
+      SYG_TRI_STEP(4) SYG_TRI_STEP(5) SYG_TRI_STEP(6) SYG_TRI_STEP(7) SYG_TRI_STEP(8)
+      "s_mov_b64 exec, %[sv]\n\t"
+      "s_nop 1"
+      : [c] "+v"(c), [t1] "+v"(t1), [sv] "=&s"(sv)
+      : [lead] "v"(lead), [hi] "v"(hi), [p0] "v"(pw[0]), [p1] "v"(pw[1]), [p2] "v"(pw[2]), [p3] "v"(pw[3]), [p4] "v"(pw[4]),
+        [p5] "v"(pw[5]), [p6] "v"(pw[6]), [p7] "v"(pw[7]), [p8] "v"(pw[8])
+      : "vcc");
+}
 #undef SYG_TRI_STEP
 #undef SYG_TRI_HEAD
 static_assert(TRI_LEAD_MAX == 4, "tri_piece_sums unrolls four entry steps");
@@ -54,10 +70,11 @@ static_assert(TRI_LEAD_MAX == 4, "tri_piece_sums unrolls four entry steps");
 // 144.4 us on one box; both windows read before the first sums: no difference)
 // scan8: some lane of the table has a step-8 link (wave-uniform; the host lays the runs out so that three steps suffice
 // where the filterbank allows it).  NPASS: 2 or 4 passes of 64 lanes.
-template <int NPASS, typename Store>
+template <int NPASS, int W = 17, typename Store>
 __device__ __forceinline__ void tri_project(const float* __restrict__ prow, const float4* __restrict__ segl, int la,
                                             bool scan8, Store&& store) {
   static_assert(NPASS == 2 || NPASS == 4, "passes come in pairs (the scans interleave four chains)");
+  static_assert(W == 17 || W == 9, "window lengths with a tri_piece_sums form");
   float R[NPASS], F[NPASS];
   int band[NPASS];
 #pragma unroll
@@ -72,9 +89,9 @@ __device__ __forceinline__ void tri_project(const float* __restrict__ prow, cons
     for (int p = 0; p < 2; ++p) {
       const unsigned w0 = (unsigned)__float_as_int(qa[p].x);
       const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(prow) + (w0 & 0xFFFFu));
-      float pw[17];
+      float pw[W];
 #pragma unroll
-      for (int i = 0; i < 17; ++i) pw[i] = src[i];
+      for (int i = 0; i < W; ++i) pw[i] = src[i];
       float c, t1;
       tri_piece_sums(pw, (int)(w0 >> 24), (int)((w0 >> 16) & 0xFFu), c, t1);
       R[pp + p] = fmaf(qc[p].y, t1, qc[p].x * c);

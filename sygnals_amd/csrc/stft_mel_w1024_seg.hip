@@ -43,9 +43,10 @@ __global__ __launch_bounds__(S1_WAVES * 64, SYG_S1_WAVES_PER_SIMD) void stft_mel
   if (tid < 64) tw2l[(tid >> 4) * wfft::TW2_STRIDE + (tid & 15)] = tw1024[(16 * (tid >> 4) * (tid & 15)) & 1023];
   for (int i = tid; i < wfft::TW1_COMPLEX; i += S1_WAVES * 64) tw1l[i] = tw1024[(i & 63) * ((i >> 6) + 1)];
   for (int i = tid; i < S1_SEG_WORDS / 4; i += S1_WAVES * 64) segl[i] = segtab[i];
-  float wv[16];
-#pragma unroll
-  for (int a = 0; a < 16; ++a) wv[a] = win[64 * a + lane];
+  // the window sits in LDS, not in 16 registers per lane: with it in registers the kernel spilled, and every reload of a
+  // spilled register waits for ALL outstanding memory operations -- the next pair's samples included
+  float* winl = reinterpret_cast<float*>(segl) + S1_SEG_WORDS;
+  for (int i = tid; i < 1024; i += S1_WAVES * 64) winl[i] = win[i];
   __syncthreads();
   unsigned lk = 0;
   {
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(S1_WAVES * 64, SYG_S1_WAVES_PER_SIMD) void stft_mel
     const int64_t ta = (u - b * pairs_per_clip) * 2;
     float2 v[16];
 #pragma unroll
-    for (int a = 0; a < 16; ++a) v[a] = make_float2(raw[a].x * wv[a], raw[a].y * wv[a]);
+    for (int a = 0; a < 16; ++a) {
+      const float wva = winl[64 * a + lane];
+      v[a] = make_float2(raw[a].x * wva, raw[a].y * wva);
+    }
     if (u + stride < n_pairs) fetch(u + stride);       // the next pair's samples, behind this pair's transform
     float2 zk[2][4], zm[2][4], z512;
     wfft::cfft1024(v, lc, sc, tw1l, tw2l, lane, zk, zm, z512);
@@ -142,7 +146,7 @@ extern "C" int syg_stft_mel_w1024_seg_f32(const float* y, int64_t B, int64_t L, 
   const int pad = center ? 512 : 0;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  const size_t lds = ((size_t)S1_WAVES * S1_SCW + 2 * (wfft::TW2_COMPLEX + wfft::TW1_COMPLEX) + S1_SEG_WORDS) * sizeof(float);
+  const size_t lds = ((size_t)S1_WAVES * S1_SCW + 2 * (wfft::TW2_COMPLEX + wfft::TW1_COMPLEX) + S1_SEG_WORDS + 1024) * sizeof(float);
   int64_t wgs = (n_pairs + S1_WAVES - 1) / S1_WAVES;
   const int64_t cap = (int64_t)cus * 2 * 2;            // two workgroups per CU resident (60 KiB of LDS each), two rounds
   if (wgs > cap) wgs = cap;

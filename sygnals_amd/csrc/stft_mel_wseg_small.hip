@@ -12,19 +12,25 @@ namespace syg {
 namespace {
 #include "mel_segments.h"
 
-constexpr int SS_WAVES = 8;
+constexpr int SS_WAVES = 16;                         // one workgroup per CU (the tables are then in LDS once)
+constexpr int SS_GF = 16;                            // frames per group: a wave transforms 16 / NF groups of NF frames in a row and
+                                                     // stores their band values as runs of 16 frames (64 bytes) per band
 constexpr int SS_BASE = 4;                           // words in front of bin 0 (room for the lead of a short first piece)
 constexpr int SS_SEG_WORDS = 4 * 2 * 64 * 4;         // four rows, one pass each
+constexpr int SS_MAX_MELS = 48;                      // bands of the [band][16 frames] tile a wave keeps in LDS
+constexpr int SS_GP = SS_GF + 1;                     // the tile's row stride (odd: the 40 lanes that hold a frame's bands write 40 banks)
 template <int NF> struct SmallCfg;
-template <> struct SmallCfg<4> { static constexpr int NFFT = 512, ROW = 296, LOGSEQ = 1; static constexpr float SCALE = 0.0625f; };
-template <> struct SmallCfg<8> { static constexpr int NFFT = 256, ROW = 160, LOGSEQ = 2; static constexpr float SCALE = 0.015625f; };
+// WINDOW: row words a lane reads per piece -- 17 (rows cut at 16-bin blocks) or 9 (256: cut at 8-bin blocks, the 129 bins
+// still fit one pass of 64 lanes: half the masked sums per row)
+template <> struct SmallCfg<4> { static constexpr int NFFT = 512, ROW = 296, LOGSEQ = 1, WINDOW = 17; static constexpr float SCALE = 0.0625f; };
+template <> struct SmallCfg<8> { static constexpr int NFFT = 256, ROW = 160, LOGSEQ = 2, WINDOW = 9; static constexpr float SCALE = 0.015625f; };
 
 __device__ __forceinline__ int ss_pos(int k) { return SS_BASE + k + (k >> 4); }      // == _tables.row_pos + row_base
 
 template <int NF>
 __global__ __launch_bounds__(SS_WAVES * 64, 4) void stft_mel_wseg_small_kernel(
-    const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int64_t units_per_clip,
-    int64_t n_units, const float* __restrict__ win, const float2* __restrict__ tw1024,
+    const float* __restrict__ y, int64_t L, int64_t ldy, int hop, int pad, int64_t T, int64_t groups_per_clip,
+    int64_t n_groups, const float* __restrict__ win, const float2* __restrict__ tw1024,
     const float4* __restrict__ segtab, int n_mels, float* __restrict__ mel_out) {
   typedef SmallCfg<NF> CF;
   constexpr int ROW = CF::ROW, NSEQ = NF / 2, SPA = 64 / NSEQ;       // samples of a sequence per 64 elements of z
@@ -38,6 +44,8 @@ __global__ __launch_bounds__(SS_WAVES * 64, 4) void stft_mel_wseg_small_kernel(
   float2* tw2l = reinterpret_cast<float2*>(lds + SS_WAVES * SCW);
   float2* tw1l = tw2l + wfft::TW2_COMPLEX;
   float4* segl = reinterpret_cast<float4*>(tw1l + wfft::TW1_COMPLEX);
+  float* stg0 = reinterpret_cast<float*>(segl) + SS_SEG_WORDS;
+  float* stg = stg0 + w * (SS_MAX_MELS * SS_GP);                                         // this wave's [band][16 frames] tile
   wfft::Lane lc;
   wfft::init_lane(lc, lane);
   if (tid < 64) tw2l[(tid >> 4) * wfft::TW2_STRIDE + (tid & 15)] = tw1024[(16 * (tid >> 4) * (tid & 15)) & 1023];
@@ -45,9 +53,10 @@ __global__ __launch_bounds__(SS_WAVES * 64, 4) void stft_mel_wseg_small_kernel(
   for (int i = tid; i < SS_SEG_WORDS / 4; i += SS_WAVES * 64) segl[i] = segtab[i];
   // element 64 a + lane of z: sequence r = lane % NSEQ = frames (first + 2 r, first + 2 r + 1), sample SPA a + lane / NSEQ
   const int rs = lane & (NSEQ - 1), nl = lane >> CF::LOGSEQ;
-  float wv[16];
-#pragma unroll
-  for (int a = 0; a < 16; ++a) wv[a] = win[SPA * a + nl];
+  // the window sits in LDS, not in 16 registers per lane: with it in registers the kernel spilled (11 registers at NF = 8),
+  // and every reload of a spilled register waits for ALL outstanding memory operations -- the next group's samples included
+  float* winl = stg0 + SS_WAVES * (SS_MAX_MELS * SS_GP);
+  for (int i = tid; i < CF::NFFT; i += SS_WAVES * 64) winl[i] = win[i];
   __syncthreads();
   unsigned lk = 0;
   {
@@ -58,10 +67,9 @@ __global__ __launch_bounds__(SS_WAVES * 64, 4) void stft_mel_wseg_small_kernel(
   const bool scan8 = __builtin_amdgcn_ballot_w64((lk >> 24) != 0) != 0;
 
   float2 raw[16];
-  auto fetch = [&](int64_t u) {
-    const int64_t bq = u / units_per_clip;
+  auto fetch = [&](int64_t bq, int64_t tfirst) {
     const float* yb = y + bq * ldy;
-    const int64_t tfirst = (u - bq * units_per_clip) * NF, tf = tfirst + 2 * rs;
+    const int64_t tf = tfirst + 2 * rs;
     const int64_t sa = tf * (int64_t)hop - pad, sb = sa + hop;
     const int64_t s_first = tfirst * (int64_t)hop - pad;
     int ln = nl;
@@ -78,16 +86,32 @@ __global__ __launch_bounds__(SS_WAVES * 64, 4) void stft_mel_wseg_small_kernel(
       }
     }
   };
+  // this wave's units: the 16 / NF groups of NF frames of frame group g, then of g + stride, ...
+  constexpr int UG = SS_GF / NF;
   const int64_t stride = (int64_t)gridDim.x * SS_WAVES;
-  int64_t u = (int64_t)blockIdx.x * SS_WAVES + w;
-  if (u < n_units) fetch(u);
-  for (; u < n_units; u += stride) {
-    const int64_t b = u / units_per_clip;
-    const int64_t tfirst = (u - b * units_per_clip) * NF;
+  auto unit_of = [&](int64_t g, int uu, int64_t& bq, int64_t& tf) -> bool {
+    if (g >= n_groups) return false;
+    bq = g / groups_per_clip;
+    tf = (g - bq * groups_per_clip) * SS_GF + (int64_t)uu * NF;
+    return tf < T;
+  };
+  int64_t g = (int64_t)blockIdx.x * SS_WAVES + w, b = 0, tfirst = 0;
+  int uu = 0;
+  bool live = unit_of(g, 0, b, tfirst);
+  if (live) fetch(b, tfirst);
+  while (live) {
     float2 v[16];
 #pragma unroll
-    for (int a = 0; a < 16; ++a) v[a] = make_float2(raw[a].x * wv[a], raw[a].y * wv[a]);
-    if (u + stride < n_units) fetch(u + stride);
+    for (int a = 0; a < 16; ++a) {
+      const float wva = winl[SPA * a + nl];
+      v[a] = make_float2(raw[a].x * wva, raw[a].y * wva);
+    }
+    // the next unit's samples are requested before this unit is transformed
+    int64_t g2 = g, b2 = 0, tf2 = 0;
+    int uu2 = uu + 1;
+    bool live2 = (uu2 < UG) && unit_of(g2, uu2, b2, tf2);
+    if (!live2) { g2 = g + stride; uu2 = 0; live2 = unit_of(g2, 0, b2, tf2); }
+    if (live2) fetch(b2, tf2);
     float2 zk[2][4], zm[2][4], z512;
     wfft::cfft1024(v, lc, sc, tw1l, tw2l, lane, zk, zm, z512);
     wave_lds_sync();                                   // the scratch is dead: the rows may be written
@@ -147,15 +171,35 @@ __global__ __launch_bounds__(SS_WAVES * 64, 4) void stft_mel_wseg_small_kernel(
       }
     }
     wave_lds_sync();
-    float* mo = mel_out + (b * n_mels) * T + tfirst;
-    const int left = (int)((T - tfirst < NF) ? T - tfirst : NF);      // frames of this group inside the clip
+    // the band values go through a [band][16 frames] tile of this wave in LDS and leave as runs of 16 consecutive frames per
+    // band (64 bytes): stored one by one from the lanes that hold them -- 40 scattered 4-byte stores per frame -- they cost
+    // 30 % of the kernel at frame length 256 (300 against 208 us without any store; runs of 8 frames: 270)
 #pragma unroll
     for (int h = 0; h < NF / 4; ++h)
-      tri_project<4>(row0 + 4 * h * ROW, segl, lq, scan8, [&](int bw, float val) {
+      tri_project<4, CF::WINDOW>(row0 + 4 * h * ROW, segl, lq, scan8, [&](int bw, float val) {
         const int band = bw & 255, r = 4 * h + (bw >> 8);             // (the host tags the band word with the row)
-        if (r < left) mo[(int64_t)band * T + r] = CF::SCALE * val;
+        stg[band * SS_GP + uu * NF + r] = CF::SCALE * val;
       });
-    wave_lds_sync();                                   // the rows are read: the next transform may use the scratch
+    wave_lds_sync();                                   // the rows are read (and the tile written): the next transform may use the scratch
+    if (g2 != g || !live2) {                           // the frame group is complete: its tile leaves
+      const int64_t t16 = tfirst - (int64_t)uu * NF;
+      float* mo = mel_out + (b * n_mels) * T + t16;
+      const int left = (int)((T - t16 < SS_GF) ? T - t16 : SS_GF);
+      // a FIXED number of unconditional stores (lanes past the tile's bands / the clip's frames repeat the last valid
+      // element: same address, same value): with a conditional store the compiler cannot count the stores behind the
+      // next group's sample loads and waits for every one of them (s_waitcnt vmcnt(0)) before it touches the samples
+      const int mlast = n_mels - 1, rlast = left - 1;
+#pragma unroll
+      for (int q = 0; q < SS_MAX_MELS * SS_GF / 64; ++q) {
+        const int i = 64 * q + lq;
+        int band = i >> 4, r = i & (SS_GF - 1);
+        band = band < mlast ? band : mlast;
+        r = r < rlast ? r : rlast;
+        mo[(int64_t)band * T + r] = stg[band * SS_GP + r];
+      }
+      wave_lds_sync();
+    }
+    g = g2; uu = uu2; b = b2; tfirst = tf2; live = live2;
   }
 }
 
@@ -163,14 +207,15 @@ template <int NF>
 int launch_small(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T, const float* window,
                  const float* twiddle, const float* segtab, int n_mels, float* mel_out, hipStream_t st) {
   typedef SmallCfg<NF> CF;
-  const int64_t upc = (T + NF - 1) / NF, n_units = B * upc;
-  SYG_REQUIRE(n_units < ((int64_t)1 << 40), "stft_mel_wseg_small: too many frames");
+  const int64_t gpc = (T + SS_GF - 1) / SS_GF, n_groups = B * gpc;
+  SYG_REQUIRE(n_groups < ((int64_t)1 << 40), "stft_mel_wseg_small: too many frames");
   const int pad = center ? CF::NFFT / 2 : 0;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  const size_t lds = ((size_t)SS_WAVES * NF * CF::ROW + 2 * (wfft::TW2_COMPLEX + wfft::TW1_COMPLEX) + SS_SEG_WORDS) * sizeof(float);
-  int64_t wgs = (n_units + SS_WAVES - 1) / SS_WAVES;
-  const int64_t cap = (int64_t)cus * 2 * 2;            // two workgroups per CU resident, two rounds
+  const size_t lds = ((size_t)SS_WAVES * NF * CF::ROW + 2 * (wfft::TW2_COMPLEX + wfft::TW1_COMPLEX) + SS_SEG_WORDS +
+                      (size_t)SS_WAVES * SS_MAX_MELS * SS_GP + CF::NFFT) * sizeof(float);
+  int64_t wgs = (n_groups + SS_WAVES - 1) / SS_WAVES;
+  const int64_t cap = (int64_t)cus * 2;                // one workgroup per CU resident (141 / 148 KiB of LDS), two rounds
   if (wgs > cap) wgs = cap;
   auto kern = stft_mel_wseg_small_kernel<NF>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -178,7 +223,7 @@ int launch_small(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int
     set_error("stft_mel_wseg_small: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e));
     return SYG_E_LAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(SS_WAVES * 64), lds, st, y, L, ldy, hop, pad, T, upc, n_units, window,
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(SS_WAVES * 64), lds, st, y, L, ldy, hop, pad, T, gpc, n_groups, window,
                      (const float2*)twiddle, (const float4*)segtab, n_mels, mel_out);
   SYG_CHECK_LAUNCH("stft_mel_wseg_small");
   return SYG_OK;
@@ -191,7 +236,7 @@ using namespace syg;
 
 // n_fft = 512 or 256, power 2: y [B, L] (row stride ldy) -> mel_out [B, n_mels, T].  segtab: the four-row table of
 // sygnals_amd._tables.pack_mel_segments_rows(sr, n_fft, n_mels, fmin, fmax, rows=4, row_words=296 (512) / 160 (256),
-// n_pass=1) (2048 words on the device, 16-byte aligned); window [n_fft]; twiddle: W_1024^k, k = 0 .. 1023.
+// n_pass=1, block=16 (512) / 8 (256)) (2048 words on the device, 16-byte aligned); window [n_fft]; twiddle: W_1024^k, k = 0 .. 1023.
 extern "C" int syg_stft_mel_wseg_small_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center,
                                            int64_t T, const float* window, const float* twiddle, const float* segtab,
                                            int n_segtab, int n_mels, float* mel_out, void* stream) {
@@ -204,7 +249,7 @@ extern "C" int syg_stft_mel_wseg_small_f32(const float* y, int64_t B, int64_t L,
   SYG_REQUIRE(n_segtab == SS_SEG_WORDS, "stft_mel_wseg_small: the piece table has %d words, this library reads %d "
               "(sygnals_amd._tables.pack_mel_segments_rows)", n_segtab, SS_SEG_WORDS);
   SYG_REQUIRE(((uintptr_t)segtab) % 16 == 0, "stft_mel_wseg_small: the piece table must be 16-byte aligned");
-  SYG_REQUIRE(n_mels >= 1 && n_mels <= 255, "stft_mel_wseg_small: n_mels must be in [1, 255]");
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= SS_MAX_MELS, "stft_mel_wseg_small: n_mels must be in [1, %d]", SS_MAX_MELS);
   if (n_fft == 512) return launch_small<4>(y, B, L, ldy, hop, center, T, window, twiddle, segtab, n_mels, mel_out, (hipStream_t)stream);
   return launch_small<8>(y, B, L, ldy, hop, center, T, window, twiddle, segtab, n_mels, mel_out, (hipStream_t)stream);
 }

@@ -268,7 +268,7 @@ _SMALL_ROW_WORDS = {512: 296, 256: 160}
 
 def wsmall_segtab(sr, n_fft, n_mels, fmin=0.0, fmax=None):
     """Four-row piece table of the frame-length-512 / 256 segment-sum kernel for this filterbank on the device, or None."""
-    if n_fft not in _SMALL_ROW_WORDS:
+    if n_fft not in _SMALL_ROW_WORDS or n_mels > 48:        # (the kernel's [band][16 frames] tile holds 48 bands)
         return None
     fmax = sr / 2.0 if fmax is None else fmax
 
@@ -276,7 +276,8 @@ def wsmall_segtab(sr, n_fft, n_mels, fmin=0.0, fmax=None):
         try:
             basis = T.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
             return _dev(T.pack_mel_segments_rows(sr, n_fft, n_mels, fmin, fmax, basis=basis, rows=4,
-                                                 row_words=_SMALL_ROW_WORDS[n_fft], n_pass=1).reshape(-1))
+                                                 row_words=_SMALL_ROW_WORDS[n_fft], n_pass=1,
+                                                 block=(8 if n_fft == 256 else 16)).reshape(-1))
         except ValueError:
             return False
     tab = _cached(("segsmall", float(sr), n_fft, n_mels, float(fmin), float(fmax)), build)

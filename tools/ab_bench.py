@@ -36,6 +36,10 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "c4blk1": lambda: FB(y2, 48000, one_launch="segments"),
       "c4blk5": lambda: FB(y2, 48000, one_launch="matrix"),
       "c4blk2": lambda: FB(y2, 48000, one_launch=False),
+      "mel256seg": lambda: ops.stft_mel_wseg_small(y, 48000, 256, 64, True, "hann", None, 40),
+      "mel512seg": lambda: ops.stft_mel_wseg_small(y, 48000, 512, 128, True, "hann", None, 40),
+      "mel1024seg": lambda: ops.stft_mel_w1024_seg(y, 48000, 256, True, "hann", None, 40),
+      "mel4096seg": lambda: ops.stft_mel_w4096(y, 48000, 1024, True, "hann", None, 40),
       "cqt": lambda: ops.cqt(stream, 48000),
       "fft48k": lambda: ops.fft_any(XC),                      # 1024 x 48000 complex, mixed radix 200 x 240
       "fft64k": lambda: ops.fft_pow2_any(XC),                 # 1024 x 65536 complex, four-step 256 x 256
