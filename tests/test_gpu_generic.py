@@ -418,3 +418,41 @@ def test_segment_kernels_random_shapes_against_the_generic_chain(ops):
         assert_parity(mel.cpu().numpy(), want, TOL, f"n_fft={n_fft} sr={sr} n_mels={n_mels} hop={hop} center={center} L={L}")
         done += 1
     assert done >= 15
+
+
+def test_segment_entry_points_refuse_bad_arguments(ops):
+    """The C entry points of the segment-sum kernels answer bad arguments with an error code and a message, not a launch:
+    a table of the wrong size, a frame count that does not follow from (L, hop, center), too many bands, null pointers."""
+    import ctypes as C
+    from sygnals_amd._lib import lib, SygnalsHipError, check
+    y = ops.to_device_f32(np.zeros((2, 8000), np.float32))
+    st = C.c_void_p(ops._stream_ptr())
+    out = torch.empty((2, 40, 64), dtype=torch.float32, device=y.device)
+    win1k, tw1k = ops.window_dev("hann", 1024, 1024), ops.twiddle_dev(1024)
+    tab1k = ops.w1024_segtab(16000, 40)
+    T1k = ops.num_frames(8000, 1024, 256, True)
+    def call(fn, *a):
+        rc = fn(*a)
+        assert rc != 0
+        with pytest.raises(SygnalsHipError):
+            check(rc, "x")
+    L = lib()
+    call(L.syg_stft_mel_w1024_seg_f32, ops._ptr(y), 2, 8000, 8000, 256, 1, T1k, ops._ptr(win1k), ops._ptr(tw1k), ops._ptr(tab1k),
+         int(tab1k.numel()) - 4, 40, ops._ptr(out), st)                                         # table size
+    call(L.syg_stft_mel_w1024_seg_f32, ops._ptr(y), 2, 8000, 8000, 256, 1, T1k + 1, ops._ptr(win1k), ops._ptr(tw1k), ops._ptr(tab1k),
+         int(tab1k.numel()), 40, ops._ptr(out), st)                                             # frame count
+    call(L.syg_stft_mel_w1024_seg_f32, ops._ptr(y), 2, 8000, 8000, 256, 1, T1k, ops._ptr(win1k), ops._ptr(tw1k), None,
+         int(tab1k.numel()), 40, ops._ptr(out), st)                                             # null table
+    tab256 = ops.wsmall_segtab(16000, 256, 40)
+    win256 = ops.window_dev("hann", 256, 256)
+    T256 = ops.num_frames(8000, 256, 64, True)
+    call(L.syg_stft_mel_wseg_small_f32, ops._ptr(y), 2, 8000, 8000, 128, 64, 1, T256, ops._ptr(win256), ops._ptr(tw1k), ops._ptr(tab256),
+         int(tab256.numel()), 40, ops._ptr(out), st)                                            # frame length
+    call(L.syg_stft_mel_wseg_small_f32, ops._ptr(y), 2, 8000, 8000, 256, 64, 1, T256, ops._ptr(win256), ops._ptr(tw1k), ops._ptr(tab256),
+         int(tab256.numel()), 49, ops._ptr(out), st)                                            # more bands than the tile holds
+    tab4k = ops.w4096_segtab(16000, 40)
+    call(L.syg_stft_mel_w4096_f32, ops._ptr(y), 2, 8000, 8000, 1024, 1, 3, ops._ptr(ops.window_dev("hann", 4096, 4096)),
+         ops._ptr(ops.twiddle_dev(4096)), ops._ptr(tab4k), int(tab4k.numel()), 40, ops._ptr(out), st)      # frame count
+    assert ops.wsmall_segtab(16000, 256, 49) is None and ops.wsmall_segtab(16000, 128, 40) is None
+    with pytest.raises(SygnalsHipError):
+        ops.stft_mel_wseg_small(y, 16000, 256, 64, True, "hann", None, 64)
