@@ -314,3 +314,53 @@ def test_mel_segment_table_refuses_what_it_cannot_hold():
     W2 = W.copy(); W2[7, 200] += 1e-4                      # not triangular any more
     with pytest.raises(ValueError, match="not reproduced"):
         T.pack_mel_segments(48000, 2048, 40, basis=W2)
+
+
+@pytest.mark.parametrize("n_fft,kw,window,row_base", [
+    (1024, dict(rows=2, row_words=568, n_pass=2), 17, 4),                 # stft_mel_w1024_seg.hip: two rows, two passes each
+    (512, dict(rows=4, row_words=296, n_pass=1), 17, 4),                  # stft_mel_wseg_small.hip <4>
+    (256, dict(rows=4, row_words=160, n_pass=1, block=8), 9, 4),          # <8>: 8-bin pieces, 9-word windows
+])
+@pytest.mark.parametrize("sr,n_mels", [(48000, 40), (16000, 40), (22050, 26)])
+def test_mel_segment_row_tables_of_the_other_frame_lengths(n_fft, kw, window, row_base, sr, n_mels):
+    """pack_mel_segments_rows: every row's block stands for the float32 filterbank, its windows stay inside the row and
+    start in distinct banks, the band words carry the row tag, and no row's last lane stores a band."""
+    from sygnals_amd import _tables as T
+    W = T.mel_filterbank(sr, n_fft, n_mels)
+    tab = T.pack_mel_segments_rows(sr, n_fft, n_mels, basis=W, **kw)
+    rows, n_pass = kw["rows"], kw["n_pass"]
+    assert tab.shape == (rows * n_pass, 2, 64, 4)
+    ti = tab.view(np.int32)
+    F = n_fft // 2 + 1
+    rng = np.random.default_rng(n_fft + sr)
+    P = (rng.random(F) ** 6 * 10.0).astype(np.float32)
+    ref = W.astype(np.float64) @ P
+    for r in range(rows):
+        blk = tab[r * n_pass:(r + 1) * n_pass].copy()
+        bi = blk.view(np.int32)
+        bw = bi[:, 0, :, 1]
+        assert ((bw[bw >= 0] >> 8) == r).all()
+        bi[:, 0, :, 1] = np.where(bw >= 0, bw & 255, -1)                    # take the row tag and the row offset back
+        w0 = bi[:, 0, :, 0]
+        bi[:, 0, :, 0] = (w0 & ~0xFFFF) | ((w0 & 0xFFFF) - 4 * r * kw["row_words"])
+        assert np.abs(T.segments_weights(blk, n_mels, F, row_base) - W).max() <= 2e-7 * W.max()
+        got = T.segments_project(blk, P, n_mels, row_base)
+        assert np.abs(got - ref).max() <= 1e-6 * ref.max()
+        nz = ref > 1e-4 * ref.max()      # (a band whose filter is nearly empty -- narrower than a bin -- is right to 1e-7 of the
+        assert (np.abs(got - ref)[nz] / ref[nz]).max() <= 3e-6          # row's scale, not of its own value)
+        live = ((bi[:, 0, :, 0] >> 16) & 0xFF) > 0
+        off = (bi[:, 0, :, 0] & 0xFFFF) // 4
+        assert (off[live] >= 0).all() and (off[live] + window <= kw["row_words"]).all()
+        assert T.segments_read_cycles(blk, window) <= (2 * n_pass + 1) * window      # at most one group with one conflict
+        assert int(ti[(r + 1) * n_pass - 1, 0, 63, 1]) < 0
+
+
+def test_mel_segment_table_four_passes_for_frame_length_4096():
+    from sygnals_amd import _tables as T
+    W = T.mel_filterbank(48000, 4096, 40)
+    tab = T.pack_mel_segments(48000, 4096, 40, basis=W, n_pass=4)
+    assert tab.shape == (4, 2, 64, 4)
+    assert np.abs(T.segments_weights(tab, 40, 2049) - W).max() <= 2e-7 * W.max()
+    assert T.segments_read_cycles(tab) == 4 * 34
+    with pytest.raises(ValueError):
+        T.pack_mel_segments(48000, 4096, 128, n_pass=4)
