@@ -532,7 +532,7 @@ __device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, flo
 
 // k-th order statistic of the powers of bins [lo, lo + n) by a 32-step radix select on the float bit patterns
 // (fallback for long bands / large k)
-__device__ __noinline__ uint32_t row_kth(lds_row prow, int lane, int lo, int n, int kk, bool largest) {
+__device__ __forceinline__ uint32_t row_kth(lds_row prow, int lane, int lo, int n, int kk, bool largest) {
   uint32_t prefix = 0;
   int remaining = kk;
   for (int bit = 31; bit >= 0; --bit) {
