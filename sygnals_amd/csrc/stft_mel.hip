@@ -397,6 +397,9 @@ __device__ __forceinline__ float fpow(float x, float p) {    // x >= 0
 // The row functions stay out of line (inlined, their registers would spill the FFT loop).  Their pointers
 // carry the address space: a generic pointer would turn every row read into a flat_load.
 typedef const __attribute__((address_space(3))) float* lds_row;
+#ifndef SYG_ROWBOTH
+#define SYG_ROWBOTH 1
+#endif
 typedef __attribute__((address_space(1))) float* gptr;
 
 // smask bits: 1 centroid, 2 bandwidth, 4 flatness, 8 rolloff, 16 dominant (only the requested rows are
@@ -409,7 +412,7 @@ __device__ __forceinline__ int stats_row_mask(int smask) {
          ((smask & 4) ? (1 << SYG_STAT_FLATNESS) : 0) | ((smask & 16) ? (1 << SYG_STAT_DOMINANT_BIN) : 0) |
          ((smask & 8) ? (1 << SYG_STAT_ROLLOFF_BIN) | (1 << SYG_STAT_POWER_SUM) | ((smask & 32) ? 0 : (1 << SYG_STAT_ROLLOFF_MARGIN)) : 0);
 }
-__device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
+__device__ __forceinline__ float row_stats_body(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
   float res = 0.f;
 #define SYG_PUT(row, val) res = (lane == (row)) ? (val) : res
   // lane owns the 16 contiguous bins [16 lane, 16 lane + 16) -- 16 consecutive words at 17 lane of the skewed row:
@@ -973,7 +976,7 @@ __device__ __forceinline__ int contrast_narrow_group(lds_row prow, int lane, int
 // argument traffic seven times).  Band r's (peak, valley) tail means come back in lane r of the two result registers;
 // the caller stores them.  The plan (lo, hi, k per band) is read from its LDS copy: one read per array, lane = band.
 typedef const __attribute__((address_space(3))) int* lds_iptr;
-__device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
+__device__ __forceinline__ float2 row_contrast_body(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
   const int n_rows = uni(n_rows_v), may_park = uni(may_park_v);
   const int lb = lane & (SYG_MAX_BANDS - 1);
   const int plo = cpl[lb], phi = cpl[SYG_MAX_BANDS + lb], pk = cpl[2 * SYG_MAX_BANDS + lb];
@@ -987,6 +990,20 @@ __device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr
     rv = (lane == r) ? pv.y : rv;
   }
   return make_float2(rp, rv);
+}
+__device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
+  return row_stats_body(prow, lane, binhz, roll_percent, bw_p, smask);
+}
+__device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
+  return row_contrast_body(prow, lane, cpl, n_rows_v, may_park_v);
+}
+// Statistics AND contrast of one row in one call (the C4 block asks for both: one entry / exit sequence, one wait for
+// the outstanding memory operations, instead of two).  x: the statistics register of row_stats, y / z: peak / valley.
+__device__ __noinline__ float3 row_features(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask,
+                                            lds_iptr cpl, int n_rows_v, int may_park_v) {
+  const float s = row_stats_body(prow, lane, binhz, roll_percent, bw_p, smask);
+  const float2 pv = row_contrast_body(prow, lane, cpl, n_rows_v, may_park_v);
+  return make_float3(s, pv.x, pv.y);
 }
 
 // MODE 3 clip epilogue (a workgroup's chunk is whole clips): power_to_db + DCT-II (+ lifter) from the LDS mel
@@ -1372,9 +1389,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         // issued behind them; statistics first (a wide contrast band parks its lists in the row's low words), the results
         // wait in lanes and are stored behind the last call.
         float sres = 0.f;
-        if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
+        float2 pv = make_float2(0.f, 0.f);
+        if (SYG_ROWBOTH && stats_out != nullptr && contrast_out != nullptr) {
+          const float3 f = row_features((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc, cplan.n_rows,
+                                        cplan.ascending);
+          sres = f.x; pv = make_float2(f.y, f.z);
+        } else {
+          if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
+          if (contrast_out != nullptr) pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
+        }
         if (contrast_out != nullptr) {
-          const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
           if (lane < cplan.n_rows) {
             contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = pv.x;
             contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = pv.y;
@@ -1562,11 +1586,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         if (stats_out != nullptr) sres = wave_sum(prow[17 * lane]);
         if (false) {
 #else
-        if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
+        const bool both = SYG_ROWBOTH && stats_out != nullptr && contrast_out != nullptr;
+        if (both) {
+          const float3 f = row_features((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc, cplan.n_rows,
+                                        cplan.ascending);
+          sres = f.x; pk = f.y; vl = f.z;
+        } else if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
         if (contrast_out != nullptr) {
 #endif
-          const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
-          pk = pv.x; vl = pv.y;
+          if (!both) {
+            const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
+            pk = pv.x; vl = pv.y;
+          }
           if (lane < cplan.n_rows) {
             contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = pk;
             contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = vl;
