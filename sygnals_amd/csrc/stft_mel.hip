@@ -397,6 +397,15 @@ __device__ __forceinline__ float fpow(float x, float p) {    // x >= 0
 // The row functions stay out of line (inlined, their registers would spill the FFT loop).  Their pointers
 // carry the address space: a generic pointer would turn every row read into a flat_load.
 typedef const __attribute__((address_space(3))) float* lds_row;
+#ifndef SYG_R7ABL
+#define SYG_R7ABL 0
+#endif
+#ifndef SYG_SELBITS
+#define SYG_SELBITS 16
+#endif
+#ifndef SYG_SEL2
+#define SYG_SEL2 1
+#endif
 #ifndef SYG_ROWBOTH
 #define SYG_ROWBOTH 1
 #endif
@@ -567,6 +576,27 @@ __device__ __forceinline__ void wave_kth_largest2_u32(uint32_t x, uint32_t y, in
   for (int bit = 31; bit >= LOWBIT; --bit) {
     const uint32_t ca = a | (1u << bit), cb = b | (1u << bit);
     const int na = __popcll(__ballot(x >= ca)), nb = __popcll(__ballot(y >= cb));
+    a = (na >= ks) ? ca : a;
+    b = (nb >= ks) ? cb : b;
+  }
+  tx = a; ty = b;
+}
+
+// The same over TWO values per lane and side (the kk-th largest of the 128 values x1, x2 / y1, y2): a tighter threshold
+// for callers whose lanes hold sorted lists -- the kk-th largest of the lanes' two top values is much closer to the
+// kk-th largest of everything than the kk-th largest lane MAXIMUM is (a lane with two of the top kk values is common,
+// one with three is rare), so that fewer candidates pass it and have to be taken back one by one.
+// x*: non-negative floats as bits (bit 31 clear), y*: complements of such (bit 31 set): the top bit is known.
+template <int LOWBIT>
+__device__ __forceinline__ void wave_kth_largest2x2_u32(uint32_t x1, uint32_t x2, uint32_t y1, uint32_t y2, int kk, uint32_t& tx,
+                                                        uint32_t& ty) {
+  const int ks = __builtin_amdgcn_readfirstlane(kk);
+  uint32_t a = 0, b = 0x80000000u;
+#pragma unroll 5
+  for (int bit = 30; bit >= LOWBIT; --bit) {
+    const uint32_t ca = a | (1u << bit), cb = b | (1u << bit);
+    const int na = __popcll(__ballot(x1 >= ca)) + __popcll(__ballot(x2 >= ca));
+    const int nb = __popcll(__ballot(y1 >= cb)) + __popcll(__ballot(y2 >= cb));
     a = (na >= ks) ? ca : a;
     b = (nb >= ks) ? cb : b;
   }
@@ -822,7 +852,11 @@ __device__ __forceinline__ bool contrast_select(lds_row prow, int lane, int lo, 
               t4 = hp ? v[R - 5] : v[R - 4];
   const float b1 = v[0], b2 = v[1], b3 = v[2], b4 = v[3];
   uint32_t Tu, Bu;
+#if SYG_SEL2
+  wave_kth_largest2x2_u32<SYG_SELBITS>(__float_as_uint(t1), __float_as_uint(t2), ~__float_as_uint(b1), ~__float_as_uint(b2), k, Tu, Bu);
+#else
   wave_kth_largest2_u32<16>(__float_as_uint(t1), ~__float_as_uint(b1), k, Tu, Bu);
+#endif
   const float Th = __uint_as_float(Tu), Tl = __uint_as_float(~Bu);
   if (__ballot(t4 >= Th || b4 <= Tl) != 0) return false;
   int ch = (t1 >= Th ? 1 : 0) + (t2 >= Th ? 1 : 0) + (t3 >= Th ? 1 : 0);
@@ -991,6 +1025,7 @@ __device__ __forceinline__ float2 row_contrast_body(lds_row prow, int lane, lds_
   }
   return make_float2(rp, rv);
 }
+__device__ __noinline__ float row_trivial(lds_row prow, int lane) { return wave_sum(prow[17 * lane]); }
 __device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
   return row_stats_body(prow, lane, binhz, roll_percent, bw_p, smask);
 }
@@ -1390,6 +1425,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         // wait in lanes and are stored behind the last call.
         float sres = 0.f;
         float2 pv = make_float2(0.f, 0.f);
+        // timing ablations (WRONG results): 1 = a trivial inline stand-in, 2 = a trivial out-of-line function
+#if SYG_R7ABL == 1
+        if (true) { sres = wave_sum(prow[17 * lane]); } else
+#elif SYG_R7ABL == 2
+        if (true) { sres = row_trivial((lds_row)prow, lane); } else
+#endif
         if (SYG_ROWBOTH && stats_out != nullptr && contrast_out != nullptr) {
           const float3 f = row_features((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc, cplan.n_rows,
                                         cplan.ascending);

@@ -1,6 +1,6 @@
 """Where the C4 launch (stft2048_kernel<16,2,7>) spends its time beyond the MFCC path: the same launch with parts of the
 row functions left out (statistics only, contrast only, the contrast plan cut to its first bands).
-    python3 tools/c4_breakdown.py [B]            -> microseconds per launch, B clips (default 2048)"""
+    python3 tools/c4_breakdown.py [B [n_cases]]   -> microseconds per launch, B clips (default 2048)"""
 import ctypes as C, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -69,5 +69,6 @@ for nb in range(1, int(full[0])):
 for b in range(int(full[0])):
     cases.append((f"+ contrast, band {b} alone [{full[1 + b]}, {full[1 + MB + b]}) k={full[1 + 2 * MB + b]}", 0, only(b)))
 cases.append(("+ centroid + rolloff + contrast (C4)", 1 | 8 | 32, cut(int(full[0]))))
+if len(sys.argv) > 2: cases = cases[:int(sys.argv[2])]
 for name, sm, plan in cases:
     print(f"{name:64s} {timed(sm, plan):8.1f} us")
