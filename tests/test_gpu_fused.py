@@ -196,17 +196,20 @@ def test_spectral_contrast_matches_oracle(ops, clips):
 
 
 def test_spectral_contrast_tail_selection_cases(ops):
-    """The wide band's tails are taken by selection (k-th largest lane maximum, count, sum, take back the extras) with a
-    fall-back to k extraction rounds when too many values tie at the threshold: clips that drive both ways -- noise (two
-    or three extras), an impulse (flat spectrum: every bin ties), silence, a tone over a noise floor, a step."""
+    """The wide band's tails are taken by selection (k-th largest of the lanes' two top values, count, sum, take back the
+    extras) with a fall-back to k extraction rounds when too many values tie at the threshold or a lane holds more than
+    three candidates: clips that drive both ways -- noise (few extras), an impulse (flat spectrum: every bin ties),
+    silence, a tone over a noise floor, a step, and twelve tones 64 bins apart (bin 278 + 64 r: every peak of the wide
+    band in the registers of the SAME three lanes)."""
     from sygnals_amd import _tables as T
     rng = np.random.default_rng(77)
     L = 48000
     t = np.arange(L) / 48000.0
     imp = np.zeros(L); imp[5 * 512 + 1024] = 1.0
     step = np.zeros(L); step[L // 2:] = 0.5
+    comb = sum((1.0 + 0.05 * r) * np.sin(2 * np.pi * (278 + 64 * r) * 48000.0 / 2048.0 * t + r) for r in range(12)) * 0.05
     K = np.stack([rng.normal(0, 0.3, L), imp, np.zeros(L), np.sin(2 * np.pi * 9000.0 * t) + rng.normal(0, 1e-4, L), step,
-                  rng.normal(0, 1.0, L) * np.linspace(0, 1, L)]).astype(np.float32)
+                  rng.normal(0, 1.0, L) * np.linspace(0, 1, L), comb + rng.normal(0, 1e-3, L)]).astype(np.float32)
     fr = O.fft_frequencies(48000, 2048)
     plan = T.contrast_plan(fr, 48000)
     _, _, pv_dev = ops.stft2048_mel(ops.to_device_f32(K), 48000, n_mels=40, contrast=plan)
