@@ -22,6 +22,8 @@ extern "C" int syg_abi_version(void) { return SYG_ABI_VERSION; }
 extern "C" int syg_build_variant(void) { return 100 + SYG_SOSC_ABL; }      // sosfilt_clip.hip timing ablations
 #elif defined(SYG_TRIX)
 extern "C" int syg_build_variant(void) { return 200 + SYG_TRIX; }          // stft_mel.hip MODE 6 timing experiments
+#elif defined(SYG_R7ABL)
+extern "C" int syg_build_variant(void) { return 300 + SYG_R7ABL; }         // stft_mel.hip MODE 7 row-function stand-ins
 #else
 extern "C" int syg_build_variant(void) { return SYG_ABL; }
 #endif
