@@ -406,6 +406,9 @@ typedef const __attribute__((address_space(3))) float* lds_row;
 #ifndef SYG_SEL2
 #define SYG_SEL2 1
 #endif
+#ifndef SYG_R7SPLIT
+#define SYG_R7SPLIT 1
+#endif
 #ifndef SYG_ROWBOTH
 #define SYG_ROWBOTH 1
 #endif
@@ -1201,8 +1204,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   const int span = (TILE_T - 1) * hop + NFFT;              // samples a tile touches
   auto dma = [&](int64_t tile) {
     const uint32_t cq = clip_of(tile);
+    int ld = lane;
+    asm volatile("" : "+v"(ld));      // (per-lane offsets are formed per refill: hoisted out of the tile loop they were spilled)
     stage_tile<WAVES>(y + (int64_t)cq * ldy, (int)(L * 4), stage, (int)(t0_of(tile, cq) * hop) - pad, span,
-                      dma_wide != 0, w, lane);
+                      dma_wide != 0, w, ld);
   };
   if (LOAD == 2) dma(tile_begin);
 
@@ -1351,11 +1356,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           }
         if (lane == 0) o[512] = x512;
       } else {
+        int dA2 = lc.dA2, dA3 = lc.dA3;
+        // (MODE 7: the four addresses formed from these are summed per frame -- kept across the tile loop they were spilled,
+        // and a spill's reload waits for every outstanding memory operation)
+        if (TRI && ROWFN) asm volatile("" : "+v"(dA2), "+v"(dA3));
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
-            const int off = (u == 0 && d == 2) ? lc.dA2 : (u == 0 && d == 3) ? lc.dA3 : 272 * d;
+            const int off = (u == 0 && d == 2) ? dA2 : (u == 0 && d == 3) ? dA3 : 272 * d;
             prow[lc.pkb[u] + off] = fmaf(xs[u][d].x, xs[u][d].x, xs[u][d].y * xs[u][d].y);
             prow[lc.pmb[u] - off] = fmaf(xm[u][d].x, xm[u][d].x, xm[u][d].y * xm[u][d].y);
           }
@@ -1397,6 +1406,38 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmp, (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES),
                         (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)pend_b, w - (WAVES - tri_idle), lane, tri_idle);
       }
+      // MODE 7: statistics / contrast of this wave's own row.  Out-of-line: the entry of such a function waits for every
+      // outstanding memory operation, so the results wait in lanes of three registers and are stored -- and the stage
+      // refill is issued -- behind the barriers.  Statistics first (a wide contrast band may park its lists in the row's
+      // low words).  WHEN a wave runs them: half of the waves of every SIMD (w & 4) right behind their projection, the
+      // other half behind X2 in front of their next transform -- between two barriers every wave does the same work, but
+      // one half transforms while the other half runs its chains of dependent reductions, instead of all sixteen doing
+      // the same thing at the same time (all behind X2: SYG_R7SPLIT=0; all in front of X1 was the first build, 832 us).
+      float row_sres = 0.f;
+      float2 row_pv = make_float2(0.f, 0.f);
+      const bool row_early = SYG_R7SPLIT && ((w >> 2) & 1);
+      auto row_compute = [&]() {
+        // timing ablations (WRONG results): 1 = a trivial inline stand-in, 2 = a trivial out-of-line function
+#if SYG_R7ABL == 1
+        if (true) { row_sres = wave_sum(prow[17 * lane]); } else
+#elif SYG_R7ABL == 2
+        if (true) { row_sres = row_trivial((lds_row)prow, lane); } else
+#endif
+        if (SYG_ROWBOTH && stats_out != nullptr && contrast_out != nullptr) {
+          const float3 f = row_features((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc, cplan.n_rows,
+                                        cplan.ascending);
+          row_sres = f.x; row_pv = make_float2(f.y, f.z);
+        } else {
+          if (stats_out != nullptr) row_sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
+          if (contrast_out != nullptr) row_pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
+        }
+      };
+      if (ROWFN && mine && row_early) {
+        // (the three result registers wait in the wave's own row, dead until its next transform: live across the fetch of
+        // the next frame they cost three spilled registers)
+        row_compute();
+        prow[lane] = row_sres; prow[64 + lane] = row_pv.x; prow[128 + lane] = row_pv.y;
+      }
       if (clip_done) {
         const float cm = wave_max(cmax);
         cmax = 0.f;
@@ -1418,35 +1459,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         cur ^= 1;
       }
       if (ROWFN && mine) {
-        // MODE 7: statistics / contrast of this wave's own row, BEHIND the barriers (their duration depends on the data:
-        // a wave that is through starts its next transform, as in MODE 1) with the next frame live in callee-saved
-        // registers.  Out-of-line: their entry waits for every outstanding memory operation, so the stage refill is
-        // issued behind them; statistics first (a wide contrast band parks its lists in the row's low words), the results
-        // wait in lanes and are stored behind the last call.
-        float sres = 0.f;
-        float2 pv = make_float2(0.f, 0.f);
-        // timing ablations (WRONG results): 1 = a trivial inline stand-in, 2 = a trivial out-of-line function
-#if SYG_R7ABL == 1
-        if (true) { sres = wave_sum(prow[17 * lane]); } else
-#elif SYG_R7ABL == 2
-        if (true) { sres = row_trivial((lds_row)prow, lane); } else
-#endif
-        if (SYG_ROWBOTH && stats_out != nullptr && contrast_out != nullptr) {
-          const float3 f = row_features((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc, cplan.n_rows,
-                                        cplan.ascending);
-          sres = f.x; pv = make_float2(f.y, f.z);
-        } else {
-          if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
-          if (contrast_out != nullptr) pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
-        }
+        if (!row_early) row_compute();
+        else { row_sres = prow[lane]; row_pv = make_float2(prow[64 + lane], prow[128 + lane]); }
         if (contrast_out != nullptr) {
           if (lane < cplan.n_rows) {
-            contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = pv.x;
-            contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = pv.y;
+            contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = row_pv.x;
+            contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = row_pv.y;
           }
         }
         if (stats_out != nullptr && lane < SYG_NSTAT && ((stats_row_mask(smask) >> lane) & 1))
-          stats_out[(b * SYG_NSTAT + lane) * T + t] = sres;
+          stats_out[(b * SYG_NSTAT + lane) * T + t] = row_sres;
       }
       if (LOAD == 2 && tile + 2 < tile_end) dma(tile + 2);
       SETPRIO(0);
