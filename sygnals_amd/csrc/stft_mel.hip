@@ -406,6 +406,15 @@ typedef const __attribute__((address_space(3))) float* lds_row;
 #ifndef SYG_SEL2
 #define SYG_SEL2 1
 #endif
+#ifndef SYG_P6SPLIT
+#define SYG_P6SPLIT 0      // (experiment, correct, measured without gain: 140.8 vs 140.6 us -- see proj_split below)
+#endif
+#ifndef SYG_R7PRIO
+#define SYG_R7PRIO 3      // issue priority of the row functions of MODE 7 (the transform runs one level below the top)
+#endif
+#ifndef SYG_R7SHIFT
+#define SYG_R7SHIFT 2     // waves w, w + 4, w + 8, w + 12 share a SIMD: two of them early, two late
+#endif
 #ifndef SYG_R7SPLIT
 #define SYG_R7SPLIT 1
 #endif
@@ -1391,7 +1400,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       const bool mine = (t < T);
       const bool clip_done = (t0 + TILE_T >= T);
       float* cmc = clipmel + cur * (n_mels * mf.tp);
-      if (mine) {
+      // MODE 6, WHEN a wave projects (SYG_P6SPLIT=1; off: what pays for the row functions of MODE 7 below does not pay
+      // here, the transform is 80 % of the interval): half of the waves of every SIMD (w & 4) behind the two barriers
+      // instead of in front of them, with their next frame already in registers -- their column of the clip's matrix and their share of its
+      // maximum arrive one barrier interval late (before X1 of the NEXT tile), which the deferred epilogue never sees (it
+      // runs a whole clip later; hence: deferred epilogue only, at least two tiles per clip, a barrier in front of the
+      // epilogue behind the loop).  Between two barriers every wave still transforms one frame and projects one row, but
+      // one half projects (latency-bound LDS reads and scans) while the other half transforms.
+      const bool proj_split = SYG_P6SPLIT && !ROWFN && LOAD == 2 && tri_defer && tiles_per_clip >= 2;
+      const bool proj_late = proj_split && ((w >> 2) & 1);
+      auto project = [&]() {
         int la = lane;
         asm volatile("" : "+v"(la)::"memory");
         wave_lds_sync();
@@ -1401,6 +1419,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
           *reinterpret_cast<float*>(colb + boff) = v;
           asm("v_max_f32_e32 %0, %0, %1" : "+v"(cmax) : "v"(v));
         });
+      };
+      auto publish_max = [&]() {
+        const float cm = wave_max(cmax);
+        cmax = 0.f;
+        if (lane == 0) tri_red[cur * WAVES + w] = cm;
+      };
+      if (mine) {
+        if (!proj_late) project();
       } else if (tri_defer && pend_b >= 0 && SYG_TRIX != 1) {
         float* cmp = clipmel + (cur ^ 1) * (n_mels * mf.tp);
         clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmp, (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES),
@@ -1415,8 +1441,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       // the same thing at the same time (all behind X2: SYG_R7SPLIT=0; all in front of X1 was the first build, 832 us).
       float row_sres = 0.f;
       float2 row_pv = make_float2(0.f, 0.f);
-      const bool row_early = SYG_R7SPLIT && ((w >> 2) & 1);
+      const bool row_early = SYG_R7SPLIT && ((w >> SYG_R7SHIFT) & 1);
       auto row_compute = [&]() {
+        if (SYG_R7PRIO != SYG_TRIPRIO) SETPRIO(SYG_R7PRIO);
         // timing ablations (WRONG results): 1 = a trivial inline stand-in, 2 = a trivial out-of-line function
 #if SYG_R7ABL == 1
         if (true) { row_sres = wave_sum(prow[17 * lane]); } else
@@ -1438,17 +1465,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         row_compute();
         prow[lane] = row_sres; prow[64 + lane] = row_pv.x; prow[128 + lane] = row_pv.y;
       }
-      if (clip_done) {
-        const float cm = wave_max(cmax);
-        cmax = 0.f;
-        if (lane == 0) tri_red[cur * WAVES + w] = cm;
-      }
+      if (clip_done && !proj_late) publish_max();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                  // X1: the clip's columns of this tile are written too
       if (LOAD == 2) {
         have = false;
         if (tile + 1 < tile_end) fetch(tile + 1);
         __syncthreads();                                // X2: every wave holds its next frame
+      }
+      if (proj_late) {
+        if (tile + 2 < tile_end) dma(tile + 2);
+        if (mine) project();
+        if (clip_done) publish_max();
       }
       if (clip_done) {
         // (clip_dct's entry waits for outstanding memory operations, so the refill is issued behind it)
@@ -1470,7 +1498,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         if (stats_out != nullptr && lane < SYG_NSTAT && ((stats_row_mask(smask) >> lane) & 1))
           stats_out[(b * SYG_NSTAT + lane) * T + t] = row_sres;
       }
-      if (LOAD == 2 && tile + 2 < tile_end) dma(tile + 2);
+      if (LOAD == 2 && !proj_late && tile + 2 < tile_end) dma(tile + 2);
       SETPRIO(0);
       continue;
     }
@@ -1685,7 +1713,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     }
   }
   if (TRI) {
-    // (deferred epilogue: the last clip's matrix is complete behind X1 of its last tile)
+    // (deferred epilogue: the last clip's matrix is complete behind X1 of its last tile -- or, with the projections of half
+    // of the waves behind the barriers, behind one more)
+    if (SYG_P6SPLIT && !ROWFN && LOAD == 2 && tri_defer && tiles_per_clip >= 2) __syncthreads();
     if (pend_b >= 0 && w < tri_ndct && SYG_TRIX != 1)
       clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)(clipmel + (cur ^ 1) * (n_mels * mf.tp)),
                       (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES), (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels,
