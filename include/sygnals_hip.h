@@ -161,6 +161,15 @@ int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t 
                                   float bw_p, int stats_mask, float* stats_out, const int32_t* cplan_host,
                                   float* contrast_out, float* mfcc_out, int mfcc_rows_per_clip, void* stream);
 
+/* The per-frame statistics / contrast tail means of syg_stft2048_mel_f32 WITHOUT the mel spectrogram: spectral_centroid /
+ * bandwidth / flatness / rolloff / contrast (manager.py:289-343 -> frequency_domain.py:25-212) only need |X|.  The kernel of
+ * syg_stft2048_features_tri_f32 with nothing projected and no clip epilogue; same stats_mask / stats_out [B, SYG_NSTAT, T] /
+ * cplan_host / contrast_out [B, 2, n_rows, T] as syg_stft2048_mel_f32, results bit-identical to it.  hop <= 512. */
+int syg_stft2048_stats_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                           const float* window, const float* twiddle, float sr, float roll_percent, float bw_p,
+                           int stats_mask, float* stats_out, const int32_t* cplan_host, float* contrast_out,
+                           void* stream);
+
 /* frame_length 4096 (librosa.stft + np.abs(.)**2 + melspectrogram, manager.py:184-187, 198, 219-222): samples in, mel power
  * out, one wave per frame (the 4096-point real transform of syg_welch_f32's wave kernel), the mel projection by segment
  * sums as in syg_stft2048_mfcc_tri_f32 with a FOUR-pass piece table (pack_mel_segments(..., n_pass=4): 2048 words).

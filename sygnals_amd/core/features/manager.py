@@ -145,7 +145,11 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
             if want_contrast:
                 cplan = T.contrast_plan(freqs, sr, cp.get("n_bands", 6), cp.get("fmin", 200.0), cp.get("quantile", 0.02))
             mel = stats = cpv = None
-            if power == 2.0 and ops.fused_mel_ok(sr, frame_length, n_mels if want_mfcc else 16, fmin, fmax):
+            if (not want_mfcc and (want_stats or want_contrast) and frame_length == 2048 and ops.stft2048_stats_fits(hop_length)):
+                # no mel-based feature asked for: transform + row functions, nothing projected (syg_stft2048_stats_f32)
+                stats, cpv = ops.stft2048_stats(yd, sr, hop_length, center, window, 2048, want_stats, roll, bw_p, cplan)
+                t_stft = Tn
+            elif power == 2.0 and ops.fused_mel_ok(sr, frame_length, n_mels if want_mfcc else 16, fmin, fmax):
                 mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
                                                    fmin, fmax, want_stats, roll, bw_p, cplan)
                 t_stft = Tn

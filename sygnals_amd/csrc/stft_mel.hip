@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // pad words of the skewed rows, the row tails and the slack are read against zero weights: they must
     // hold finite values, so the whole buffer (and the slab behind it) is cleared once
     for (int i = tid; i < LM::P_FLOATS + LM::SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
-    if (TRI) {
+    if (TRI && wpacked != nullptr) {                    // (no table: statistics only, nothing is projected)
       for (int i = tid; i < SEGTAB_WORDS; i += NTHREADS) {
         // (word 1 of a lane's first 16 bytes: the band it stores -> that band's byte offset inside a mel matrix)
         int v = reinterpret_cast<const int*>(wpacked)[i];
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   // MODE 6: output tiles of the clip epilogue; waves without a frame in a clip's last tile; whether those waves take the
   // epilogue of the clip before (at most three output tiles each: it must stay shorter than a transform)
   bool tri_scan8 = false;
-  if (TRI) {
+  if (TRI && wpacked != nullptr) {
     const unsigned lk = (unsigned)(cpl[4 * lane + 2] | cpl[4 * lane + 3] | cpl[4 * (128 + lane) + 2] | cpl[4 * (128 + lane) + 3]);
     tri_scan8 = __builtin_amdgcn_ballot_w64((lk >> 24) != 0) != 0;
   }
@@ -1425,8 +1425,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         cmax = 0.f;
         if (lane == 0) tri_red[cur * WAVES + w] = cm;
       };
+      const bool tri_proj = wpacked != nullptr;
       if (mine) {
-        if (!proj_late) project();
+        if (!proj_late && tri_proj) project();
       } else if (tri_defer && pend_b >= 0 && SYG_TRIX != 1) {
         float* cmp = clipmel + (cur ^ 1) * (n_mels * mf.tp);
         clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmp, (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES),
@@ -1475,12 +1476,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       }
       if (proj_late) {
         if (tile + 2 < tile_end) dma(tile + 2);
-        if (mine) project();
+        if (mine && tri_proj) project();
         if (clip_done) publish_max();
       }
       if (clip_done) {
         // (clip_dct's entry waits for outstanding memory operations, so the refill is issued behind it)
-        if (tri_defer) pend_b = b;
+        if (tri_defer) pend_b = mf.n_mfcc > 0 ? (int64_t)b : pend_b;
         else if (w < tri_ndct && SYG_TRIX != 1)
           clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmc, (int)(uintptr_t)(lds_fptr)(tri_red + cur * WAVES),
                           (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)b, w, lane);
@@ -2018,6 +2019,33 @@ extern "C" int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t 
   return launch<16, 7>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, nullptr,
                        sr / (float)NFFT, roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr,
                        (hipStream_t)stream, mf);
+}
+
+// MODE 7 without a filterbank: the per-frame statistics / contrast tail means alone (spectral_centroid / bandwidth /
+// flatness / rolloff / contrast of manager.py:289-343 need no mel spectrogram) -- transform + row functions, nothing is
+// projected, no clip epilogue; the waves only meet at the two stage hand-over barriers and run their row functions in two
+// staggered halves (see MODE 7).  hop <= 512 (staged tiles); other hops: syg_stft2048_mel_f32.
+extern "C" int syg_stft2048_stats_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                                      const float* window, const float* twiddle, float sr, float roll_percent, float bw_p,
+                                      int stats_mask, float* stats_out, const int32_t* cplan_host, float* contrast_out,
+                                      void* stream) {
+  SYG_REQUIRE(stats_out || contrast_out, "stft2048_stats: no statistics requested");
+  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
+  if (rc) return rc;
+  SYG_REQUIRE(hop <= 512 && L < ((int64_t)1 << 28), "stft2048_stats: needs hop <= 512 (staged tiles); use syg_stft2048_mel_f32");
+  SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_stats: clip too long");
+  ContrastPlan cp;
+  rc = parse_contrast_plan(contrast_out, cplan_host, cp);
+  if (rc) return rc;
+  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && (stats_mask & 31) != 0 &&
+                                 stats_mask > 0 && stats_mask < 64, "stft2048_stats: invalid statistics parameters");
+  MelPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  MfccArgs mf;
+  memset(&mf, 0, sizeof(mf));
+  mf.amin = 1e-10f; mf.top_db = -1.f;
+  return launch<16, 7>(2, y, B, L, ldy, hop, center, T, window, twiddle, nullptr, plan, 0, nullptr, sr / (float)NFFT,
+                       roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr, (hipStream_t)stream, mf);
 }
 
 // MODE 5: the statistics / contrast rows of syg_stft2048_mel_f32 AND the clip-resident MFCC of syg_stft2048_mfcc_f32

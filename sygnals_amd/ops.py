@@ -382,6 +382,45 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
     return mel, stats, cpv
 
 
+def stft2048_stats_fits(hop: int) -> bool:
+    """Whether stft2048_stats takes this call (staged tiles: hop <= 512; the 16-wave kernel)."""
+    return hop <= 512 and fused_waves() == 16
+
+
+def stft2048_stats(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann", win_length: int = 2048,
+                   want_stats=True, roll_percent: float = 0.85, bw_p: float = 2.0, contrast: Optional[np.ndarray] = None):
+    """The statistics / contrast rows of stft2048_mel WITHOUT the mel spectrogram (syg_stft2048_stats_f32: transform + row
+    functions, nothing projected) -- what spectral_centroid / bandwidth / flatness / rolloff / contrast need
+    (manager.py:289-343).  Returns (stats [B, 8, T] | None, contrast_pv [B, 2, R, T] | None), bit-identical to
+    stft2048_mel's."""
+    smask = 31 if want_stats is True else int(want_stats or 0)
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if not smask and contrast is None:
+        raise ValueError("stft2048_stats: nothing requested (want_stats and contrast are both empty)")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    B, L = y.shape
+    Tn = num_frames(L, 2048, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    win = window_dev(window, win_length, 2048)
+    tw = twiddle_dev(2048)
+    stats = torch.zeros((B, 8, Tn), dtype=torch.float32, device=y.device) if smask else None
+    cpv = None
+    cplan_p = None
+    if contrast is not None:
+        cplan = np.ascontiguousarray(contrast, dtype=np.int32)
+        cpv = torch.empty((B, 2, int(cplan[0]), Tn), dtype=torch.float32, device=y.device)
+        cplan_p = cplan.ctypes.data_as(C.c_void_p)
+    rc = lib().syg_stft2048_stats_f32(_ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw), float(sr),
+                                      float(roll_percent), float(bw_p), smask or 1, _ptr(stats), cplan_p, _ptr(cpv),
+                                      C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft2048_stats_f32")
+    return stats, cpv
+
+
 def stft2048_c2c(y: torch.Tensor, hop: int = 512, center: bool = True, window="hann", win_length: int = 2048):
     """Complex STFT, frame-major [B, T, 1025, 2] float32."""
     require_gpu()

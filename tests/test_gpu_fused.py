@@ -195,6 +195,40 @@ def test_spectral_contrast_matches_oracle(ops, clips):
     assert unsure <= 0.10 * cells           # (measured: 5 %; a gate that excluded most cells would prove nothing)
 
 
+@pytest.mark.parametrize("hop,center,L", [(512, True, 48000), (256, True, 20000), (441, False, 30011), (512, True, 2047)])
+def test_stats_without_mel_is_bit_identical(ops, hop, center, L):
+    """syg_stft2048_stats_f32 (transform + row functions, nothing projected) returns the statistics rows and the contrast
+    tail means of syg_stft2048_mel_f32 bit for bit: same transform, same rows, same row functions.  Ragged clip lengths,
+    a hop that leaves waves without a frame, an all-zero clip; every mask the callers use."""
+    from sygnals_amd import _tables as T
+    rng = np.random.default_rng(5)
+    Y = (rng.normal(0, 0.2, (37, L)) * rng.random((37, 1))).astype(np.float32)
+    Y[3] = 0.0
+    y = ops.to_device_f32(Y)
+    plan = T.contrast_plan(O.fft_frequencies(48000, 2048), 48000)
+    for mask, cp in ((31, None), (1 | 8, plan), (0, plan), (4, None), (1 | 8 | 32, plan)):
+        _, st_ref, pv_ref = ops.stft2048_mel(y, 48000, hop, center, n_mels=40, want_stats=mask, contrast=cp)
+        st, pv = ops.stft2048_stats(y, 48000, hop, center, want_stats=mask, contrast=cp)
+        if mask:
+            assert torch.equal(st, st_ref), f"statistics rows differ (mask {mask})"
+        else:
+            assert st is None
+        if cp is not None:
+            assert torch.equal(pv, pv_ref), f"contrast tail means differ (mask {mask})"
+        else:
+            assert pv is None
+    with pytest.raises(ValueError):
+        ops.stft2048_stats(y, 48000, hop, center, want_stats=0, contrast=None)
+
+
+def test_stats_without_mel_bad_arguments(ops):
+    """The C entry refuses what it cannot run (hop > 512: not staged) with an error code, not a launch."""
+    from sygnals_amd._lib import SygnalsHipError
+    y = ops.to_device_f32(np.zeros((2, 48000), np.float32))
+    with pytest.raises(SygnalsHipError):
+        ops.stft2048_stats(y, 48000, 1024, True, want_stats=1)
+
+
 def test_spectral_contrast_tail_selection_cases(ops):
     """The wide band's tails are taken by selection (k-th largest of the lanes' two top values, count, sum, take back the
     extras) with a fall-back to k extraction rounds when too many values tie at the threshold or a lane holds more than

@@ -44,6 +44,7 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "fft48k": lambda: ops.fft_any(XC),                      # 1024 x 48000 complex, mixed radix 200 x 240
       "fft64k": lambda: ops.fft_pow2_any(XC),                 # 1024 x 65536 complex, four-step 256 x 256
       "stats5": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=31),       # the a6-a9 row: all five statistics + mel (MODE 1)
+      "stats5only": lambda: ops.stft2048_stats(y, 48000, want_stats=31),           # the same rows without the mel spectrogram
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
 for _ in range(400 if what != "cqt" and not what.startswith("fft") else 20): fn()
 torch.cuda.synchronize()

@@ -79,6 +79,7 @@ if want("C4 share"):
     report("C4 share: MFCC + centroid + rolloff + contrast -> [2048, 22, 94] block", lambda: feature_block(y4, SR), 2048 * L, 2048 * (4 * L + 4 * 22 * Tn))
     del y4
 report("a6-a9 all five spectral statistics + mel, 1024 clips", lambda: ops.stft2048_mel(y, SR, n_mels=40, want_stats=31), B * L, B * (4 * L + 4 * (40 + 5) * Tn))
+report("a6-a9 all five spectral statistics, no mel (syg_stft2048_stats_f32), 1024 clips", lambda: ops.stft2048_stats(y, SR, want_stats=31), B * L, B * (4 * L + 4 * 5 * Tn))
 report("f-1 time-domain frame features (9 rows), 1024 clips", lambda: ops.frame_stats(y, 2048, 512, True), B * L, B * (4 * L + 4 * 9 * Tn))
 # a10: batched FFT
 if want("a10 complex FFT"):
