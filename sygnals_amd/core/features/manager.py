@@ -145,7 +145,25 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
             if want_contrast:
                 cplan = T.contrast_plan(freqs, sr, cp.get("n_bands", 6), cp.get("fmin", 200.0), cp.get("quantile", 0.02))
             mel = stats = cpv = None
-            if (not want_mfcc and (want_stats or want_contrast) and frame_length == 2048 and ops.stft2048_stats_fits(hop_length)):
+            n_mfcc, lifter = int(mp.get("n_mfcc", 13)), float(mp.get("lifter", 0.0))
+            # the MFCC rows straight from the fused launch (the clip's mel matrix stays in LDS) when the request is the
+            # default cepstrum (DCT-II ortho on the power mel spectrogram) -- mfcc is the only mel-based feature here
+            # (SYGNALS_AMD_ONE_LAUNCH_FEATURES=0: the mel launch + logmel_dct, for comparisons)
+            import os
+            std_mfcc = (want_mfcc and frame_length == 2048 and power == 2.0 and mp.get("dct_type", 2) == 2 and
+                        mp.get("norm", "ortho") == "ortho" and 1 <= n_mfcc <= n_mels and ops.fused_waves() == 16 and
+                        os.environ.get("SYGNALS_AMD_ONE_LAUNCH_FEATURES", "1") != "0")
+            one = None
+            if std_mfcc and (want_stats or want_contrast) and lifter == 0.0:
+                one = features_one_launch(yd, sr, hop_length, center, window, n_mels, fmin, fmax, n_mfcc, want_stats, roll, bw_p, cplan)
+            if one is not None:
+                cache["mfcc_dev"], stats, cpv = one
+                t_stft = Tn
+            elif (std_mfcc and not (want_stats or want_contrast) and ops.fused_mel_ok(sr, 2048, n_mels, fmin, fmax)
+                  and ops.mfcc_fused_fits(n_mels, Tn, n_mfcc)):
+                cache["mfcc_dev"] = ops.stft2048_mfcc(yd, sr, hop_length, center, window, n_mels, n_mfcc, fmin, fmax, lifter)[0]
+                t_stft = Tn
+            elif (not want_mfcc and (want_stats or want_contrast) and frame_length == 2048 and ops.stft2048_stats_fits(hop_length)):
                 # no mel-based feature asked for: transform + row functions, nothing projected (syg_stft2048_stats_f32)
                 stats, cpv = ops.stft2048_stats(yd, sr, hop_length, center, window, 2048, want_stats, roll, bw_p, cplan)
                 t_stft = Tn
@@ -250,8 +268,11 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 items.append(("contrast_delta", host(cdb[:, R - 1])))
             elif name == "mfcc":
                 mel, _, _, cur_T = stft_products()
-                _, mf = ops.logmel_dct(mel, mp.get("n_mfcc", 13), mp.get("dct_type", 2), mp.get("norm", "ortho"),
-                                       float(mp.get("lifter", 0.0)), ref="max", keep_mel=True)
+                if "mfcc_dev" in cache:
+                    mf = cache["mfcc_dev"]
+                else:
+                    _, mf = ops.logmel_dct(mel, mp.get("n_mfcc", 13), mp.get("dct_type", 2), mp.get("norm", "ortho"),
+                                           float(mp.get("lifter", 0.0)), ref="max", keep_mel=True)
                 for i in range(mf.shape[1]):
                     items.append((f"mfcc_{i}", host(mf[:, i])))
             for nm, arr in items:
@@ -307,6 +328,39 @@ def extract_features(y, sr: int, features: List[str], frame_length: int = 2048, 
     df = pd.DataFrame(final, index=idx)
     df.index.name = "time"
     return df
+
+
+def features_one_launch(y, sr, hop_length, center, window, n_mels, fmin, fmax, n_mfcc, smask, roll_percent, bw_p, cplan):
+    """MFCC rows + statistics rows + contrast tail means of [B, L] device clips from ONE launch
+    (syg_stft2048_features_tri_f32: frame_length 2048, power 2, DCT-II ortho, no lifter, ref = max, top_db 80 -- the
+    defaults of manager.py:219-227 / cepstral.py:20-120), or None when the shape has no segment-sum form (the caller then
+    takes the mel launch).  Returns (mfcc [B, n_mfcc, T], stats [B, 8, T] | None, contrast_pv [B, 2, R, T] | None)."""
+    import ctypes as C
+    from ..._lib import check, lib
+    B, L = y.shape
+    Tn = ops.num_frames(L, 2048, hop_length, center)
+    if not (hop_length <= 512 and ops.fused_waves() == 16 and 1 <= n_mfcc <= n_mels <= 127 and (smask or cplan is not None)):
+        return None
+    cfg = ops.mel_config(sr, 2048, n_mels, fmin, fmax, waves=16)
+    if cfg.segtab is None or not lib().syg_stft2048_mfcc_tri_fits(int(n_mels), int(Tn), int(n_mfcc)):
+        return None
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    mf = torch.empty((B, n_mfcc, Tn), dtype=torch.float32, device=y.device)
+    stats = torch.zeros((B, 8, Tn), dtype=torch.float32, device=y.device) if smask else None
+    cpv = cph = None
+    if cplan is not None:
+        cph = np.ascontiguousarray(cplan, np.int32)
+        cpv = torch.empty((B, 2, int(cph[0]), Tn), dtype=torch.float32, device=y.device)
+    dct = ops._cached(("dct", n_mfcc, n_mels, 2, "ortho"), lambda: ops._dev(T.dct_matrix(n_mfcc, n_mels, 2, "ortho")))
+    rc = lib().syg_stft2048_features_tri_f32(
+        ops._ptr(y), B, L, y.stride(0), hop_length, int(center), Tn, ops._ptr(ops.window_dev(window, 2048, 2048)),
+        ops._ptr(ops.twiddle_dev(2048)), ops._ptr(cfg.segtab), int(cfg.segtab.numel()), n_mels, ops._ptr(dct), n_mfcc, None,
+        1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), float(bw_p), (smask | 32) if smask else 1, ops._ptr(stats),
+        cph.ctypes.data_as(C.c_void_p) if cph is not None else None, ops._ptr(cpv), ops._ptr(mf), n_mfcc,
+        C.c_void_p(ops._stream_ptr()))
+    check(rc, "syg_stft2048_features_tri_f32")
+    return mf, stats, cpv
 
 
 # ------------------------------------------------------------------ config C4: the packed per-clip feature block

@@ -554,10 +554,20 @@ def test_c4_feature_block_equals_the_manager_columns():
         [f"contrast_band_{i}" for i in range(6)] + ["contrast_delta"]
     blk2 = feature_block(ops.to_device_f32(Y), 48000, one_launch=False).cpu().numpy()      # mel -> feature_block form
     for r, k in enumerate(names):
-        assert np.array_equal(blk2[:, r].astype(np.float64), d[k]), k
+        # the manager takes the same one-launch kernel as the block (syg_stft2048_features_tri_f32): the same bits
+        assert np.array_equal(blk[:, r].astype(np.float64), d[k]), k
         if r < 13:
-            # the one-launch form converts to dB with the hardware log2 (like syg_stft2048_mfcc_f32): same values within
-            # a fifth of the parity gate, not the same bits
-            assert peak_rel(blk[:, r].astype(np.float64), d[k]) <= 2e-6, k
+            # the one-launch form converts to dB with the hardware log2 (like syg_stft2048_mfcc_f32), the two-launch form
+            # with log10f: same values within a fifth of the parity gate, not the same bits
+            assert peak_rel(blk2[:, r].astype(np.float64), d[k]) <= 2e-6, k
         else:
-            assert np.array_equal(blk[:, r].astype(np.float64), d[k]), k
+            assert np.array_equal(blk2[:, r].astype(np.float64), d[k]), k
+    # ... and with the one-launch forms switched off the manager's columns are the two-launch block's, bit for bit
+    import os
+    os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"] = "0"
+    try:
+        d2 = extract_features_batch(Y, 48000, feats, feature_params={"mfcc": {"n_mels": 40}})
+    finally:
+        del os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"]
+    for r, k in enumerate(names):
+        assert np.array_equal(blk2[:, r].astype(np.float64), d2[k]), k

@@ -19,7 +19,7 @@ what = sys.argv[1]
 B = 1024
 Y = synth_clips(64, 48000, 48000, seed=1); y = ops.to_device_f32(np.tile(Y, (B // 64, 1)))
 CP = T.contrast_plan(np.fft.rfftfreq(2048, 1 / 48000), 48000)
-from sygnals_amd.core.features.manager import feature_block as FB
+from sygnals_amd.core.features.manager import feature_block as FB, extract_features_batch as EFB
 stream = None
 if what == "cqt":
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -45,6 +45,8 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "fft64k": lambda: ops.fft_pow2_any(XC),                 # 1024 x 65536 complex, four-step 256 x 256
       "stats5": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=31),       # the a6-a9 row: all five statistics + mel (MODE 1)
       "stats5only": lambda: ops.stft2048_stats(y, 48000, want_stats=31),           # the same rows without the mel spectrogram
+      "efb_c4": lambda: EFB(y, 48000, ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"], feature_params={"mfcc": {"n_mels": 40}}, to_host=False),   # the reference-API path of C4's features, 1024 clips
+      "efb_mfcc": lambda: EFB(y, 48000, ["mfcc"], feature_params={"mfcc": {"n_mels": 40}}, to_host=False),
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
 for _ in range(400 if what != "cqt" and not what.startswith("fft") else 20): fn()
 torch.cuda.synchronize()
