@@ -21,6 +21,8 @@ Y = synth_clips(64, 48000, 48000, seed=1); y = ops.to_device_f32(np.tile(Y, (B /
 CP = T.contrast_plan(np.fft.rfftfreq(2048, 1 / 48000), 48000)
 from sygnals_amd.core.features.manager import feature_block as FB, extract_features_batch as EFB
 stream = None
+from sygnals_amd.core import filters as FL
+SOS = FL.design_butterworth_sos((300.0, 3400.0), 48000, 4, "bandpass")
 if what == "cqt":
     g = torch.Generator(device="cuda").manual_seed(5)
     stream = (torch.randn(48000 * 3600, device="cuda", generator=g, dtype=torch.float32) * 0.05).reshape(1, -1)
@@ -47,6 +49,7 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "stats5only": lambda: ops.stft2048_stats(y, 48000, want_stats=31),           # the same rows without the mel spectrogram
       "efb_c4": lambda: EFB(y, 48000, ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"], feature_params={"mfcc": {"n_mels": 40}}, to_host=False),   # the reference-API path of C4's features, 1024 clips
       "efb_mfcc": lambda: EFB(y, 48000, ["mfcc"], feature_params={"mfcc": {"n_mels": 40}}, to_host=False),
+      "sos": lambda: FL.apply_sos_filter_batch(SOS, y),                               # C3's filter alone, 1024 clips
       "c4": lambda: ops.stft2048_mel(y, 48000, n_mels=40, want_stats=9, contrast=CP)}[what]
 for _ in range(400 if what != "cqt" and not what.startswith("fft") else 20): fn()
 torch.cuda.synchronize()
