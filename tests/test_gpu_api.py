@@ -571,3 +571,40 @@ def test_c4_feature_block_equals_the_manager_columns():
         del os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"]
     for r, k in enumerate(names):
         assert np.array_equal(blk2[:, r].astype(np.float64), d2[k]), k
+
+
+@pytest.mark.parametrize("hop,center,window,n_mels,feats", [
+    (512, True, "hann", 40, ["mfcc", "spectral_centroid", "spectral_bandwidth", "spectral_flatness", "dominant_frequency"]),
+    (256, False, "hamming", 32, ["spectral_contrast", "mfcc"]),
+    (512, True, "hann", 128, ["mfcc", "spectral_rolloff"]),          # no segment-sum form at 128 bands: the mel launch
+    (1024, True, "hann", 40, ["mfcc", "spectral_centroid"]),         # hop > 512: the mel launch
+    (512, True, "hann", 40, ["mfcc"]),
+    (441, True, "blackman", 26, ["spectral_centroid", "spectral_rolloff", "spectral_contrast"]),   # no mel-based feature
+])
+def test_manager_one_launch_routes_match_the_mel_route(hop, center, window, n_mels, feats):
+    """extract_features_batch through the one-launch kernels (the default) and with them switched off
+    (SYGNALS_AMD_ONE_LAUNCH_FEATURES=0: mel launch + logmel_dct): same columns, statistics / contrast bit for bit, MFCC
+    within a fifth of the parity gate (hardware log2 vs log10f); ragged clip length, a silent clip."""
+    import os
+    from sygnals_amd.core.features.manager import extract_features_batch
+    rng = np.random.default_rng(19)
+    Y = (rng.normal(0, 0.2, (9, 30011)) * rng.random((9, 1))).astype(np.float32)
+    Y[4] = 0.0
+    kw = dict(hop_length=hop, center=center, window=window, feature_params={"mfcc": {"n_mels": n_mels}})
+    a = extract_features_batch(Y, 22050 if n_mels == 26 else 48000, feats, **kw)
+    os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"] = "0"
+    try:
+        b = extract_features_batch(Y, 22050 if n_mels == 26 else 48000, feats, **kw)
+    finally:
+        del os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"]
+    assert list(a) == list(b) and len(a) > 1
+    for k in a:
+        if k.startswith("mfcc_"):
+            assert a[k].shape == b[k].shape
+        else:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+    if "mfcc" in feats:
+        A = np.stack([a[f"mfcc_{i}"] for i in range(13)], 1); Bm = np.stack([b[f"mfcc_{i}"] for i in range(13)], 1)
+        for c in range(Y.shape[0]):
+            assert peak_rel(A[c], Bm[c]) <= 2e-6 or np.abs(Bm[c]).max() == 0, c
+
