@@ -624,10 +624,25 @@ template <> struct SortNet<4> {
   static constexpr int N = 5;
   static constexpr int P[5][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}};
 };
+template <> struct SortNet<5> {
+  static constexpr int N = 9;
+  static constexpr int P[9][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {0, 4}, {2, 4}, {1, 2}, {3, 4}};
+};
 template <> struct SortNet<7> {
   static constexpr int N = 16;
   static constexpr int P[16][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {4, 6}, {5, 6},
                                    {0, 4}, {2, 6}, {2, 4}, {1, 5}, {3, 5}, {1, 2}, {3, 4}, {5, 6}};
+};
+template <> struct SortNet<8> {
+  static constexpr int N = 19;
+  static constexpr int P[19][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6},
+                                   {0, 4}, {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}};
+};
+template <> struct SortNet<10> {
+  static constexpr int N = 32;
+  static constexpr int P[32][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4},
+                                   {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {0, 8}, {4, 8},
+                                   {2, 4}, {6, 8}, {1, 9}, {5, 9}, {3, 5}, {7, 9}, {1, 2}, {3, 4}, {5, 6}, {7, 8}};
 };
 template <> struct SortNet<12> {
   static constexpr int N = 41;
@@ -910,10 +925,25 @@ __device__ __forceinline__ float2 band_contrast(lds_row prow, int lane, int lo, 
     else if (n <= 64) contrast_extract<1>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 128) contrast_extract<2>(prow, lane, lo, n, k, spk, svl);
     else if (n <= 256) contrast_extract<4>(prow, lane, lo, n, k, spk, svl);
-    else if (n <= 448) contrast_extract<7>(prow, lane, lo, n, k, spk, svl);
-    else if (n > 64 * 11 && k >= 4 && contrast_select<12>(prow, lane, lo, n, k, spk, svl)) {}
-    else if (may_park && ppos(hi - 1) >= 64 * 12) contrast_extract_lds<12>(prow, lane, lo, n, k, spk, svl);
-    else contrast_extract<12>(prow, lane, lo, n, k, spk, svl);
+    else {
+      // Bands of more than 256 bins with k >= 4 whose registers are all full but the last (64 (R - 1) < n <= 64 R for
+      // R = 5, 7, 8, 10, 12 -- the wide bands of the usual sample rates: 298 / 431 bins at 22.05 kHz, 479 at 24 kHz, 616 at
+      // 32 kHz, 728 at 44.1 kHz, 751 at 48 kHz) are taken by selection; whatever it refuses (ties, a lane with more than
+      // three candidates) and every other width by extraction rounds on 7 or 12 registers.
+      bool done = false;
+      if (k >= 4) {
+        if (n > 704) done = contrast_select<12>(prow, lane, lo, n, k, spk, svl);
+        else if (n > 576 && n <= 640) done = contrast_select<10>(prow, lane, lo, n, k, spk, svl);
+        else if (n > 448 && n <= 512) done = contrast_select<8>(prow, lane, lo, n, k, spk, svl);
+        else if (n > 384 && n <= 448) done = contrast_select<7>(prow, lane, lo, n, k, spk, svl);
+        else if (n > 256 && n <= 320) done = contrast_select<5>(prow, lane, lo, n, k, spk, svl);
+      }
+      if (!done) {
+        if (n <= 448) contrast_extract<7>(prow, lane, lo, n, k, spk, svl);
+        else if (may_park && ppos(hi - 1) >= 64 * 12) contrast_extract_lds<12>(prow, lane, lo, n, k, spk, svl);
+        else contrast_extract<12>(prow, lane, lo, n, k, spk, svl);
+      }
+    }
     const float rk = frcp((float)k);
     return make_float2(spk * rk, svl * rk);
   }

@@ -229,6 +229,32 @@ def test_stats_without_mel_bad_arguments(ops):
         ops.stft2048_stats(y, 48000, 1024, True, want_stats=1)
 
 
+@pytest.mark.parametrize("sr", [16000, 22050, 24000, 32000, 44100])
+def test_spectral_contrast_tail_means_other_sample_rates(ops, sr):
+    """The band plan changes with the sample rate (top band of 206 / 431 / 479 / 616 / 728 bins, k = 4 ... 15): every
+    selection form of band_contrast against sorting, through the statistics-only launch and the mel launch."""
+    from sygnals_amd import _tables as T
+    rng = np.random.default_rng(sr)
+    L = 20000
+    t = np.arange(L) / sr
+    K = np.stack([rng.normal(0, 0.3, L), np.sin(2 * np.pi * 0.31 * sr * t) + rng.normal(0, 1e-3, L), np.zeros(L),
+                  rng.normal(0, 1.0, L) * np.linspace(0, 1, L)]).astype(np.float32)
+    fr = O.fft_frequencies(sr, 2048)
+    plan = T.contrast_plan(fr, sr)
+    y = ops.to_device_f32(K)
+    _, pv_dev = ops.stft2048_stats(y, sr, want_stats=0, contrast=plan)
+    _, _, pv_mel = ops.stft2048_mel(y, sr, n_mels=40, contrast=plan)
+    assert torch.equal(pv_dev, pv_mel)
+    pv = pv_dev.cpu().numpy()
+    for i in range(K.shape[0]):
+        S = np.abs(O.stft(K[i].astype(np.float64), 2048, 512))
+        atol = TOL * max(S.max(), 1e-30)
+        for k, (bins, kk) in enumerate(O.contrast_bands(fr, sr)):
+            srt = np.sort(S[bins], axis=0)
+            assert np.abs(pv[i, 1, k] - srt[:kk].mean(axis=0)).max() <= atol, f"sr {sr} clip {i} valley band {k}"
+            assert np.abs(pv[i, 0, k] - srt[-kk:].mean(axis=0)).max() <= atol, f"sr {sr} clip {i} peak band {k}"
+
+
 def test_spectral_contrast_tail_selection_cases(ops):
     """The wide band's tails are taken by selection (k-th largest of the lanes' two top values, count, sum, take back the
     extras) with a fall-back to k extraction rounds when too many values tie at the threshold or a lane holds more than

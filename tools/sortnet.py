@@ -49,7 +49,7 @@ def sorts(pairs, R):
 
 
 if __name__ == "__main__":
-    for R in (2, 4, 7, 12):
+    for R in (2, 4, 5, 7, 8, 10, 12):
         net = network(R)
         assert sorts(net, R)
         print(R, len(net), net)
