@@ -23,8 +23,15 @@ step k runs beside the kernels of step k+1.  Every rank runs exactly the kernels
 (opt-in, unmeasured on a multi-GPU node) switches to the two-launch form on all but n CUs and caps RCCL's
 point-to-point channels to fit them.
 
-The clock pre-warm (`--prewarm`, untimed, reported) runs before the driver's own warm-up: the GPU needs ~150
-launches (30 ms) from idle to reach its steady clock.  Rank 0 prints ONE JSON line.
+`value` / `ms_per_step` are the driver's protocol and nothing else: W warm-up steps, then exactly K timed steps between
+two barrier + synchronize pairs.  On a GPU coming from idle the first ~150 launches (30 ms) run below the steady clock,
+so a short run (K = 20) reads lower than a long one; the same K steps timed again behind `--prewarm` further launches
+are reported BESIDE the value as `steady_clock` (never as `value`).  Rank 0 prints ONE JSON line.
+
+N > 1 adds what the first hardware run needs to diagnose itself: `compute_only_ms` (the same K steps with the gather
+off, timed first), `gather_wait_ms` (host time spent inside the waits for the gathers of the timed steps, per step),
+`ranks_seen` (world size and every rank's device), and -- `--reserve-cus auto` -- one re-timing with 32 CUs set aside
+for the collective when a step costs more than 1.15 x its compute.
 """
 import argparse
 import json
@@ -65,7 +72,7 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(target_seconds=10.0):
+def cpu_baseline(target_seconds=10.0, all_cores_seconds=4.0):
     """The oracle (float64 NumPy/SciPy port of the reference CPU path) on the host cores of this box.
 
     Runs BEFORE the GPU is initialised (worker processes are forked).  Sample: clips of the same
@@ -88,10 +95,23 @@ def cpu_baseline(target_seconds=10.0):
         pool.map(_cpu_worker, [(100 + i, n_per) for i in range(cores)])
     wall = time.perf_counter() - t0
     clips = cores * n_per
-    return {"value": round(clips * L / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{clips} clips x 1 s @ 48 kHz (same recipe/config as the C2 GPU workload), float64 oracle, "
-                      f"one clip per call, {cores} processes x 1 thread, {wall:.1f} s wall",
-            "single_core_value": round(L / per_clip / 1e6, 3), "cores_available": avail}
+    out = {"value": round(clips * L / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+           "sample": f"{clips} clips x 1 s @ 48 kHz (same recipe/config as the C2 GPU workload), float64 oracle, "
+                     f"one clip per call, {cores} processes x 1 thread, {wall:.1f} s wall",
+           "single_core_value": round(L / per_clip / 1e6, 3), "cores_available": avail}
+    if avail > cores:
+        # SURVEY 8(d) "(ii) all host cores": one process per core the affinity mask shows (a box's cgroup share may be
+        # smaller than its mask -- the figure is what this process can actually get), a shorter second run
+        n_all = min(avail, 512)
+        n_each = max(4, min(n_per, int(all_cores_seconds / per_clip)))
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(n_all) as pool:
+            pool.map(_cpu_worker, [(1000 + i, n_each) for i in range(n_all)], chunksize=1)
+        wall_all = time.perf_counter() - t0
+        out["all_cores_value"] = round(n_all * n_each * L / wall_all / 1e6, 3)
+        out["all_cores"] = n_all
+        out["all_cores_sample"] = f"{n_all * n_each} clips, {n_all} processes x 1 thread, {wall_all:.1f} s wall (pool start-up included)"
+    return out
 
 
 CPU_ENV = "SYG_BENCH_CPU_BASELINE"
@@ -100,19 +120,28 @@ CPU_ENV = "SYG_BENCH_CPU_BASELINE"
 def launch_ranks(a):
     """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process (which makes no GPU call,
     so the children start on an untouched device) times the CPU baseline, then runs one rank per GPU under
-    torch.distributed.run as a child process and relays its output and return code."""
+    torch.distributed.run as a child process and relays its output and return code.  The rendezvous port is picked by
+    binding port 0; should another process take it before the child binds (the child then dies in its rendezvous, before
+    any GPU work), one more child is started on a fresh port."""
     import socket
     import subprocess
     env = dict(os.environ)
     if not a.no_cpu_baseline and not env.get(CPU_ENV):
         env[CPU_ENV] = json.dumps(cpu_baseline())
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    rc = 1
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(p.stderr)
+        rc = p.returncode
+        if rc == 0 or "address already in use" not in p.stderr.lower():
+            break
+    return rc
 
 
 def mfma_flops_per_launch(ops, B, segments):
@@ -133,13 +162,16 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--prewarm", type=int, default=300,
-                    help="untimed launches ahead of --warmup that bring the GPU from idle to its steady clock")
+                    help="launches between the driver-protocol measurement (`value`) and the `steady_clock` re-timing; 0: skip it")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the configuration's)")
-    ap.add_argument("--reserve-cus", type=int, default=0,
-                    help="N > 1, opt-in: leave this many CUs to RCCL (two-launch form, capped p2p channels)")
+    ap.add_argument("--reserve-cus", default="0",
+                    help="N > 1: leave this many CUs to RCCL (two-launch form, capped p2p channels); `auto`: time the plain "
+                         "form first and, when a step costs more than 1.15 x its compute, once more with 32 CUs set aside")
     a = ap.parse_args()
+    reserve_auto = a.reserve_cus == "auto"
+    a.reserve_cus = 0 if reserve_auto else int(a.reserve_cus)
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a))             # plain `python bench.py --gpus N`: start the ranks ourselves
@@ -179,7 +211,8 @@ def main():
             # opt-in: CUs set aside for the collective + RCCL capped to fit them; set before the process group and
             # the first launch read them
             per_peer = max(1, (reserve - 4) // (world - 1))
-            os.environ["SYGNALS_AMD_RESERVE_CUS"] = str(reserve)
+            if not dry:
+                ops.set_reserved_cus(reserve)
             os.environ.setdefault("NCCL_NCHANNELS_PER_PEER", str(min(4, per_peer)))
             os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", str(min(4, per_peer) * (world - 1)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -212,11 +245,18 @@ def main():
     # N > 1: every step's result block is gathered to rank 0 (the only exchange of the path).  The gather
     # of step k is asynchronous and overlaps the kernel of step k+1; all gathers are finished inside the timed region.
     gat = RootGather(n_total, (B, rows, T_FRAMES), torch.float32, "cpu" if same_gpu else torch.device("cuda", dev_index))
+    backend = "gloo (same-GPU / dry rehearsal, through the host)" if same_gpu else "RCCL"
+    wait_acc = [0.0]
 
-    def step():
+    def finish_gather():
+        t0 = time.perf_counter()
+        gat.finish()                                   # (the previous step's gather; a stream-side wait under RCCL)
+        wait_acc[0] += time.perf_counter() - t0
+
+    def step(gather=True):
         out = compute()
-        if world > 1:
-            gat.finish()                               # (the previous step's gather; a stream-side wait)
+        if world > 1 and gather:
+            finish_gather()
             gat.start(out.cpu() if same_gpu else out)
         return out
 
@@ -226,43 +266,70 @@ def main():
 
     def sync():
         if world > 1:
-            gat.finish()
+            finish_gather()
         dev_sync()
         if world > 1:
             dist.barrier()
             dev_sync()
 
-    def timed(steps):
+    def timed(steps, gather=True):
         sync()
+        wait_acc[0] = 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            step(gather)
         sync()
         el = time.perf_counter() - t0
+        wait = wait_acc[0]
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
+            t = torch.tensor([el, wait], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+            el, wait = float(t[0].item()), float(t[1].item())
+        return el, wait
 
-    # the driver's protocol exactly (W warm-up steps, K timed steps), before the clock pre-warm: reported beside `value`
-    # as `no_prewarm` (on a GPU coming from idle the first ~150 launches run at a lower clock)
+    # The driver's protocol exactly: W warm-up steps, K timed steps -> `value`.  (N > 1: the same K steps with the
+    # gather off are timed first, so that the line shows what the collective costs.)
     for _ in range(a.warmup):
         step()
-    elapsed_cold = timed(a.steps) if a.prewarm > 0 else None
-    for _ in range(a.prewarm):                         # clock pre-warm: compute only, untimed, reported
-        compute()
+    compute_only = None
+    if world > 1:
+        compute_only, _ = timed(a.steps, gather=False)
+    elapsed, gather_wait = timed(a.steps)
+    # once more behind `--prewarm` further launches (a GPU coming from idle needs ~150 launches to reach its steady clock):
+    # reported beside the value, never as the value
+    steady = None
     if a.prewarm > 0:
+        for _ in range(a.prewarm):
+            compute()
         for _ in range(a.warmup):
             step()
-    elapsed = timed(a.steps)
+        steady, _ = timed(a.steps)
+    # --reserve-cus auto: a step that costs more than 1.15 x its compute is waiting for the collective (or the collective
+    # for CUs: the persistent kernels fill every CU); one re-timing with 32 CUs left to RCCL, both printed
+    retry = None
+    if world > 1 and reserve_auto and not dry:
+        ref_el = steady if steady is not None else elapsed
+        if ref_el > 1.15 * compute_only:
+            ops.set_reserved_cus(32)
+            for _ in range(a.warmup):
+                step()
+            r_el, r_wait = timed(a.steps)
+            ops.set_reserved_cus(0)
+            retry = {"reserved_cus": 32, "ms_per_step": round(r_el / a.steps * 1e3, 4),
+                     "gather_wait_ms": round(r_wait / a.steps * 1e3, 4),
+                     "value": round(n_total * L * a.steps / r_el / 1e6, 1)}
+    ranks_seen = None
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, "cpu (dry run)" if dry else f"cuda:{dev_index} {torch.cuda.get_device_name(dev_index)}")
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": backend, "devices": names}
 
     # dominant kernel: HIP events on the stream it is launched on, back-to-back launches (steady clock: the timed
     # steps above have just run); the average includes the ~2 us dispatch gap, rocprofv3's per-dispatch average does not
     roof = None
     if rank == 0 and not dry:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = max(10, min(a.steps, 100))
+        reps = 200                                         # (>= 30 ms of back-to-back launches: the steady clock)
         if a.config == "c2" and one_launch:
             segments = ops.mel_config(SR, N_FFT, N_MELS, waves=16).segtab is not None
             kname = ("stft2048_kernel<16,2,6> (16 waves, staged tiles, per-wave mel projection by segment sums, clip-resident "
@@ -278,7 +345,8 @@ def main():
             from sygnals_amd.core.features.manager import feature_block_dominant
             kname, kfn, krows = feature_block_dominant(y, SR, HOP, N_MELS, N_MFCC)
             kbytes = B * (4 * L + 4 * krows * T_FRAMES)
-        kfn()
+        for _ in range(200 if steady is None else 20):     # (without the steady_clock leg: bring the clock up here)
+            kfn()
         e0.record()
         for _ in range(reps):
             kfn()
@@ -286,16 +354,23 @@ def main():
         e1.synchronize()
         kdur = e0.elapsed_time(e1) * 1e-3 / reps
         achieved = kbytes / kdur / 1e9
-        traffic = None
+        # traffic / binding: from the committed rocprofv3 PMC passes of this kernel (profiles/traffic.json says which
+        # file); PMC collection needs the profiler, so it is not re-measured inside this run
+        traffic = binding = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp) and a.config == "c2" and one_launch:
             try:
-                traffic = json.load(open(tp)).get("dominant_kernel_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("dominant_kernel_bytes_per_launch")
+                binding = tj.get("binding")
             except Exception:
-                traffic = None
+                traffic = binding = None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kname,
-                "kernel_avg_us": round(kdur * 1e6, 2), "algorithmic_bytes_per_launch": kbytes}
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes; not re-measured in this run)" if traffic else None,
+                "binding": binding, "kernel": kname,
+                "kernel_avg_us": round(kdur * 1e6, 2), "kernel_launches_timed": reps,
+                "algorithmic_bytes_per_launch": kbytes}
         if a.config == "c2" and one_launch:
             fl = mfma_flops_per_launch(ops, B, segments)
             roof["mfma_util"] = {"flops_per_launch": fl, "achieved_tflops": round(fl / kdur / 1e12, 2),
@@ -320,19 +395,23 @@ def main():
                         "block per step, gathered to rank 0")
         par = f"clip-sharded x{world}"
         if world > 1:
-            par += (", asynchronous RCCL gather to rank 0 in the timed region" +
+            par += (f", asynchronous gather to rank 0 in the timed region ({backend})" +
                     (f", two-launch form on all but {reserve} CUs" if reserve else ", same kernels as N = 1"))
         if dry:
             value = 0.0
         line = {
             "metric": "Msamples/s STFT->MFCC (n_fft=2048, hop=512)", "value": round(value, 1), "unit": "Msamples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_steps": a.prewarm,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not dry else "DRY RUN: launcher rehearsal without a GPU, zeros instead of kernels, no measurement",
-            "no_prewarm": None if elapsed_cold is None else {
-                "value": round(samples / elapsed_cold / 1e6, 1), "ms_per_step": round(elapsed_cold / a.steps * 1e3, 4),
-                "note": "the same W warm-up + K timed steps run BEFORE the clock pre-warm"},
+            "steady_clock": None if steady is None or dry else {
+                "value": round(samples / steady / 1e6, 1), "ms_per_step": round(steady / a.steps * 1e3, 4),
+                "launches_before": a.prewarm + a.warmup,
+                "note": "the same K steps timed again behind further launches (GPU at its steady clock); not the value"},
+            "compute_only_ms": None if compute_only is None else round(compute_only / a.steps * 1e3, 4),
+            "gather_wait_ms": None if world == 1 else round(gather_wait / a.steps * 1e3, 4),
+            "ranks_seen": ranks_seen, "reserve_cus_retry": retry,
             "config": {"workload": workload, "clips_per_gpu": B, "clip_samples": L, "sr": SR, "n_fft": N_FFT, "hop": HOP,
                        "n_mels": N_MELS, "n_mfcc": N_MFCC, "rows_per_clip": rows, "parallelism": par},
             "hbm_roofline_frac_whole_step": round(job_bytes / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),

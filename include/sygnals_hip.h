@@ -10,12 +10,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
  *   - the caller owns every buffer (inputs, outputs, tables, workspaces); the library
- *     allocates nothing; its only state is a thread-local error string (no caches keyed by shape or
- *     device: kernel attributes are set at every launch, the CU count is queried per call).  A few
- *     DEVELOPMENT switches are read from the environment at every call and select between kernels
- *     that the tests hold to the same results (unset in production): SYGNALS_AMD_RESERVE_CUS,
- *     SYGNALS_AMD_LOAD (syg_stft2048_*), SYGNALS_AMD_SOS_CLIP (syg_sosfiltfilt_*), SYGNALS_AMD_CQT_STAGED,
- *     SYGNALS_AMD_CQT_RT, SYGNALS_AMD_CQT_WAVES (syg_cqt_octave_*) -- listed in INTEGRATION.md section 4b;
+ *     allocates nothing; its only state is a thread-local error string and the process-wide options of
+ *     syg_set_option() below (no caches keyed by shape or device: kernel attributes are set at every launch, the
+ *     CU count is queried per call).  Nothing is read from the environment;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
  *     enqueue work on it and never synchronise;
  *   - return value: 0 on success, negative SYG_E_* on error, message via syg_last_error();
@@ -44,6 +41,23 @@ int syg_abi_version(void);
  * results are wrong by design: a binding must refuse to use such a library. */
 int syg_build_variant(void);
 const char* syg_last_error(void);
+
+/* Process-wide options (atomics; read when a launch is planned).  All but the first select between kernels that the
+ * tests hold to the same results and exist for those tests; production code leaves them at their defaults.
+ *   SYG_OPT_RESERVED_CUS  n >= 0 (default 0): the persistent syg_stft2048_* kernels leave n CUs out of their grid, for a
+ *                         collective (RCCL's send / receive workgroups) running beside them
+ *   SYG_OPT_STFT_LOAD     -1 (default: staged tiles) | 0 | 1 | 2: frame load path of the syg_stft2048_* kernels
+ *   SYG_OPT_SOS_CLIP      1 (default) | 0: clip-resident form of syg_sosfiltfilt_f32 / the chunked form only
+ *   SYG_OPT_CQT_STAGED    -1 (default: where it pays) | 0 (never) | 1 | 2 (also at hop = n_fft / 2): staged form of
+ *                         syg_cqt_octave_bf16x3_f32
+ * syg_set_option returns SYG_OK or SYG_E_INVALID (unknown key / value out of range); syg_get_option the current value. */
+#define SYG_OPT_RESERVED_CUS 0
+#define SYG_OPT_STFT_LOAD 1
+#define SYG_OPT_SOS_CLIP 2
+#define SYG_OPT_CQT_STAGED 3
+#define SYG_OPT_COUNT 4
+int syg_set_option(int key, int value);
+int syg_get_option(int key);
 
 /* ---------------------------------------------------------------------------------
  * Fused headline path: framed STFT (n_fft = 2048) -> |X|^2 -> mel filterbank.

@@ -23,6 +23,8 @@ SIGNATURES = {
     "syg_abi_version": (_i, []),
     "syg_build_variant": (_i, []),
     "syg_last_error": (C.c_char_p, []),
+    "syg_set_option": (_i, [_i, _i]),
+    "syg_get_option": (_i, [_i]),
     "syg_stft2048_mel_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p, _i, _p, _f, _f, _f, _i, _p, _p, _p, _p]),
     "syg_stft2048_c2c_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p]),
     "syg_stft2048_mfcc_fits": (_i, [_i, _l, _i]),

@@ -148,11 +148,10 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
             n_mfcc, lifter = int(mp.get("n_mfcc", 13)), float(mp.get("lifter", 0.0))
             # the MFCC rows straight from the fused launch (the clip's mel matrix stays in LDS) when the request is the
             # default cepstrum (DCT-II ortho on the power mel spectrogram) -- mfcc is the only mel-based feature here
-            # (SYGNALS_AMD_ONE_LAUNCH_FEATURES=0: the mel launch + logmel_dct, for comparisons)
-            import os
+            # (ops.settings.one_launch_features = False: the mel launch + logmel_dct, for comparisons)
             std_mfcc = (want_mfcc and frame_length == 2048 and power == 2.0 and mp.get("dct_type", 2) == 2 and
                         mp.get("norm", "ortho") == "ortho" and 1 <= n_mfcc <= n_mels and ops.fused_waves() == 16 and
-                        os.environ.get("SYGNALS_AMD_ONE_LAUNCH_FEATURES", "1") != "0")
+                        ops.settings.one_launch_features)
             one = None
             if std_mfcc and (want_stats or want_contrast) and lifter == 0.0:
                 one = features_one_launch(yd, sr, hop_length, center, window, n_mels, fmin, fmax, n_mfcc, want_stats, roll, bw_p, cplan)
@@ -163,7 +162,7 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                   and ops.mfcc_fused_fits(n_mels, Tn, n_mfcc)):
                 cache["mfcc_dev"] = ops.stft2048_mfcc(yd, sr, hop_length, center, window, n_mels, n_mfcc, fmin, fmax, lifter)[0]
                 t_stft = Tn
-            elif (not want_mfcc and (want_stats or want_contrast) and frame_length == 2048 and ops.stft2048_stats_fits(hop_length)):
+            elif (not want_mfcc and (want_stats or want_contrast) and frame_length == 2048 and ops.stft2048_stats_fits(hop_length, yd.shape[1])):
                 # no mel-based feature asked for: transform + row functions, nothing projected (syg_stft2048_stats_f32)
                 stats, cpv = ops.stft2048_stats(yd, sr, hop_length, center, window, 2048, want_stats, roll, bw_p, cplan)
                 t_stft = Tn

@@ -11,6 +11,8 @@ namespace syg {
 
 // thread-local last-error string, defined in capi.hip
 void set_error(const char* fmt, ...);
+// process-wide option (syg_set_option / SYG_OPT_*), defined in capi.hip
+int option(int key);
 
 #define SYG_REQUIRE(cond, ...)                 \
   do {                                         \

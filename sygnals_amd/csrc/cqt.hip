@@ -32,10 +32,8 @@ __global__ __launch_bounds__(DEC_NT) void decimate2_kernel(const float* __restri
   const int64_t b = blockIdx.y;
   const float* xb = x + b * ldx;
   const int tid = threadIdx.x;
-  // the fast path moves the input run with 16-byte loads (an 8-byte load per lane runs at 0.54-0.70 of that rate --
-  // MI355X_MICROARCH.md, table of load flavours -- and this pass is bound by its 1.3 GB of traffic): tile starts are
-  // multiples of four samples by construction (NF << NL and HALF (2^NL - 1) both are)
-  const bool pair_ok = ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+  // the fast path stages sample pairs with 8-byte loads: rows and the base pointer must be 8-byte aligned
+  const bool pair_ok = ((ldx & 1) == 0) && ((((uintptr_t)x) & 7) == 0);
   for (int j = tid; j < ntaps; j += DEC_NT) hs[j] = taps[j];
   for (int64_t n0 = (int64_t)blockIdx.x * DEC_NBO; n0 < Lout; n0 += (int64_t)gridDim.x * DEC_NBO) {
     // lowest input index used: 2 n0 + half - (ntaps - 1) = 2 n0 - half; mbase = floor(that / 2)
@@ -231,7 +229,12 @@ __global__ __launch_bounds__(DEC_NT, SYG_DEC_WAVES) void decimate2_chain_kernel(
   const int64_t b = blockIdx.y;
   const float* xb = x + b * ldx;
   const int tid = threadIdx.x;
-  const bool pair_ok = ((ldx & 1) == 0) && ((((uintptr_t)x) & 7) == 0);
+  // the fast path moves the input run with 16-byte loads (an 8-byte load per lane runs at 0.54-0.70 of that rate --
+  // MI355X_MICROARCH.md, table of load flavours -- and this pass is bound by its 1.3 GB of traffic): tile starts are
+  // multiples of four samples by construction (NF << NL and HALF (2^NL - 1) both are), so every row start must be
+  // 16-byte aligned too: ldx % 4 == 0 and a 16-byte aligned base (rows with ldx % 4 == 2, e.g. 22 050-sample clips,
+  // take the element-wise path)
+  const bool pair_ok = ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
   for (int j = tid; j < NT; j += DEC_NT) hs[j] = taps[j];
   if (tid == 0) ol = o;
   __syncthreads();
@@ -953,8 +956,7 @@ extern "C" int syg_cqt_octave_gemm_f32(const float* y, int64_t B, int64_t L, int
   const int n_rowtiles = (2 * n_filt + 15) / 16;
   const int64_t ntiles = (T + 15) / 16;
   // two row tiles per wave when they come in pairs and the operands fit the registers (n_fft <= 256: 128 + 64 VGPRs)
-  const char* rte = getenv("SYGNALS_AMD_CQT_RT");          // development aid: 1 forces one row tile per wave
-  const int rt = (n_rowtiles % 2 == 0 && n_fft <= 256 && !(rte && rte[0] == '1')) ? 2 : 1;
+  const int rt = (n_rowtiles % 2 == 0 && n_fft <= 256) ? 2 : 1;
   const int ngroups = n_rowtiles / rt;
   // persistent waves: about 8 (rt = 2) / 12 per CU over the batch, never more than there are frame tiles
   int64_t wpr = (256 * (rt == 2 ? 8 : 12)) / ((int64_t)ngroups * B);
@@ -991,8 +993,8 @@ extern "C" int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, i
   hipStream_t st = (hipStream_t)stream;
   // overlapping frames: every wave splits the sample run of its 16-frame tile once (cqt_bf16x3_staged_kernel)
   {
-    const char* e = getenv("SYGNALS_AMD_CQT_STAGED");
-    const bool off = e && e[0] == '0';
+    const int staged_opt = option(SYG_OPT_CQT_STAGED);   // -1 default, 0 off, 2: also where hop = n_fft / 2 (for the tests)
+    const bool off = staged_opt == 0;
     const bool shape_ok = hop % 4 == 0 && hop <= n_fft / 2;
     const int ncopy = hop % 8 == 0 ? 1 : 2;
     const int nchunks = shape_ok ? (15 * hop + n_fft) / 8 : 0;
@@ -1005,8 +1007,8 @@ extern "C" int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, i
     int nwv = shape_ok ? (int)((160 * 1024 - 512 - atab_bytes) / wave_bytes) : 0;       // regions the LDS holds
     const int maxc = (ncopy * nchunks + 63) / 64;
     // (hop = n_fft / 2, maxc 5: a sample sits in two frames only and the LDS holds 7 regions -- measured slower than the
-    //  per-frame kernel, 78 vs 66 us per C5 octave; SYGNALS_AMD_CQT_STAGED=2 forces it for the tests)
-    const bool worth = maxc <= 3 || (e && e[0] == '2');
+    //  per-frame kernel, 78 vs 66 us per C5 octave; SYG_OPT_CQT_STAGED = 2 forces it for the tests)
+    const bool worth = maxc <= 3 || staged_opt == 2;
     const int wcap = maxc > 3 ? 8 : maxc == 3 ? 12 : 16;       // the kernels' launch bounds (longer runs hold more registers)
     if (nwv > wcap) nwv = wcap;
     if (!off && worth && shape_ok && ((uintptr_t)y) % 16 == 0 && (B == 1 || ldy % 4 == 0) && ncopy * nchunks <= 5 * 64 &&
@@ -1017,7 +1019,6 @@ extern "C" int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, i
         set_error("cqt_octave_bf16x3: cannot query the device");
         return SYG_E_LAUNCH;
       }
-      if (const char* pe = getenv("SYGNALS_AMD_CQT_WAVES")) { const int v = atoi(pe); if (v >= 1 && v < nwv) nwv = v; }  // (development)
       const size_t lds = atab_bytes + (size_t)nwv * wave_bytes;
       int64_t gx = ((int64_t)n_cu + B - 1) / B;    // one workgroup per CU over the batch
       if (gx * nwv > ntiles) gx = (ntiles + nwv - 1) / nwv;

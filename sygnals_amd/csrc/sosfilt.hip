@@ -377,8 +377,8 @@ using namespace syg;
 
 // true when the clip-resident form (both sweeps in one launch, no workspace) takes this shape
 static bool clip_resident(int64_t lext, int n_sections) {
-  const char* e = getenv("SYGNALS_AMD_SOS_CLIP");      // development switch: =0 keeps the chunked path
-  return sos_clip_chunk(lext) > 0 && sos_clip_supported(n_sections) && !(e && e[0] == '0');
+  // (SYG_OPT_SOS_CLIP = 0 keeps the chunked path: the tests hold the two forms to the same results)
+  return sos_clip_chunk(lext) > 0 && sos_clip_supported(n_sections) && option(SYG_OPT_SOS_CLIP) != 0;
 }
 
 extern "C" int64_t syg_sosfiltfilt_work_bytes(int64_t B, int64_t L, int padlen, int n_sections) {

@@ -1771,7 +1771,7 @@ constexpr size_t lds_bytes() {
 }
 
 // Workgroups per CU: two of 8 waves or one of 16; each takes a contiguous chunk of tiles.
-// SYGNALS_AMD_RESERVE_CUS=n (read at every launch) leaves n CUs out of the grid.  A workgroup of these kernels fills a
+// syg_set_option(SYG_OPT_RESERVED_CUS, n) leaves n CUs out of the grid.  A workgroup of these kernels fills a
 // CU (16 waves x 128 VGPRs), so a kernel of another stream that needs a few CUs at the same time -- RCCL's send /
 // receive workgroups while the previous batch is gathered -- either waits for a whole launch or makes this launch wait
 // for it (tools/queue_bench.py: 167 -> 256 us for every second launch).  With the CUs set aside both run side by side.
@@ -1783,10 +1783,8 @@ void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
       hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
     n_cu = 256;
   int use_cu = n_cu;
-  if (const char* e = getenv("SYGNALS_AMD_RESERVE_CUS")) {
-    const int r = atoi(e);
-    if (r > 0 && r < n_cu) use_cu = n_cu - r;
-  }
+  const int r = option(SYG_OPT_RESERVED_CUS);
+  if (r > 0 && r < n_cu) use_cu = n_cu - r;
   const int64_t slots = (int64_t)use_cu * (waves == 8 ? 2 : 1);
   int64_t p = (total_tiles + slots - 1) / slots;
   if (p < 1) p = 1;
@@ -1794,10 +1792,10 @@ void persistent_grid(int64_t total_tiles, int waves, int& wgs, int& per) {
   wgs = (int)((total_tiles + p - 1) / p);
 }
 
-// SYGNALS_AMD_LOAD = 0 | 1 | 2 forces the frame load path (development aid, read at every call); default: staged tiles
+// SYG_OPT_STFT_LOAD = 0 | 1 | 2 forces the frame load path (the tests compare the three); default: staged tiles
 int load_mode() {
-  const char* e = getenv("SYGNALS_AMD_LOAD");
-  return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
+  const int v = option(SYG_OPT_STFT_LOAD);
+  return (v >= 0 && v <= 2) ? v : 2;
 }
 
 int check_common(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,

@@ -90,10 +90,72 @@ def num_frames(L: int, n_fft: int, hop: int, center: bool) -> int:
 
 
 # ------------------------------------------------------------------ fused 2048 path
+class _Settings:
+    """Process-wide switches between kernels that the tests hold to the same results (plain attributes: nothing is read
+    from the environment; tests and tools set them with `ops.override(...)`):
+      waves                 16 (one workgroup per CU) | 8: waves per workgroup of the matrix-form fused 2048 kernels
+      cqt_mode              "bf16x3" (default) | "gemm" | "fft": octave kernel of compute_cqt
+      cqt_streams           1 | 2: octave products on a side stream (measured: no gain)
+      cqt_chain             True: up to three decimation levels per pass; False: one launch per level
+      one_launch_features   True: extract_features routes MFCC + statistics / contrast requests to the one-launch kernels
+    Options that live in the library (syg_set_option): reserved_cus, stft_load, sos_clip, cqt_staged."""
+    waves = T.WAVES
+    cqt_mode = "bf16x3"
+    cqt_streams = 1
+    cqt_chain = True
+    one_launch_features = True
+
+
+settings = _Settings()
+_LIB_OPTIONS = {"reserved_cus": 0, "stft_load": 1, "sos_clip": 2, "cqt_staged": 3}      # SYG_OPT_* of include/sygnals_hip.h
+
+
+def set_option(name: str, value: int) -> None:
+    """syg_set_option by name (reserved_cus | stft_load | sos_clip | cqt_staged)."""
+    check(lib().syg_set_option(_LIB_OPTIONS[name], int(value)), "syg_set_option")
+
+
+def get_option(name: str) -> int:
+    return int(lib().syg_get_option(_LIB_OPTIONS[name]))
+
+
+def set_reserved_cus(n: int) -> None:
+    """Leave `n` CUs out of the persistent grids of the fused 2048 kernels (room for a collective's workgroups)."""
+    set_option("reserved_cus", n)
+
+
+class override:
+    """Context manager: `with ops.override(cqt_mode="fft", cqt_staged=0): ...` sets Python-side settings and library
+    options for the block and puts the previous values back."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            if k in _LIB_OPTIONS:
+                self.old[k] = get_option(k)
+                set_option(k, v)
+            else:
+                if not hasattr(_Settings, k):
+                    raise KeyError(k)
+                self.old[k] = getattr(settings, k)
+                setattr(settings, k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if k in _LIB_OPTIONS:
+                set_option(k, v)
+            else:
+                setattr(settings, k, v)
+        return False
+
+
 def fused_waves() -> int:
     """Waves per workgroup of the fused kernel: 8 (two workgroups per CU) or 16 (one)."""
-    import os
-    return int(os.environ.get("SYGNALS_AMD_WAVES", T.WAVES))
+    return int(settings.waves)
 
 
 class MelConfig:
@@ -382,9 +444,10 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
     return mel, stats, cpv
 
 
-def stft2048_stats_fits(hop: int) -> bool:
-    """Whether stft2048_stats takes this call (staged tiles: hop <= 512; the 16-wave kernel)."""
-    return hop <= 512 and fused_waves() == 16
+def stft2048_stats_fits(hop: int, L: int = 0) -> bool:
+    """Whether stft2048_stats takes this call: the C side's conditions (syg_stft2048_stats_f32: staged tiles need
+    hop <= 512 and 32-bit byte offsets, L < 2^28; frame count below 2^24) and the 16-wave kernel."""
+    return hop <= 512 and L < (1 << 28) and 1 + L // max(hop, 1) < (1 << 24) and fused_waves() == 16
 
 
 def stft2048_stats(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann", win_length: int = 2048,
@@ -1493,20 +1556,20 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
     s2 = float(np.sqrt(2.0))
     # octave kernel: "bf16x3" (default: the framed product with bfloat16-split operands, fp32-equivalent), "gemm" (the
     # single-instruction fp32 MFMA form), "fft" (rfft x sparse rows; also what other frame lengths take)
-    mode = os.environ.get("SYGNALS_AMD_CQT", "bf16x3")
+    mode = settings.cqt_mode
     use_gemm = mode != "fft"
-    # SYGNALS_AMD_CQT_STREAMS=2: the decimation chain (memory-bound) on the caller's stream, the octave products
+    # settings.cqt_streams = 2: the decimation chain (memory-bound) on the caller's stream, the octave products
     # (matrix-core bound, no LDS) on a side stream, so that octave i runs beside the decimation towards octave i + 1.
     # Measured on one 1-hour stream: 1.03 ms against 1.05 ms on one stream -- the two kernels slow each other down by
     # about what the overlap saves -- so one stream is the default.
     main = torch.cuda.current_stream()
-    two = os.environ.get("SYGNALS_AMD_CQT_STREAMS", "1") == "2"
+    two = settings.cqt_streams == 2
     side = _side_stream(y.device) if two else main
     if two:
         side.wait_stream(main)                    # `out` and `y` are ready for the side stream
-    # every decimation level up front (three levels per pass; SYGNALS_AMD_CQT_CHAIN=0: one launch per level)
+    # every decimation level up front (three levels per pass; settings.cqt_chain = False: one launch per level)
     n_dec = plan.early + sum(1 for o in plan.octaves[:-1] if o["decimate_after"])
-    chain = os.environ.get("SYGNALS_AMD_CQT_CHAIN", "1") != "0" and not two and n_dec > 0
+    chain = settings.cqt_chain and not two and n_dec > 0
     levels = None
     if chain:
         keepl = [i >= plan.early - 1 for i in range(n_dec)]

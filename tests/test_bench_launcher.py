@@ -28,17 +28,30 @@ def test_plain_invocation_with_two_gpus_launches_its_own_ranks():
     assert line["scaling"] == "weak" and line["unit"] == "Msamples/s"
     assert line["cpu_baseline"] == cpu                       # non-null for N > 1: the parent's baseline reaches rank 0
     assert line["data"].startswith("DRY RUN")                # and a rehearsal can never pass for a measurement
-    assert "x2" in line["config"]["parallelism"]
-    assert line["no_prewarm"] is not None
+    assert "x2" in line["config"]["parallelism"] and "RCCL" not in line["config"]["parallelism"]   # (gloo rehearsal)
+    # the fields the first multi-GPU hardware run diagnoses itself with
+    assert line["compute_only_ms"] is not None and line["compute_only_ms"] >= 0
+    assert line["gather_wait_ms"] is not None and line["gather_wait_ms"] >= 0
+    rs = line["ranks_seen"]
+    assert rs["world_size"] == 2 and len(rs["devices"]) == 2 and rs["backend"].startswith("gloo")
+    assert line["reserve_cus_retry"] is None
+    assert "prewarm_steps" not in line and "no_prewarm" not in line      # `value` is the driver's protocol, nothing ahead of it
 
 
 def test_c4_payload_through_the_launcher():
     line = _run({}, "--gpus", "2", "--config", "c4", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--clips", "4",
                 "--no-cpu-baseline")
     assert line["n_gpus"] == 2 and line["config"]["rows_per_clip"] == 22 and line["cpu_baseline"] is None
-    assert line["no_prewarm"] is None
+    assert line["steady_clock"] is None and line["ranks_seen"]["world_size"] == 2
 
 
 def test_single_gpu_dry_line():
     line = _run({}, "--steps", "2", "--warmup", "1", "--prewarm", "0", "--clips", "4", "--no-cpu-baseline")
     assert line["n_gpus"] == 1 and line["ms_per_step"] >= 0
+    assert line["compute_only_ms"] is None and line["gather_wait_ms"] is None and line["ranks_seen"] is None
+
+
+def test_reserve_cus_auto_is_accepted():
+    line = _run({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--clips", "4", "--no-cpu-baseline",
+                "--reserve-cus", "auto")
+    assert line["n_gpus"] == 2 and line["reserve_cus_retry"] is None     # (a dry run never re-times)

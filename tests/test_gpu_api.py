@@ -267,7 +267,7 @@ def test_cqt_both_octave_kernels_vs_oracle(path, monkeypatch):
     fp32-equivalent) or as single fp32 MFMA instructions -- and as rfft x sparse basis rows (the fallback for other
     frame lengths) are the same linear map: all three against the oracle at 1e-5."""
     from sygnals_amd import ops
-    monkeypatch.setenv("SYGNALS_AMD_CQT", path)
+    monkeypatch.setattr(ops.settings, "cqt_mode", path)
     rng = np.random.default_rng(11)
     sr = 48000
     n = sr * 3 + 77                                          # odd length: ragged decimated lengths, masked edge tiles
@@ -293,13 +293,14 @@ def test_cqt_staged_frames_identical(sr, hop, n_bins, L, B, monkeypatch):
     import torch
     rng = np.random.default_rng(L)
     x = ops.to_device_f32(rng.normal(0, 0.3, (B, L)).astype(np.float32))
-    monkeypatch.setenv("SYGNALS_AMD_CQT", "bf16x3")
-    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "2")          # 2: also where hop = n_fft / 2 (not the default there)
-    a = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
-    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "1")
-    a1 = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
-    monkeypatch.setenv("SYGNALS_AMD_CQT_STAGED", "0")
-    b = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
+    monkeypatch.setattr(ops.settings, "cqt_mode", "bf16x3")
+    with ops.override(cqt_staged=2):                            # 2: also where hop = n_fft / 2 (not the default there)
+        a = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
+    with ops.override(cqt_staged=1):
+        a1 = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
+    with ops.override(cqt_staged=0):
+        b = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
+    assert ops.get_option("cqt_staged") == -1
     assert a.shape == b.shape and torch.equal(a, b) and torch.equal(a1, b)
     if L <= 48000 * 2 + 77 and B == 1:
         ref = O.cqt(x[0].cpu().numpy().astype(np.float64), sr, hop_length=hop, n_bins=n_bins)
@@ -307,7 +308,8 @@ def test_cqt_staged_frames_identical(sr, hop, n_bins, L, B, monkeypatch):
         assert peak_rel(got[..., 0] + 1j * got[..., 1], ref) <= TOL
 
 
-@pytest.mark.parametrize("B,L", [(1, 1), (1, 5), (2, 101), (1, 3823), (3, 3824 * 2 + 1), (1, 478 * 8 * 9), (2, 1 << 20), (1, (1 << 21) + 12345)])
+@pytest.mark.parametrize("B,L", [(1, 1), (1, 5), (2, 101), (1, 3823), (3, 3824 * 2 + 1), (1, 478 * 8 * 9), (2, 1 << 20), (1, (1 << 21) + 12345),
+                                 (2, 22050), (3, (1 << 20) + 2)])   # rows of L % 4 == 2: no 16-byte row starts
 def test_decimate2_chain_identical_to_level_by_level(B, L):
     """Two or three decimations carried through LDS in one pass: the same bits as one launch per level (zero padding of
     every level at both ends, tiles whose halo crosses the signal's ends, ragged lengths, batches with odd row strides),
@@ -340,10 +342,9 @@ def test_cqt_chain_and_level_by_level_identical(monkeypatch):
     from sygnals_amd import ops
     import torch
     x = ops.to_device_f32(np.random.default_rng(3).normal(0, 0.3, (2, 48000 * 5 + 3)).astype(np.float32))
-    monkeypatch.setenv("SYGNALS_AMD_CQT_CHAIN", "1")
     a = ops.cqt(x, 48000)
-    monkeypatch.setenv("SYGNALS_AMD_CQT_CHAIN", "0")
-    assert torch.equal(a, ops.cqt(x, 48000))
+    with ops.override(cqt_chain=False):
+        assert torch.equal(a, ops.cqt(x, 48000))
 
 
 def test_cqt_batch_long_stream_consistency():
@@ -563,12 +564,8 @@ def test_c4_feature_block_equals_the_manager_columns():
         else:
             assert np.array_equal(blk2[:, r].astype(np.float64), d[k]), k
     # ... and with the one-launch forms switched off the manager's columns are the two-launch block's, bit for bit
-    import os
-    os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"] = "0"
-    try:
+    with ops.override(one_launch_features=False):
         d2 = extract_features_batch(Y, 48000, feats, feature_params={"mfcc": {"n_mels": 40}})
-    finally:
-        del os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"]
     for r, k in enumerate(names):
         assert np.array_equal(blk2[:, r].astype(np.float64), d2[k]), k
 
@@ -583,20 +580,17 @@ def test_c4_feature_block_equals_the_manager_columns():
 ])
 def test_manager_one_launch_routes_match_the_mel_route(hop, center, window, n_mels, feats):
     """extract_features_batch through the one-launch kernels (the default) and with them switched off
-    (SYGNALS_AMD_ONE_LAUNCH_FEATURES=0: mel launch + logmel_dct): same columns, statistics / contrast bit for bit, MFCC
+    (ops.settings.one_launch_features = False: mel launch + logmel_dct): same columns, statistics / contrast bit for bit, MFCC
     within a fifth of the parity gate (hardware log2 vs log10f); ragged clip length, a silent clip."""
-    import os
+    from sygnals_amd import ops
     from sygnals_amd.core.features.manager import extract_features_batch
     rng = np.random.default_rng(19)
     Y = (rng.normal(0, 0.2, (9, 30011)) * rng.random((9, 1))).astype(np.float32)
     Y[4] = 0.0
     kw = dict(hop_length=hop, center=center, window=window, feature_params={"mfcc": {"n_mels": n_mels}})
     a = extract_features_batch(Y, 22050 if n_mels == 26 else 48000, feats, **kw)
-    os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"] = "0"
-    try:
+    with ops.override(one_launch_features=False):
         b = extract_features_batch(Y, 22050 if n_mels == 26 else 48000, feats, **kw)
-    finally:
-        del os.environ["SYGNALS_AMD_ONE_LAUNCH_FEATURES"]
     assert list(a) == list(b) and len(a) > 1
     for k in a:
         if k.startswith("mfcc_"):

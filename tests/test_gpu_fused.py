@@ -62,7 +62,7 @@ def test_mel_projection_plans(ops, clips, monkeypatch, waves, n_mels, sr, fmin, 
     extra-step loop), both workgroup shapes -- mel power against the float64 product with the same float32 basis."""
     if n_mels > 128 and waves == 8:
         pytest.skip("more than 32 groups of four rows need the 16-wave plan")
-    monkeypatch.setenv("SYGNALS_AMD_WAVES", str(waves))
+    monkeypatch.setattr(ops.settings, "waves", waves)
     y = ops.to_device_f32(clips[:3])
     mel, _, _ = ops.stft2048_mel(y, sr, n_mels=n_mels, fmin=fmin, fmax=fmax)
     mel = mel.cpu().numpy()
@@ -403,16 +403,22 @@ def test_mfcc_batch_other_frame_lengths(n_fft, hop, n_mels):
 
 
 def test_reserved_cus_change_shares_not_results(monkeypatch):
-    """SYGNALS_AMD_RESERVE_CUS leaves compute units out of the persistent grids (room for a collective's workgroups):
+    """syg_set_option(SYG_OPT_RESERVED_CUS) leaves compute units out of the persistent grids (room for a collective's workgroups):
     other tile / clip shares per workgroup, the same bits."""
     from sygnals_amd import ops
     Y = ops.to_device_f32(O.synth_clips(300, 30000, 48000, seed=3))
     ref1 = ops.mfcc_batch(Y, 48000, n_mels=40, fused=True)
     ref2 = ops.mfcc_batch(Y, 48000, n_mels=40, fused=False)
-    for r in ("32", "200", "255", "1000", "junk"):
-        monkeypatch.setenv("SYGNALS_AMD_RESERVE_CUS", r)
-        assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=True), ref1), r
-        assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=False), ref2), r
+    for r in (32, 200, 255):
+        with ops.override(reserved_cus=r):
+            assert ops.get_option("reserved_cus") == r
+            assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=True), ref1), r
+            assert torch.equal(ops.mfcc_batch(Y, 48000, n_mels=40, fused=False), ref2), r
+    assert ops.get_option("reserved_cus") == 0
+    for bad in (-1, 256, 1000):                                  # out of range: refused, the option keeps its value
+        with pytest.raises(ops.SygnalsHipError):
+            ops.set_reserved_cus(bad)
+    assert ops.get_option("reserved_cus") == 0
 
 
 @pytest.mark.parametrize("form", ["segments", "matrix"])

@@ -166,10 +166,9 @@ def test_sosfiltfilt_clip_resident_lengths(ops, L, monkeypatch):
     rng = np.random.default_rng(L)
     x = np.stack([rng.normal(0, 0.3, L) + 0.7, np.sin(np.arange(L) * 0.05) * (1 + rng.normal(0, 0.01, L)),
                   rng.normal(0, 1.0, L)]).astype(np.float32)
-    monkeypatch.setenv("SYGNALS_AMD_SOS_CLIP", "1")
     y = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
-    monkeypatch.setenv("SYGNALS_AMD_SOS_CLIP", "0")
-    yc = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
+    with ops.override(sos_clip=0):
+        yc = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), 27).cpu().numpy()
     for i in range(3):
         ref = O.apply_sos_filter(sos, x[i].astype(np.float64))
         assert_parity(y[i], ref, TOL, f"L={L} row {i}")

@@ -200,6 +200,38 @@ def test_frame_count_rule():
         assert ops.num_frames(L, n, h, c) == O.num_frames(L, n, h, c)
 
 
+def test_statistics_route_condition_mirrors_the_c_side():
+    """manager.py picks syg_stft2048_stats_f32 only where that entry point accepts the call (hop <= 512, L < 2^28, fewer
+    than 2^24 frames): a very long clip falls through to the mel route instead of raising."""
+    from sygnals_amd import ops
+    assert ops.stft2048_stats_fits(512, 48000) and ops.stft2048_stats_fits(1, 48000)
+    assert not ops.stft2048_stats_fits(513, 48000)
+    assert not ops.stft2048_stats_fits(512, 1 << 28) and ops.stft2048_stats_fits(512, (1 << 28) - 1)
+    assert not ops.stft2048_stats_fits(1, (1 << 24) + 5)
+
+
+def test_library_options_and_settings_do_not_read_the_environment(monkeypatch):
+    """The library's switches are syg_set_option values, the Python side's are ops.settings attributes: no getenv in the
+    product sources, and an environment variable of the old names changes nothing."""
+    from sygnals_amd import ops
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sygnals_amd", "csrc")):
+        for f in files:
+            assert "getenv" not in open(os.path.join(dirpath, f)).read(), f
+    monkeypatch.setenv("SYGNALS_AMD_RESERVE_CUS", "32")
+    monkeypatch.setenv("SYGNALS_AMD_WAVES", "8")
+    assert ops.get_option("reserved_cus") == 0 and ops.fused_waves() == 16
+    with ops.override(reserved_cus=16, stft_load=1, sos_clip=0, cqt_staged=2, cqt_mode="fft", waves=8):
+        assert [ops.get_option(k) for k in ("reserved_cus", "stft_load", "sos_clip", "cqt_staged")] == [16, 1, 0, 2]
+        assert ops.settings.cqt_mode == "fft" and ops.fused_waves() == 8
+    assert [ops.get_option(k) for k in ("reserved_cus", "stft_load", "sos_clip", "cqt_staged")] == [0, -1, 1, -1]
+    assert ops.settings.cqt_mode == "bf16x3" and ops.fused_waves() == 16
+    with pytest.raises(ops.SygnalsHipError):
+        ops.set_option("stft_load", 3)
+    with pytest.raises(KeyError):
+        with ops.override(no_such_switch=1):
+            pass
+
+
 def test_product_never_imports_the_oracle():
     """The product path must not route through oracle/ (or any CPU fallback)."""
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|cpu_ref", re.M)

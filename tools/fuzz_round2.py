@@ -70,10 +70,9 @@ for it in range(N):
         except Exception:
             continue
         outs = []
-        for st in ("2", "1", "0"):
-            os.environ["SYGNALS_AMD_CQT_STAGED"] = st
-            outs.append(ops.cqt(xd, sr, hop_length=hop, n_bins=n_bins))
-        os.environ.pop("SYGNALS_AMD_CQT_STAGED")
+        for st in (2, 1, 0):
+            with ops.override(cqt_staged=st):
+                outs.append(ops.cqt(xd, sr, hop_length=hop, n_bins=n_bins))
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), ("cqt staged bits", sr, hop, n_bins, Lc)
         g = outs[0][0].cpu().numpy()
         track("cqt", g[..., 0] + 1j * g[..., 1], want)

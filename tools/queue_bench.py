@@ -22,7 +22,7 @@ res = {}
 for busy in (0, 8, 16):
     for name, fused, reserve in (("one launch, all CUs", True, 0), ("two launches, all CUs", False, 0),
                                  ("two launches, 16 CUs set aside", False, 16), ("one launch, 16 CUs set aside", True, 16)):
-        os.environ["SYGNALS_AMD_RESERVE_CUS"] = str(reserve)
+        ops.set_reserved_cus(reserve)
         def step():
             if busy:
                 side.wait_stream(torch.cuda.current_stream())
@@ -32,5 +32,5 @@ for busy in (0, 8, 16):
         torch.cuda.synchronize()
         res[f"{name}; {busy} CUs held by another kernel"] = round(t * 1e6, 1)
         print(f"{name:32s} {busy:3d} CUs held by another kernel: {t * 1e6:7.1f} us per step", flush=True)
-os.environ["SYGNALS_AMD_RESERVE_CUS"] = "0"
+ops.set_reserved_cus(0)
 json.dump(res, open("gpurun_out/queue_r01.json", "w"), indent=1)

@@ -8,5 +8,5 @@ B, L, SR = 1024, 48000, 48000
 y = ops.to_device_f32(np.tile(O.synth_clips(64, L, SR, seed=1), (B // 64, 1)))
 for _ in range(300): ops.mfcc_batch(y, SR, n_mels=40)
 for r in (0, 8, 16, 24, 32, 48):
-    os.environ["SYGNALS_AMD_RESERVE_CUS"] = str(r)
+    ops.set_reserved_cus(r)
     print(r, "reserved:", round(timeit(lambda: ops.mfcc_batch(y, SR, n_mels=40, fused=False), 200, 50) * 1e6, 1), "us two-launch")

@@ -2,7 +2,7 @@
 Prints one line per row: time, input Msamples/s and algorithmic GB/s (bytes per SURVEY 8d).
 
     python tools/row_bench.py [substring ...]     only the rows whose name contains one of the substrings
-    ROWS_OUT=path                                 where the JSON goes (default gpurun_out/rows_r03.json)
+    ROWS_OUT=path                                 where the JSON goes (default gpurun_out/rows_r04.json)
 """
 import json, os, sys, time
 import numpy as np, torch
@@ -40,6 +40,29 @@ ops.mfcc_batch(y, SR, n_mels=40); torch.cuda.synchronize()
 for _ in range(300): ops.mfcc_batch(y, SR, n_mels=40)       # clock warm-up
 Tn = 94
 report("C2 a1-a5 STFT->mel->MFCC (one launch)", lambda: ops.mfcc_batch(y, SR, n_mels=40), B * L, B * (4 * L + 4 * 13 * Tn), n=100)
+# the reference's DEFAULT filterbank (manager.py:214: n_mels = 128; features_cmd.py:82-90 passes no feature_params, so
+# `sygnals features extract -f mfcc` -- BASELINE config C1 -- always runs 128 bands), and 64 bands
+for nm in (128, 64):
+    report(f"a1-a5 STFT->mel->MFCC n_fft=2048 n_mels={nm}" + (" (the reference's default)" if nm == 128 else "") + ", 1024 clips",
+           lambda: ops.mfcc_batch(y, SR, n_mels=nm), B * L, B * (4 * L + 4 * 13 * Tn), n=50)
+if want("C1 one clip"):
+    y1 = ops.to_device_f32(synth_clips(1, 160000, 16000, seed=3))
+    report("C1 one clip 10 s @ 16 kHz n_mels=128 (device part of `features extract -f mfcc`)", lambda: ops.mfcc_batch(y1, 16000, n_mels=128),
+           160000, 4 * 160000 + 4 * 13 * 313, "one clip: launch-bound, one workgroup busy", n=50)
+    y1b = ops.to_device_f32(synth_clips(256, 160000, 16000, seed=3))
+    report("C1-shaped batch: 256 clips x 10 s @ 16 kHz n_mels=128", lambda: ops.mfcc_batch(y1b, 16000, n_mels=128),
+           256 * 160000, 256 * (4 * 160000 + 4 * 13 * 313), n=20)
+    del y1, y1b
+# the reference's own manager tests: frame_length=1024 with spectral features (tests/test_features_manager.py:58-62,167-174)
+if want("n_fft=1024 manager"):
+    from sygnals_amd.core.features.manager import extract_features_batch
+    T4 = 1 + L // 256
+    report("a6-a9 n_fft=1024 hop=256: centroid + rolloff through extract_features_batch (device resident), 1024 clips",
+           lambda: extract_features_batch(y, SR, ["spectral_centroid", "spectral_rolloff"], 1024, 256, to_host=False), B * L,
+           B * (4 * L + 4 * 2 * T4), n=5, warm=2)
+    report("C4-style block n_fft=1024 hop=256: mfcc(40) + centroid + rolloff + contrast through extract_features_batch, 1024 clips",
+           lambda: extract_features_batch(y, SR, ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"], 1024, 256,
+                                          feature_params={"mfcc": {"n_mels": 40}}, to_host=False), B * L, B * (4 * L + 4 * 22 * T4), n=5, warm=2)
 report("a1 complex STFT 2048/512 (frame-major c64 out)", lambda: ops.stft2048_c2c(y[:256]), 256 * L, 256 * (4 * L + 8 * 1025 * Tn), "256 clips")
 # the other power-of-two frame lengths (the reference's tests: 1024 / 256): one launch, clip-resident
 for nf, hp in ((1024, 256), (512, 128), (256, 64)):
@@ -133,6 +156,6 @@ if want("f-3 convolution autocorrelation Hilbert periodogram"):
     report("f-3 Hilbert envelope, 1024 rows x 65536", lambda: D.envelope_batch(y65), 1024 * 65536, 1024 * 8 * 65536)
     report("f-3 Hilbert envelope, 1024 clips x 48000 (mixed radix 200 x 240)", lambda: D.envelope_batch(y), B * L, B * 8 * L, n=5, warm=2)
     report("f-3 periodogram, 1024 clips x 48000 (mixed radix 200 x 240)", lambda: D.periodogram_batch(y, fs=SR), B * L, B * (4 * L + 4 * (L // 2 + 1)), n=5, warm=2)
-out = os.environ.get("ROWS_OUT", "gpurun_out/rows_r03.json")
+out = os.environ.get("ROWS_OUT", "gpurun_out/rows_r04.json")
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
 json.dump(rows, open(out, "w"), indent=1)
