@@ -100,7 +100,10 @@ struct MelPlan {
   int table_off;    // offset (in floats) of the tables inside wpacked
 };
 constexpr int MTAB_INTS = 256;
-constexpr int SEGTAB_WORDS = 2 * 2 * 64 * 4;   // piece table of the segment-sum projection (pack_mel_segments)
+constexpr int SEGTAB_WORDS = 2 * 2 * 64 * 4;   // piece table of the segment-sum projection (pack_mel_segments), two passes
+constexpr int SEGTAB4_WORDS = 2 * SEGTAB_WORDS; // ... four passes (MODE 8 / 9: filterbanks of up to 256 pieces, e.g. 128 bands)
+constexpr int TRI4_ROW_BASE = 4;               // the four-pass tables are built with row_base = 4 (a short first piece needs room
+                                               // for its lead): the projection reads from 4 words in front of the power row
 
 struct ContrastPlan {
   int n_rows;
@@ -1170,13 +1173,16 @@ __device__ __noinline__ void clip_dct(int clipmel_addr, int red_addr, int dct_ad
 // Per tile: FFT(v) -> rows | barrier A | MFMA -> slab ; fetch the next frame into v | barrier B |
 //           start the DMA of the tile after next ; reduce + store [; statistics | barrier].
 // The DMA therefore runs behind the reduce and the whole next FFT phase, and is drained at barrier A.
-template <int WAVES, bool SLAB = true>
+template <int WAVES, bool SLAB = true, int NPASS = 2>
 struct Lds {
   static constexpr int TILE_T = WAVES;
-  static constexpr int P_FLOATS = TILE_T * P_STRIDE + 16;
+  // (four-pass tables: 16 words in front of the first row, so that row 0's lead words are inside the allocation)
+  static constexpr int O_P = (NPASS == 4) ? 16 : 0;
+  static constexpr int P_FLOATS = O_P + TILE_T * P_STRIDE + 16;
   static constexpr int SLAB_FLOATS = SLAB ? WAVES * 16 * TILE_T : 0;    // (MODE 6 projects per wave: no partial tiles)
   // contrast plan + the mel plan's slot / group tables; MODE 6: the piece table of the segment-sum projection instead
-  static constexpr int CPL_FLOATS = SLAB ? 3 * SYG_MAX_BANDS + MTAB_INTS : SEGTAB_WORDS + 3 * SYG_MAX_BANDS;
+  static constexpr int SEG_WORDS = NPASS * (SEGTAB_WORDS / 2);
+  static constexpr int CPL_FLOATS = SLAB ? 3 * SYG_MAX_BANDS + MTAB_INTS : SEG_WORDS + 3 * SYG_MAX_BANDS;
   static constexpr int STAGE_FLOATS = (WAVES - 1) * 512 + NFFT;
   static constexpr int O_SLAB = P_FLOATS;
   static constexpr int O_TW2 = O_SLAB + SLAB_FLOATS;
@@ -1198,27 +1204,34 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     float* __restrict__ contrast_out, float2* __restrict__ cout, int dma_wide, MfccArgs mf) {
   // MODE 6: MODE 3 with the per-wave projection by segment sums (tri_project); MODE 7: MODE 6 + the per-frame row
   // functions of MODE 1 (statistics / contrast): config C4's four features from one launch, no mel matrix in HBM
-  constexpr bool TRI = (MODE == 6 || MODE == 7);
-  typedef Lds<WAVES, !TRI> LM;
+  // MODE 8: the tile form of MODE 6 -- the per-wave projection with a FOUR-pass table (up to 256 pieces: the reference's
+  // default 128 bands, 64 bands at 44.1 / 48 kHz), every frame's mel column written straight to HBM (a 128-band clip
+  // matrix does not fit the LDS beside the rows; syg_logmel_dct_f32 is the second launch), tiles shared out evenly over
+  // the workgroups (no whole-clip chunks: one long clip fills the chip); MODE 9: MODE 8 + the row functions of MODE 7
+  constexpr bool TRIMEL = (MODE == 8 || MODE == 9);
+  constexpr bool TRI = (MODE == 6 || MODE == 7 || TRIMEL);
+  constexpr int NPASS = TRIMEL ? 4 : 2;
+  typedef Lds<WAVES, !TRI, NPASS> LM;
+  constexpr int SEG_WORDS = LM::SEG_WORDS;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr bool COMPLEX_OUT = (MODE == 2);
   // MODE 5 = MODE 1 (statistics / contrast rows) + MODE 3 (clip-resident dB + DCT): config C4's four features from ONE
   // launch -- only samples in, MFCCs + statistics rows + contrast tail means out (the mel matrix never reaches HBM)
-  constexpr bool ROWFN = (MODE == 1 || MODE == 5 || MODE == 7);      // per-frame row functions (MODE 1 / 5: behind barrier B)
-  constexpr bool CLIPM = (MODE == 3 || MODE == 5 || TRI);   // the clip's mel matrix lives in LDS; epilogue at clip end
+  constexpr bool ROWFN = (MODE == 1 || MODE == 5 || MODE == 7 || MODE == 9);   // per-frame row functions (MODE 1 / 5: behind barrier B)
+  constexpr bool CLIPM = (MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7);   // the clip's mel matrix lives in LDS; epilogue at clip end
   // MODE 0 / 3 (mel only): the power rows hold 4 |X|^2 (wave_rfft2048<.., X2>); the factor is taken back -- exactly, a
   // power of two -- where mel values leave the kernel (MODE 0: at the store; MODE 3: the dB conversion works on 4 x mel
   // with 4 x amin and 4 x ref, the optional mel copy is scaled at its store).  MODE 1's statistics need the true powers.
-  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || MODE == 6);
+  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || MODE == 6 || MODE == 8);
   constexpr float MELSC = X2 ? 0.25f : 1.f;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Pbuf = lds;
+  float* Pbuf = lds + LM::O_P;
   float* slab = lds + LM::O_SLAB;
   float2* tw2l = reinterpret_cast<float2*>(lds + LM::O_TW2);        // [4][18] complex
   float2* tw1l = reinterpret_cast<float2*>(lds + LM::O_TW1);        // [15][64] complex
   int* cpl = reinterpret_cast<int*>(lds + LM::O_CPL);
-  int* cplc = TRI ? cpl + SEGTAB_WORDS : cpl;        // contrast plan (MODE 6 / 7: behind the piece table)
+  int* cplc = TRI ? cpl + SEG_WORDS : cpl;           // contrast plan (MODE 6 ... 9: behind the piece table)
   float2* winl = reinterpret_cast<float2*>(lds + LM::O_WIN);
   float* stage = lds + LM::O_STAGE;
   float* clipmel = lds + LM::TOTAL;                 // MODE 3: [n_mels][mf.tp], red[WAVES], dct rows, lifter
@@ -1269,12 +1282,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   if (!COMPLEX_OUT) {
     // pad words of the skewed rows, the row tails and the slack are read against zero weights: they must
     // hold finite values, so the whole buffer (and the slab behind it) is cleared once
-    for (int i = tid; i < LM::P_FLOATS + LM::SLAB_FLOATS; i += NTHREADS) Pbuf[i] = 0.f;
+    for (int i = tid; i < LM::P_FLOATS + LM::SLAB_FLOATS; i += NTHREADS) lds[i] = 0.f;
     if (TRI && wpacked != nullptr) {                    // (no table: statistics only, nothing is projected)
-      for (int i = tid; i < SEGTAB_WORDS; i += NTHREADS) {
-        // (word 1 of a lane's first 16 bytes: the band it stores -> that band's byte offset inside a mel matrix)
+      // (word 1 of a lane's first 16 bytes: the band it stores -> that band's byte offset inside a mel matrix -- the
+      // clip's LDS matrix [n_mels][tp], or (MODE 8 / 9) the clip's [n_mels][T] block of mel_out)
+      const int band_bytes = (TRIMEL ? (int)T : mf.tp) * 4;
+      for (int i = tid; i < SEG_WORDS; i += NTHREADS) {
         int v = reinterpret_cast<const int*>(wpacked)[i];
-        if ((i & 3) == 1 && ((i >> 8) & 1) == 0 && v >= 0) v *= mf.tp * 4;
+        if ((i & 3) == 1 && ((i >> 8) & 1) == 0 && v >= 0) v *= band_bytes;
         cpl[i] = v;
       }
     }
@@ -1296,12 +1311,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   // epilogue of the clip before (at most three output tiles each: it must stay shorter than a transform)
   bool tri_scan8 = false;
   if (TRI && wpacked != nullptr) {
-    const unsigned lk = (unsigned)(cpl[4 * lane + 2] | cpl[4 * lane + 3] | cpl[4 * (128 + lane) + 2] | cpl[4 * (128 + lane) + 3]);
+    unsigned lk = 0;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) lk |= (unsigned)(cpl[4 * (128 * p + lane) + 2] | cpl[4 * (128 * p + lane) + 3]);
     tri_scan8 = __builtin_amdgcn_ballot_w64((lk >> 24) != 0) != 0;
   }
   const int tri_ndct = ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4);
-  const int tri_idle = TRI ? mf.tp - (int)T : 0;
-  const bool tri_defer = TRI && tri_idle > 0 && (tri_ndct + tri_idle - 1) / tri_idle <= 3;
+  const int tri_idle = (TRI && !TRIMEL) ? mf.tp - (int)T : 0;
+  const bool tri_defer = TRI && !TRIMEL && tri_idle > 0 && (tri_ndct + tri_idle - 1) / tri_idle <= 3;
   // staged mode: the frame of the NEXT tile is fetched (LDS -> registers) one phase ahead, so that the stage
   // buffer can be refilled behind the FFT phase; direct modes load at the top of the tile loop
   float2 v[16];
@@ -1444,11 +1461,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         asm volatile("" : "+v"(la)::"memory");
         wave_lds_sync();
         // (the table's band word was turned into the band's BYTE offset inside a mel matrix when the workgroup copied it)
-        char* colb = reinterpret_cast<char*>(cmc + (int)t);
-        tri_project<2>(prow, reinterpret_cast<const float4*>(cpl), la, tri_scan8, [&](int boff, float v) {
-          *reinterpret_cast<float*>(colb + boff) = v;
-          asm("v_max_f32_e32 %0, %0, %1" : "+v"(cmax) : "v"(v));
-        });
+        if (TRIMEL) {
+          char* colg = reinterpret_cast<char*>(mel_out + (b * n_mels) * T + t);
+          tri_project<4>(prow - TRI4_ROW_BASE, reinterpret_cast<const float4*>(cpl), la, tri_scan8,
+                         [&](int boff, float v) { *reinterpret_cast<float*>(colg + boff) = MELSC * v; });
+        } else {
+          char* colb = reinterpret_cast<char*>(cmc + (int)t);
+          tri_project<2>(prow, reinterpret_cast<const float4*>(cpl), la, tri_scan8, [&](int boff, float v) {
+            *reinterpret_cast<float*>(colb + boff) = v;
+            asm("v_max_f32_e32 %0, %0, %1" : "+v"(cmax) : "v"(v));
+          });
+        }
       };
       auto publish_max = [&]() {
         const float cm = wave_max(cmax);
@@ -1496,7 +1519,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         row_compute();
         prow[lane] = row_sres; prow[64 + lane] = row_pv.x; prow[128 + lane] = row_pv.y;
       }
-      if (clip_done && !proj_late) publish_max();
+      if (CLIPM && clip_done && !proj_late) publish_max();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                  // X1: the clip's columns of this tile are written too
       if (LOAD == 2) {
@@ -1509,7 +1532,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         if (mine && tri_proj) project();
         if (clip_done) publish_max();
       }
-      if (clip_done) {
+      if (CLIPM && clip_done) {
         // (clip_dct's entry waits for outstanding memory operations, so the refill is issued behind it)
         if (tri_defer) pend_b = mf.n_mfcc > 0 ? (int64_t)b : pend_b;
         else if (w < tri_ndct && SYG_TRIX != 1)
@@ -1743,7 +1766,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       if (FETCH_EARLY && tile + 2 < tile_end) dma(tile + 2);
     }
   }
-  if (TRI) {
+  if (TRIMEL) {
+    // (no clip epilogue: the mel columns are in HBM)
+  } else if (TRI) {
     // (deferred epilogue: the last clip's matrix is complete behind X1 of its last tile -- or, with the projections of half
     // of the waves behind the barriers, behind one more)
     if (SYG_P6SPLIT && !ROWFN && LOAD == 2 && tri_defer && tiles_per_clip >= 2) __syncthreads();
@@ -1765,9 +1790,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #endif
 }
 
-template <int WAVES, bool SLAB = true>
+template <int WAVES, bool SLAB = true, int NPASS = 2>
 constexpr size_t lds_bytes() {
-  return (size_t)Lds<WAVES, SLAB>::TOTAL * sizeof(float);
+  return (size_t)Lds<WAVES, SLAB, NPASS>::TOTAL * sizeof(float);
 }
 
 // Workgroups per CU: two of 8 waves or one of 16; each takes a contiguous chunk of tiles.
@@ -1824,8 +1849,10 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   const int64_t total_tiles = B * tiles;
   int wgs = 0, per = 0;
   persistent_grid(total_tiles, WAVES, wgs, per);
+  constexpr bool TRIMEL = (MODE == 8 || MODE == 9);      // tile form of the segment-sum projection, four-pass table
   constexpr bool TRI = (MODE == 6 || MODE == 7);
-  size_t lds = lds_bytes<WAVES, !TRI>();
+  size_t lds = TRIMEL ? lds_bytes<WAVES, false, 4>() : lds_bytes<WAVES, !TRI>();
+  if (TRIMEL) mf.tp = tiles * WAVES;
   if (MODE == 3 || MODE == 5 || TRI) {
     // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
     int cw = 0, cper = 0;
@@ -1849,7 +1876,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   {
     // set at every launch: the attribute belongs to the (function, device) pair, and a per-process "already set"
     // flag would leave a second device without it
-    const size_t cap = (MODE == 3 || MODE == 5 || TRI) ? LDS_LIMIT : lds_bytes<WAVES>();
+    const size_t cap = (MODE == 3 || MODE == 5 || TRI) ? LDS_LIMIT : TRIMEL ? lds_bytes<WAVES, false, 4>() : lds_bytes<WAVES>();
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
@@ -2047,6 +2074,44 @@ extern "C" int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t 
   return launch<16, 7>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, nullptr,
                        sr / (float)NFFT, roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr,
                        (hipStream_t)stream, mf);
+}
+
+// MODE 8 / 9: the TILE form of the segment-sum projection with a FOUR-pass piece table (up to 256 pieces: the reference's
+// default filterbank of 128 bands, manager.py:214, and 64 ... 128 bands at the usual sample rates, which have no two-pass
+// table) -- samples in, mel POWER out [B, n_mels, T] (no weight matrix, no projection barriers, every frame's column written
+// by the wave that transformed it); syg_logmel_dct_f32 is the second launch of an MFCC.  Optional statistics / contrast
+// rows from the same launch (MODE 9: the row functions of syg_stft2048_features_tri_f32).  Tiles are shared out evenly
+// over the workgroups, so one long clip (BASELINE config C1) fills the chip.
+//   segtab   pack_mel_segments(..., n_pass=4, row_base=4): [4][2][64][4] words, n_segtab = 2048
+extern "C" int syg_stft2048_mel_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                                        const float* window, const float* twiddle, const float* segtab, int n_segtab,
+                                        int n_mels, float* mel_out, float sr, float roll_percent, float bw_p, int stats_mask,
+                                        float* stats_out, const int32_t* cplan_host, float* contrast_out, void* stream) {
+  SYG_REQUIRE(segtab && mel_out, "stft2048_mel_tri: null pointer argument");
+  SYG_REQUIRE(n_segtab == SEGTAB4_WORDS, "stft2048_mel_tri: the piece table has %d words, this library reads %d "
+              "(sygnals_amd._tables.pack_mel_segments(..., n_pass=4, row_base=4))", n_segtab, SEGTAB4_WORDS);
+  SYG_REQUIRE(((uintptr_t)segtab) % 16 == 0, "stft2048_mel_tri: the piece table must be 16-byte aligned");
+  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
+  if (rc) return rc;
+  SYG_REQUIRE(n_mels >= 1 && n_mels <= 255, "stft2048_mel_tri: need 1 <= n_mels <= 255 (got %d)", n_mels);
+  SYG_REQUIRE(T * (int64_t)n_mels < ((int64_t)1 << 29), "stft2048_mel_tri: clip too long (32-bit byte offsets inside a clip's mel block)");
+  ContrastPlan cp;
+  rc = parse_contrast_plan(contrast_out, cplan_host, cp);
+  if (rc) return rc;
+  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && (stats_mask & 31) != 0 &&
+                                 stats_mask > 0 && stats_mask < 64, "stft2048_mel_tri: invalid statistics parameters");
+  MelPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  MfccArgs mf;
+  memset(&mf, 0, sizeof(mf));
+  mf.amin = 1e-10f; mf.top_db = -1.f;
+  const bool extra = stats_out != nullptr || contrast_out != nullptr;
+  if (extra)
+    return launch<16, 9>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, mel_out,
+                         sr / (float)NFFT, roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr,
+                         (hipStream_t)stream, mf);
+  return launch<16, 8>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, mel_out, 0.f, 0.f,
+                       0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
 }
 
 // MODE 7 without a filterbank: the per-frame statistics / contrast tail means alone (spectral_centroid / bandwidth /

@@ -180,11 +180,20 @@ class MelConfig:
         # piece table of the per-wave projection by segment sums (MODE 6 of the fused kernel): triangular filterbanks
         # whose pieces fit 128 lane slots (n_mels = 40 at any usual rate; 64 and more do not)
         self.segtab = None
+        # ... and the four-pass table of the tile form (MODE 8 / 9: up to 256 pieces -- the reference's default of 128
+        # bands, 64 ... 128 bands at the usual rates; row_base 4: a short first piece needs room for its lead)
+        self.segtab4 = None
         if n_fft == 2048:
             try:
                 self.segtab = _dev(T.pack_mel_segments(sr, n_fft, n_mels, fmin, fmax, basis=basis).reshape(-1))
             except ValueError:
                 pass
+            if n_mels <= 255:
+                try:
+                    self.segtab4 = _dev(T.pack_mel_segments(sr, n_fft, n_mels, fmin, fmax, basis=basis, n_pass=4,
+                                                            row_base=4).reshape(-1))
+                except ValueError:
+                    pass
 
 
 def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None, waves=None) -> MelConfig:
@@ -195,9 +204,13 @@ def mel_config(sr, n_fft, n_mels, fmin=0.0, fmax=None, waves=None) -> MelConfig:
 
 
 def fused_mel_ok(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> bool:
-    """True when the fused frame-length-2048 kernel has a block-sparse plan for this filterbank (n_mels <= 256, and
-    <= 128 in the 8-wave development mode); otherwise callers take the generic chain (stft_any -> mel_dense)."""
-    return n_fft == 2048 and 1 <= n_mels <= 256 and mel_config(sr, n_fft, n_mels, fmin, fmax).wpacked is not None
+    """True when the fused frame-length-2048 kernel has a block-sparse plan or a four-pass piece table for this filterbank
+    (n_mels <= 256, and <= 128 in the 8-wave development mode); otherwise callers take the generic chain
+    (stft_any -> mel_dense)."""
+    if n_fft != 2048 or not 1 <= n_mels <= 256:
+        return False
+    cfg = mel_config(sr, n_fft, n_mels, fmin, fmax)
+    return cfg.wpacked is not None or cfg.segtab4 is not None
 
 
 def fused_pow2_ok(n_fft, n_mels) -> bool:
@@ -409,10 +422,13 @@ def stft_mel_w4096(y: torch.Tensor, sr: float, hop: int = 1024, center: bool = T
 def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
                  win_length: int = 2048, n_mels: int = 128, fmin: float = 0.0, fmax=None,
                  want_stats=False, roll_percent: float = 0.85, bw_p: float = 2.0,
-                 contrast: Optional[np.ndarray] = None):
+                 contrast: Optional[np.ndarray] = None, projection: str = "auto"):
     """Fused STFT(2048) -> power -> mel.  Returns (mel [B, M, T], stats [B, 8, T] | None,
     contrast_pv [B, 2, R, T] | None).  `want_stats`: False, True (all rows) or a bit mask (1 centroid,
-    2 bandwidth, 4 flatness, 8 rolloff, 16 dominant): only the selected rows are computed / written."""
+    2 bandwidth, 4 flatness, 8 rolloff, 16 dominant): only the selected rows are computed / written.
+    projection: "segments" (syg_stft2048_mel_tri_f32: per-wave segment sums, four-pass table, no barriers in the
+    projection), "matrix" (syg_stft2048_mel_f32: block-sparse weights on the matrix cores), "auto": segments where the
+    filterbank has a table and the 16-wave kernel is selected."""
     smask = 31 if want_stats is True else int(want_stats or 0)
     require_gpu()
     if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
@@ -424,7 +440,14 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
     if Tn <= 0:
         raise ValueError("signal too short for one frame")
     cfg = mel_config(sr, 2048, n_mels, fmin, fmax)
-    if cfg.wpacked is None:
+    if projection not in ("auto", "segments", "matrix"):
+        raise ValueError("projection must be 'auto', 'segments' or 'matrix'")
+    tri = cfg.segtab4 is not None and fused_waves() == 16 and Tn * n_mels < (1 << 29) and projection != "matrix"
+    if projection == "auto" and cfg.segtab is not None and cfg.wpacked is not None:
+        tri = False       # few pieces (a two-pass table exists, e.g. 40 bands): four passes would be half idle -- matrix form
+    if projection == "segments" and not tri:
+        raise SygnalsHipError("stft2048_mel: no four-pass piece table for this filterbank (projection='segments')")
+    if not tri and cfg.wpacked is None:
         raise SygnalsHipError("fused path: no block-sparse plan for this filterbank (n_mels <= 256; <= 128 with 8 waves)")
     win = window_dev(window, win_length, 2048)
     tw = twiddle_dev(2048)
@@ -436,6 +459,13 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
         cplan = np.ascontiguousarray(contrast, dtype=np.int32)
         cpv = torch.empty((B, 2, int(cplan[0]), Tn), dtype=torch.float32, device=y.device)
         cplan_p = cplan.ctypes.data_as(C.c_void_p)
+    if tri:
+        rc = lib().syg_stft2048_mel_tri_f32(
+            _ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(cfg.segtab4), int(cfg.segtab4.numel()),
+            n_mels, _ptr(mel), float(sr), float(roll_percent), float(bw_p), smask, _ptr(stats), cplan_p, _ptr(cpv),
+            C.c_void_p(_stream_ptr()))
+        check(rc, "syg_stft2048_mel_tri_f32")
+        return mel, stats, cpv
     rc = lib().syg_stft2048_mel_f32(
         _ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(cfg.wpacked),
         cfg.plan.ctypes.data_as(C.c_void_p), n_mels, _ptr(mel), float(sr), float(roll_percent), float(bw_p),

@@ -479,3 +479,62 @@ def test_mfcc_projection_forms_agree_on_random_shapes(ops):
         key = [k for k in ops._mfcc_calls if k[4] == float(sr) and k[8] == n_mels and k[-1] == "auto" and k[2] == L and k[5] == hop]
         seg += any(ops._mfcc_calls[k].tri for k in key)
     assert seg >= 8
+
+
+# ---------------------------------------------------------------- MODE 8 / 9: the tile form with a four-pass piece table
+@pytest.mark.parametrize("sr,n_mels,hop,center,L,fmin,fmax", [
+    (48000, 128, 512, True, 48000, 0.0, None),        # the reference's default filterbank (manager.py:214) on the C2 clip
+    (16000, 128, 512, True, 160000, 0.0, None),       # BASELINE config C1: 10 s @ 16 kHz (nearly empty low filters)
+    (44100, 64, 441, True, 30011, 0.0, None),         # odd hop: unaligned staged runs
+    (48000, 96, 1024, True, 50000, 100.0, 12000.0),   # hop > 512: direct frame loads
+    (22050, 128, 256, False, 9000, 0.0, None),        # center=False, four frames per 1024 samples
+    (48000, 40, 512, True, 2047, 0.0, None),          # a clip shorter than a frame (all padding but the middle)
+])
+def test_mel_tri_four_pass_matches_oracle_and_matrix_form(ops, sr, n_mels, hop, center, L, fmin, fmax):
+    """syg_stft2048_mel_tri_f32 (per-wave segment sums, four passes, mel columns written by the transforming wave) against
+    the float64 oracle at 1e-5 and against the matrix form of the projection (same float32 weights to 2e-7)."""
+    Y = O.synth_clips(5, L, sr, seed=L % 97)
+    Y[3] *= 1e-3
+    Y[4][:] = 0.0
+    y = ops.to_device_f32(Y)
+    a, _, _ = ops.stft2048_mel(y, sr, hop, center, "hann", 2048, n_mels, fmin, fmax, projection="segments")
+    b, _, _ = ops.stft2048_mel(y, sr, hop, center, "hann", 2048, n_mels, fmin, fmax, projection="matrix")
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert a.shape == b.shape and np.isfinite(a).all()
+    for i in range(5):
+        S = np.abs(O.stft(Y[i].astype(np.float64), 2048, hop, center=center)) ** 2
+        ref = O.melspectrogram(S, sr, 2048, n_mels, fmin, fmax if fmax is not None else sr / 2.0)
+        assert a[i].shape == ref.shape
+        assert_parity(a[i], ref, TOL, f"segments clip {i}")
+        assert_parity(b[i], ref, TOL, f"matrix clip {i}")
+    assert (a[4] == 0).all()
+
+
+def test_default_mfcc_128_bands_takes_the_segment_kernel(ops, clips):
+    """mfcc_batch with the reference's default n_mels = 128: the four-pass segment kernel + the dB / DCT launch, 1e-5 against
+    the oracle; C1's shape (one 10 s clip @ 16 kHz) likewise."""
+    cfg = ops.mel_config(48000, 2048, 128)
+    assert cfg.segtab is None and cfg.segtab4 is not None
+    out = ops.mfcc_batch(ops.to_device_f32(clips), 48000).cpu().numpy()          # (n_mels defaults to 128)
+    ref = O.mfcc_batch(clips, 48000, n_mels=128, n_mfcc=13)
+    assert peak_rel(out, ref) <= TOL
+    Y1 = O.synth_clips(1, 160000, 16000, seed=11)
+    out1 = ops.mfcc_batch(ops.to_device_f32(Y1), 16000).cpu().numpy()
+    assert out1.shape == (1, 13, 313)
+    assert peak_rel(out1, O.mfcc_batch(Y1, 16000, n_mels=128, n_mfcc=13)) <= TOL
+
+
+def test_mel_tri_rows_are_the_rows_of_the_statistics_kernel(ops):
+    """MODE 9 = MODE 8 + the row functions: statistics / contrast rows bit for bit those of syg_stft2048_stats_f32 (the same
+    functions on the same power rows), the mel block bit for bit MODE 8's."""
+    from sygnals_amd import _tables as T
+    sr = 48000
+    Y = O.synth_clips(6, 40000, sr, seed=5)
+    y = ops.to_device_f32(Y)
+    cplan = T.contrast_plan(np.fft.rfftfreq(2048, 1.0 / sr), sr)
+    mel, st, cpv = ops.stft2048_mel(y, sr, n_mels=128, want_stats=31, contrast=cplan, projection="segments")
+    st2, cpv2 = ops.stft2048_stats(y, sr, want_stats=31, contrast=cplan)
+    assert torch.equal(st, st2) and torch.equal(cpv, cpv2)
+    mel0, _, _ = ops.stft2048_mel(y, sr, n_mels=128, projection="segments")
+    # MODE 8 keeps 4 |X|^2 in the rows and scales the bands back (exact); MODE 9 keeps |X|^2: same sums up to that scaling
+    assert peak_rel(mel.cpu().numpy(), mel0.cpu().numpy()) <= 1e-6

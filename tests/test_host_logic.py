@@ -396,3 +396,38 @@ def test_mel_segment_table_four_passes_for_frame_length_4096():
     assert T.segments_read_cycles(tab) == 4 * 34
     with pytest.raises(ValueError):
         T.pack_mel_segments(48000, 4096, 128, n_pass=4)
+
+
+@pytest.mark.parametrize("sr,n_mels,fmin,fmax", [(48000, 128, 0.0, None), (16000, 128, 0.0, None), (22050, 128, 0.0, None),
+                                                 (44100, 64, 0.0, None), (48000, 64, 0.0, None), (48000, 96, 100.0, 12000.0),
+                                                 (8000, 128, 0.0, None), (48000, 40, 0.0, None), (32000, 160, 0.0, None)])
+def test_mel_segment_table_four_passes_for_the_default_filterbank(sr, n_mels, fmin, fmax):
+    """The tile form of the 2048 kernel (MODE 8 / 9, syg_stft2048_mel_tri_f32) reads a FOUR-pass table built with
+    row_base = 4: the reference's default of 128 bands (manager.py:214) and the other filterbanks without a two-pass table
+    are reproduced to 2e-7 of the largest weight; the float32 model of the kernel's sums agrees with the float64 product;
+    a window starts at most 4 words in front of bin 0 and ends at most 16 words behind the row's 1090 (masked words: they
+    lie in the next wave's row, or in the 16 slack words behind the last row -- inside the allocation either way)."""
+    from sygnals_amd import _tables as T
+    W = T.mel_filterbank(sr, 2048, n_mels, fmin, fmax)
+    tab = T.pack_mel_segments(sr, 2048, n_mels, fmin, fmax, basis=W, n_pass=4, row_base=4)
+    assert tab.shape == (4, 2, 64, 4) and tab.dtype == np.float32
+    assert np.abs(T.segments_weights(tab, n_mels, 1025, 4) - W).max() <= 2e-7 * W.max()
+    rng = np.random.default_rng(sr + n_mels)
+    for P in (rng.random(1025) ** 8 * 100.0, np.ones(1025)):
+        ref = W.astype(np.float64) @ P
+        got = T.segments_project(tab, P.astype(np.float32), n_mels, 4)
+        assert np.abs(got - ref).max() <= 1e-6 * ref.max()
+        # a band is right to 1e-7 of the powers under its filter times the filter's peak -- the row's local scale -- not to
+        # 1e-7 of its own value: a T0 + b T1 cancels where the power sits at the zero end of an edge (narrow filters, a
+        # spectrum of 8 decades as here: 2e-5 of a band 3 decades down, i.e. 1e-4 dB; the matrix form is there for callers
+        # who need such bands to the last bit)
+        nz = ref > 1e-4 * ref.max()
+        assert (np.abs(got - ref)[nz] / ref[nz]).max() <= 5e-5
+    ti = tab.view(np.int32)
+    w0 = ti[:, 0, :, 0]
+    live = ((w0 >> 16) & 0xFF) > 0
+    off = (w0 & 0xFFFF) // 4
+    assert (off[live] >= 0).all() and (off[live] + 17 <= 4 + 1090 + 16).all()
+    bands = ti[:, 0, :, 1].ravel()
+    assert sorted(bands[bands >= 0].tolist()) == list(range(n_mels))
+    assert int(ti[3, 0, 63, 1]) < 0                                        # the last lane never stores a band
