@@ -41,6 +41,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one BLAS / OpenMP thread per process, set BEFORE numpy loads its BLAS: the CPU baseline runs one process per core, and a
+# forked worker whose BLAS pool was sized for every core of the box (256 here) turns 256 workers into 65 536 threads
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_k, "1")
 
 import numpy as np
 
@@ -65,8 +69,11 @@ def _cpu_worker(args):
     """n clips through the oracle's C2 chain, one clip per call; returns the seconds spent IN the chain (the synthesis of the
     worker's 32 distinct clips is not part of the path and not timed)."""
     seed, n = args
-    for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-        os.environ[k] = "1"
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
     from oracle import cpu_ref as O
     Y = O.synth_clips(min(32, n), L, SR, seed=seed)
     el, done = 0.0, 0

@@ -108,20 +108,6 @@ int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int 
                          float sr, float roll_percent, float bw_p, int stats_mask, float* stats_out,
                          const int32_t* cplan_host, float* contrast_out, void* stream);
 
-/* The statistics / contrast rows of syg_stft2048_mel_f32 AND the clip-resident MFCC of syg_stft2048_mfcc_f32 from ONE
- * launch: extract_features(["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]) (BASELINE config C4,
- * manager.py:289-371) with only the samples read and the feature rows written -- the mel matrix never reaches HBM.
- * Arguments as in those two entry points (at least one of stats_out / contrast_out; mel_out optional).  The MFCC rows
- * of clip b go to mfcc_out + (b * mfcc_rows_per_clip) * T: with mfcc_rows_per_clip > n_mfcc they are the head of a
- * wider per-clip block whose other rows syg_feature_block_f32(mel = NULL, ...) fills.  The clip's mel matrix must fit
- * the LDS (syg_stft2048_mfcc_fits). */
-int syg_stft2048_features_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
-                              const float* window, const float* twiddle, const float* wpacked, const int32_t* plan_host,
-                              int n_mels, const float* dct, int n_mfcc, const float* lifter, float amin, float top_db,
-                              int ref_is_max, float ref_value, float sr, float roll_percent, float bw_p, int stats_mask,
-                              float* stats_out, const int32_t* cplan_host, float* contrast_out, float* mel_out,
-                              float* mfcc_out, int mfcc_rows_per_clip, void* stream);
-
 /* Same front end, complex STFT output (librosa.stft as called by compute_stft,
  * sygnals/core/dsp.py:167-229).  out [B, T, 1025] complex64, FRAME-major. */
 int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
@@ -164,10 +150,12 @@ int syg_stft2048_mfcc_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy,
                               float amin, float top_db, int ref_is_max, float ref_value, float* mfcc_out,
                               void* stream);
 
-/* syg_stft2048_features_f32 with the segment-sum projection of syg_stft2048_mfcc_tri_f32: BASELINE config C4
- * (extract_features(["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]), manager.py:289-371) from
- * one launch, no mel matrix in HBM.  Arguments as syg_stft2048_features_f32 with segtab / n_segtab in place of
- * wpacked / plan_host and no mel_out; shapes that fit: syg_stft2048_mfcc_tri_fits(). */
+/* The statistics / contrast rows of syg_stft2048_mel_f32 AND the clip-resident MFCC of syg_stft2048_mfcc_tri_f32 from ONE
+ * launch: extract_features(["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]) (BASELINE config C4,
+ * manager.py:289-371) with only the samples read and the feature rows written -- the mel matrix never reaches HBM.
+ * Arguments as in those two entry points (at least one of stats_out / contrast_out).  The MFCC rows of clip b go to
+ * mfcc_out + (b * mfcc_rows_per_clip) * T: with mfcc_rows_per_clip > n_mfcc they are the head of a wider per-clip block
+ * whose other rows syg_feature_block_f32(mel = NULL, ...) fills.  Shapes that fit: syg_stft2048_mfcc_tri_fits(). */
 int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                                   const float* window, const float* twiddle, const float* segtab, int n_segtab,
                                   int n_mels, const float* dct, int n_mfcc, const float* lifter, float amin,
@@ -216,6 +204,17 @@ int syg_stft_mel_w4096_f32(const float* y, int64_t B, int64_t L, int64_t ldy, in
 int syg_stft_mel_w1024_seg_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                                const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
                                float* mel_out, void* stream);
+
+/* syg_stft_mel_w1024_seg_f32 with the per-frame statistics / contrast rows of syg_stft2048_mel_f32 from the same launch
+ * (bins 0 .. 512, bin frequency k sr / 1024): extract_features(frame_length=1024, [spectral features ...]) -- the call of
+ * the reference's own manager tests (tests/test_features_manager.py:58-62, 167-174; manager.py:289-343 over
+ * frequency_domain.py:24-386) -- without a spectrogram in HBM.  stats_out [B, SYG_NSTAT, T] (rows selected by stats_mask)
+ * and / or cplan_host + contrast_out [B, 2, n_rows, T]: at least one.  The mel block is optional: segtab == NULL and
+ * mel_out == NULL compute the rows alone. */
+int syg_stft_rows_w1024_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                            const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
+                            float* mel_out, float sr, float roll_percent, float bw_p, int stats_mask, float* stats_out,
+                            const int32_t* cplan_host, float* contrast_out, void* stream);
 
 /* The same for frame_length 512 and 256 (256: the reference's short-signal tests): a wave owns four / eight frames per
  * transform and projects its four / eight power rows.  segtab: pack_mel_segments_rows(sr, n_fft, n_mels, fmin, fmax,
@@ -394,7 +393,7 @@ int syg_welch_f32(const float* x, int64_t B, int64_t L, int64_t ldx, int nperseg
  *   K + 2 ..      spectral contrast dB rows from contrast_pv [B, 2, R, T] (peak, valley)    (frequency_domain.py:200-207)
  * -- the columns extract_features(["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"]) returns, in
  * order: the [B/W, 22, 94] block a rank contributes to config C4's gather.  stats: [B, SYG_NSTAT, T].
- * mel == NULL (dct may then be NULL too): rows 0 .. K-1 are left as they are -- syg_stft2048_features_f32 has
+ * mel == NULL (dct may then be NULL too): rows 0 .. K-1 are left as they are -- syg_stft2048_features_tri_f32 has
  * written the MFCCs there -- and only the statistics / contrast rows are filled.
  * ------------------------------------------------------------------------------- */
 int syg_feature_block_f32(const float* mel, int64_t B, int M, int64_t T, const float* dct, int K, float amin,

@@ -170,6 +170,17 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 mel, stats, cpv = ops.stft2048_mel(yd, sr, hop_length, center, window, 2048, n_mels if want_mfcc else 16,
                                                    fmin, fmax, want_stats, roll, bw_p, cplan)
                 t_stft = Tn
+            elif (frame_length == 1024 and (want_stats or want_contrast) and
+                  (not want_mfcc or (power in (1.0, 2.0) and ops.fused_pow2_ok(1024, n_mels)))):
+                # frame length 1024 with spectral features (the reference's own manager tests: tests/test_features_manager.py:
+                # 58-62, 167-174): the rows from the segment-sum kernel's launch, no spectrogram in HBM; the mel block from the
+                # same launch where the filterbank has a piece table (power 2), else from the dense-matrix kernel
+                seg_mel = want_mfcc and power == 2.0 and ops.w1024_segtab(sr, n_mels, fmin, fmax) is not None
+                mel, stats, cpv = ops.stft_rows_w1024(yd, sr, hop_length, center, window, None, n_mels if seg_mel else None,
+                                                      fmin, fmax, want_stats, roll, bw_p, cplan)
+                if want_mfcc and not seg_mel:
+                    mel = ops.stft_mel_pow2(yd, sr, 1024, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
+                t_stft = Tn
             elif (want_mfcc and not (want_stats or want_contrast) and power == 2.0 and
                   (mel := ops.stft_mel_segments(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax)) is not None):
                 # only the mel spectrogram is needed: the segment-sum kernel of this frame length (1024 / 512 / 256 / 4096)
@@ -392,40 +403,29 @@ def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: i
     st = C.c_void_p(ops._stream_ptr())
     # one_launch: everything from ONE fused launch -- samples in; MFCC rows straight into the head of the block,
     # statistics rows and contrast tail means out (the mel matrix stays in LDS) -- then the small kernel that turns those
-    # into the block's other rows.  With a piece table for the filterbank that launch is syg_stft2048_features_tri_f32
-    # (each wave projects its own row by segment sums; the clip epilogue runs on waves that have no frame), else
-    # syg_stft2048_features_f32 (matrix form: measured SLOWER than the two launches below, 735 vs 724 us per 2048 clips,
-    # because the clip epilogue occupies six of the sixteen waves while the others wait at the tile barrier).
-    # one_launch=None picks the default (TRI_FEATURES_DEFAULT), True insists on one launch (segment form where it applies),
-    # "segments" / "matrix" on that form of it, False on two launches.
+    # into the block's other rows: syg_stft2048_features_tri_f32 (each wave projects its own row by segment sums; the clip
+    # epilogue runs on waves that have no frame).  Needs a two-pass piece table for the filterbank and the clip's mel
+    # matrix in LDS (n_mels = 40: yes; 128: no).  one_launch=None picks it where it applies, True insists, False takes
+    # the two launches below.  (Round 3's matrix form of the one launch lost to the two launches, 735 vs 724 us per 2048
+    # clips, and is gone.)
     cfg = ops.mel_config(sr, 2048, n_mels, 0.0, None, waves=16)
     tri_ok = (cfg.segtab is not None and hop_length <= 512 and ops.fused_waves() == 16
               and bool(lib().syg_stft2048_mfcc_tri_fits(int(n_mels), int(Tn), int(n_mfcc))))
-    if one_launch not in (None, True, False, "segments", "matrix"):
-        raise ValueError("one_launch must be None, True, False, 'segments' or 'matrix'")
-    if one_launch == "segments" and not tri_ok:
-        raise SygnalsHipError("feature_block: no segment-sum projection for this shape")
-    if one_launch == "matrix":
-        tri_ok = False
+    if one_launch not in (None, True, False, "segments"):
+        raise ValueError("one_launch must be None, True, False or 'segments'")
+    if one_launch in (True, "segments") and not tri_ok:
+        raise SygnalsHipError("feature_block: no one-launch form for this shape (two-pass piece table + the clip's mel matrix in LDS)")
     if one_launch is None:
         one_launch = tri_ok and TRI_FEATURES_DEFAULT
-    if one_launch and not tri_ok and not (ops.mfcc_fused_fits(n_mels, Tn, n_mfcc) and ops.fused_waves() == 16):
-        raise SygnalsHipError("feature_block: the one-launch form needs the clip's mel matrix to fit the LDS (16-wave plan)")
     if one_launch:
         stats = torch.empty((B, 8, Tn), dtype=torch.float32, device=y.device)       # (only the rows read below are written)
         cpv = torch.empty((B, 2, R, Tn), dtype=torch.float32, device=y.device)
-        head = (ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn, ops._ptr(ops.window_dev("hann", 2048, 2048)),
-                ops._ptr(ops.twiddle_dev(2048)))
-        tail = (n_mels, ops._ptr(dct), n_mfcc, None, 1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), 2.0, 1 | 8 | 32,
-                ops._ptr(stats), np.ascontiguousarray(cplan, np.int32).ctypes.data_as(C.c_void_p), ops._ptr(cpv))
-        if tri_ok:
-            rc = lib().syg_stft2048_features_tri_f32(*head, ops._ptr(cfg.segtab), int(cfg.segtab.numel()), *tail,
-                                                     ops._ptr(out), rows, st)
-            check(rc, "syg_stft2048_features_tri_f32")
-        else:
-            rc = lib().syg_stft2048_features_f32(*head, ops._ptr(cfg.wpacked), cfg.plan.ctypes.data_as(C.c_void_p), *tail,
-                                                 None, ops._ptr(out), rows, st)
-            check(rc, "syg_stft2048_features_f32")
+        rc = lib().syg_stft2048_features_tri_f32(
+            ops._ptr(y), B, L, y.stride(0), hop_length, 1, Tn, ops._ptr(ops.window_dev("hann", 2048, 2048)),
+            ops._ptr(ops.twiddle_dev(2048)), ops._ptr(cfg.segtab), int(cfg.segtab.numel()), n_mels, ops._ptr(dct), n_mfcc, None,
+            1e-10, 80.0, 1, 1.0, float(sr), float(roll_percent), 2.0, 1 | 8 | 32, ops._ptr(stats),
+            np.ascontiguousarray(cplan, np.int32).ctypes.data_as(C.c_void_p), ops._ptr(cpv), ops._ptr(out), rows, st)
+        check(rc, "syg_stft2048_features_tri_f32")
         rc = lib().syg_feature_block_f32(None, B, n_mels, Tn, None, n_mfcc, 1e-10, 80.0, ops._ptr(stats), float(sr) / 2048.0,
                                          ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out), st)
         check(rc, "syg_feature_block_f32")

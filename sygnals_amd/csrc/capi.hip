@@ -30,19 +30,14 @@ extern "C" int syg_set_option(int key, int value) {
 }
 extern "C" int syg_get_option(int key) { return syg::option(key); }
 
-#ifndef SYG_ABL
-#define SYG_ABL 0
-#endif
 extern "C" int syg_abi_version(void) { return SYG_ABI_VERSION; }
-// 0 for the product build; the SYG_ABL number of a development build (ablation / timeline variants compute WRONG
-// results by design; build_lib.sh writes them to their own path and the Python binding refuses to load one)
+// 0 for the product build; non-zero for a development build (timeline / ablation variants whose results are wrong by
+// design or whose outputs carry stamps; build_lib.sh writes them to their own path and the Python binding refuses one)
 #if defined(SYG_SOSC_ABL)
 extern "C" int syg_build_variant(void) { return 100 + SYG_SOSC_ABL; }      // sosfilt_clip.hip timing ablations
-#elif defined(SYG_TRIX)
-extern "C" int syg_build_variant(void) { return 200 + SYG_TRIX; }          // stft_mel.hip MODE 6 timing experiments
-#elif defined(SYG_R7ABL)
-extern "C" int syg_build_variant(void) { return 300 + SYG_R7ABL; }         // stft_mel.hip MODE 7 row-function stand-ins
+#elif defined(SYG_DEV) && SYG_DEV
+extern "C" int syg_build_variant(void) { return 9; }                       // stft_mel.hip with per-phase stamps (stft_dev.h)
 #else
-extern "C" int syg_build_variant(void) { return SYG_ABL; }
+extern "C" int syg_build_variant(void) { return 0; }
 #endif
 extern "C" const char* syg_last_error(void) { return syg::g_err; }

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NT) void feature_block_kernel(const float* __restri
   float* ob = out + b * (int64_t)rows * T;
   const int64_t n = (int64_t)M * T, nc = (int64_t)R * T;
   float mx = 0.f, m0 = 0.f, m1 = 0.f;       // powers and magnitudes are non-negative
-  const bool have_mel = mel != nullptr;     // (null: rows 0 .. K-1 were written by syg_stft2048_features_f32)
+  const bool have_mel = mel != nullptr;     // (null: rows 0 .. K-1 were written by syg_stft2048_features_tri_f32)
   if (have_mel)
     for (int64_t i = tid; i < n; i += NT) mx = fmaxf(mx, src[i]);
   for (int64_t i = tid; i < nc; i += NT) { m0 = fmaxf(m0, pk[i]); m1 = fmaxf(m1, vl[i]); }

@@ -30,53 +30,17 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifndef SYG_TRIX
-#define SYG_TRIX 0   // development experiments on MODE 6 (timing only)
-#endif
-#ifndef SYG_ABL
-#define SYG_ABL 0   // development ablations (tools/ablate.sh); 0 = product build
-#endif
 // Issue priority falls as a wave advances through its frame: the SIMD's arbiter otherwise favours the oldest
 // wave, which then idles at barrier A while the youngest finishes alone with nothing to hide its LDS latency.
-#ifndef SYG_NOPRIO
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-// level n for the younger waves, one lower for the older ones (experiment SYG_AGEPRIO: the arbiter serves the oldest wave
-// first at equal priority)
-#define SETPRIO_AGE(n, older) do { if (older) SETPRIO((n) > 0 ? (n) - 1 : 0); else SETPRIO(n); } while (0)
-#else
-#define SETPRIO(n)
-#endif
-#if SYG_ABL == 9
-// -DSYG_TICK_NOVM: the stamps do not drain vector memory (the DMA / store waits then show up where the product waits)
-#ifdef SYG_TICK_NOVM
-#define SYG_TICK_WAIT "s_waitcnt lgkmcnt(0)"
-#else
-#define SYG_TICK_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)"
-#endif
-// timeline mode: per-wave cycle accumulators per phase, dumped into stats_out (tools/timeline.py)
-#define TICK(slot, reg)                                                                                         \
-  do {                                                                                                          \
-    unsigned long long _t;                                                                                      \
-    asm volatile(SYG_TICK_WAIT "\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t), "+v"(reg)::"memory"); \
-    tacc[slot] += _t - tprev;                                                                                   \
-    tprev = _t;                                                                                                 \
-  } while (0)
-#define TARGS , unsigned long long (&tacc)[12], unsigned long long& tprev
-#define TPASS , tacc, tprev
-#else
-#define TICK(slot, reg)
-#define TARGS
-#define TPASS
-#endif
+// -DSYG_DEV=1: per-phase cycle stamps (tools/timeline.py; a development build -- syg_build_variant() != 0 -- whose
+// statistics output carries the counters)
+#include "stft_dev.h"
 
 namespace syg {
 namespace {
 
-#ifndef SYG_NOX2
 constexpr bool X2_MEL = true;    // mel-only modes keep 4 |X|^2 in the power rows (see stft2048_kernel)
-#else
-constexpr bool X2_MEL = false;
-#endif
 constexpr int NFFT = 2048;
 constexpr int MC = 1024;         // complex points per frame
 constexpr int NBIN = 1025;
@@ -115,6 +79,8 @@ struct ContrastPlan {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#include "row_features.h"
+
 // MODE 3 (clip-resident MFCC): the mel tiles of a clip stay in LDS; after the clip's last tile the workgroup
 // converts them to dB (per-clip max reference, top_db floor) and applies the DCT -- only MFCCs reach HBM.
 struct MfccArgs {
@@ -130,9 +96,6 @@ struct MfccArgs {
 
 // exchange 2 (half buffer by c' & 7, planar in b'): slot of group (c, c') inside a plane
 __device__ __forceinline__ int x2g(int c, int cp) { return (cp & 7) * 16 + ((c + 4 * ((cp & 7) >> 1)) & 15); }
-// position of bin k inside an LDS power row: one pad word every 16 bins turns the stride-16 bin pattern
-// of the pass-3 output into a conflict-free store while 16-aligned runs of bins stay contiguous for the MFMA
-__device__ __forceinline__ int ppos(int k) { return k + (k >> 4); }
 
 struct LaneConst {
   float2 twb[2];     // W_2048^kb of each unit (kb = c + 16 c'); pair d uses twb * W_8^d
@@ -147,6 +110,8 @@ struct LaneConst {
 // unit u = lane + 64 j: primary group (c = u >> 3, c' = u & 7), bins k = kb + 256 d; mirror group
 // (16 - c, 15 - c') holds bins 1024 - k, with the c = 0 exceptions (0, 16 - c') and, for u = 0 (lane 0), the
 // self-mirrored pair of groups (0,0) / (0,8) whose four pairs are the bins {0, 256, 128, 384} (+ bin 512).
+// TWB: also fetch twb from the twiddle table (false: the caller keeps twb and re-makes the rest -- lane arithmetic only)
+template <bool TWB = true>
 __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const float2* __restrict__ twid) {
   constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
 #pragma unroll
@@ -160,7 +125,7 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
     lc.kb[j] = kb;
     lc.pkb[j] = ppos(kb);
     lc.pmb[j] = ppos(MC - kb);
-    lc.twb[j] = twid[kb];
+    if (TWB) lc.twb[j] = twid[kb];
   }
   const bool sp = (lane == 0);
   lc.cA2 = sp ? make_float2(C1, -S1) : make_float2(0.f, -1.f);   // W_2048^128 = W_16^1   |  W_8^2
@@ -172,27 +137,18 @@ __device__ __forceinline__ void init_lane_const(LaneConst& lc, int lane, const f
 // 1024-point complex forward FFT of the windowed frame + real split.  v[a] holds z[64a + lane] on entry.
 // On exit pair (j, d) holds X[k] in xs[j][d] and X[1024 - k] in xm[j][d] (k = kb_j + 256 d; lane 0 / unit 0:
 // k = 0, 256, 128, 384); lane 0 also returns X[512].
-// NPF > 0: the first NPF 16-byte groups of the wave's filterbank operands (pf_src, 64 float4 apart) are requested
-// behind pass 3 -- the transform's register peak is over there -- so that their L2 latency hides behind the real split
-// and the row stores instead of standing in front of barrier A.
 // PD: priority drop (MODE 1 keeps the top level for its row functions, the transform then runs one level lower)
 // X2: return 2 X instead of X (the two halvings of the real split are left out; the caller's powers are then 4 |X|^2 --
 // an exact scaling that the mel-only modes take back where the mel values leave the kernel: 32 instructions per frame)
-template <int NPF, int PD = 0, bool X2 = false>
+template <int PD = 0, bool X2 = false>
 __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& lc, float2* __restrict__ sc,
                                              const float2* __restrict__ tw1l, const float2* __restrict__ tw2l,
-                                             int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512,
-                                             const float4* __restrict__ pf_src, float4* __restrict__ pf, bool older TARGS) {
+                                             int lane, float2 (&xs)[2][4], float2 (&xm)[2][4], float2& x512 TARGS) {
   const int cl = lane >> 2, bp = lane & 3;
   // ---- pass 1: radix-16 over a (stride 64), twiddle W_1024^(b*c)
   dft16(v);
-#if SYG_ABL == 3 || SYG_ABL == 4
-#pragma unroll
-  for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], make_float2(0.6f, 0.8f));
-#else
 #pragma unroll
   for (int c = 1; c < 16; ++c) v[c] = cmul(v[c], tw1l[(c - 1) * 64 + lane]);
-#endif
   // ---- exchange 1 in two half-rounds through a 512-complex buffer.  Round h moves the 8 ROWS c = 8h..8h+7:
   // all 64 lanes store (row r = c & 7 at r*64 + (b ^ 4r)) -- an LDS store costs its 6 cycles whatever the EXEC
   // mask, so half-wave stores would pay twice.  A pass-2 lane (c = lane>>2, b' = lane&3) needs the 16 operands
@@ -203,10 +159,6 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   TICK(1, v[1].x);
   float2 t[16];
   {
-#if SYG_ABL == 2 || SYG_ABL == 4
-#pragma unroll
-    for (int a = 0; a < 16; ++a) t[a] = v[a];
-#else
     const int r7 = cl & 7;
     const int rbase = r7 * 64 + bp + 8 * (cl & 8) / 2;      // + 32 for the upper half-wave (a = 8..15)
 #pragma unroll
@@ -225,11 +177,10 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
       t[i] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
       t[8 + i] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
     }
-#endif
   }
   TICK(2, t[0].x);
   // ---- pass 2: lane = (c = lane>>2, b' = lane&3); radix-16 over a'
-  SETPRIO_AGE(2 - PD > 0 ? 2 - PD : 0, older);
+  SETPRIO(2 - PD > 0 ? 2 - PD : 0);
   dft16(t);
   {
     // W_64^(b'*c') from a 64-entry LDS table (4 lane classes): two twiddles per 16-byte read
@@ -250,13 +201,6 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
   float2 G[2][4], H[2][4];
   {
     const int wbase = bp * PL2;
-#if SYG_ABL == 2 || SYG_ABL == 4
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bfly4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3], G[j][0], G[j][1], G[j][2], G[j][3]);
-      bfly4(t[8 + 4 * j], t[9 + 4 * j], t[10 + 4 * j], t[11 + 4 * j], H[j][0], H[j][1], H[j][2], H[j][3]);
-    }
-#else
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -270,16 +214,9 @@ __device__ __forceinline__ void wave_rfft2048(float2 (&v)[16], const LaneConst& 
       }
       wave_lds_sync();
     }
-#endif
   }
   TICK(4, G[0][0].x);
-  SETPRIO_AGE(1 - PD > 0 ? 1 - PD : 0, older);
-  if (NPF > 0) {
-    int lp = lane;                     // laundered: the loads may not be hoisted above this point (register peak)
-    asm volatile("" : "+v"(lp));
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) pf[q] = pf_src[(int64_t)q * 64 + lp];
-  }
+  SETPRIO(1 - PD > 0 ? 1 - PD : 0);
   // ---- real split on mirror pairs
   x512 = X2 ? make_float2(2.f * G[0][2].x, -2.f * G[0][2].y)
             : make_float2(G[0][2].x, -G[0][2].y);      // X[512] = conj(Z[512]) (meaningful in lane 0 only)
@@ -383,707 +320,12 @@ __device__ __forceinline__ void stage_tile(const float* yb, int clip_bytes, floa
                                                0);
   }
 }
-
-// ----------------------------------------------------------------------------------
-// per-row statistics from an LDS power row (one wave per row)
-// ----------------------------------------------------------------------------------
-// Hardware transcendental forms (v_sqrt / v_log / v_exp / v_rcp_f32, <= 1 ulp): the IEEE-exact library
-// versions expand to 15-200 instructions each, and 17 inlined copies overflow the instruction cache.
-__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }  // ln
-__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-__device__ __forceinline__ float fpow(float x, float p) {    // x >= 0
-  return (x > 0.f) ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : 0.f;
-}
-
-// The row functions stay out of line (inlined, their registers would spill the FFT loop).  Their pointers
-// carry the address space: a generic pointer would turn every row read into a flat_load.
-typedef const __attribute__((address_space(3))) float* lds_row;
-#ifndef SYG_R7ABL
-#define SYG_R7ABL 0
-#endif
-#ifndef SYG_SELBITS
-#define SYG_SELBITS 16
-#endif
-#ifndef SYG_SEL2
-#define SYG_SEL2 1
-#endif
-#ifndef SYG_P6SPLIT
-#define SYG_P6SPLIT 0      // (experiment, correct, measured without gain: 140.8 vs 140.6 us -- see proj_split below)
-#endif
-#ifndef SYG_R7PRIO
-#define SYG_R7PRIO 3      // issue priority of the row functions of MODE 7 (the transform runs one level below the top)
-#endif
-#ifndef SYG_R7SHIFT
-#define SYG_R7SHIFT 2     // waves w, w + 4, w + 8, w + 12 share a SIMD: two of them early, two late
-#endif
-#ifndef SYG_R7SPLIT
-#define SYG_R7SPLIT 1
-#endif
-#ifndef SYG_ROWBOTH
-#define SYG_ROWBOTH 1
-#endif
-typedef __attribute__((address_space(1))) float* gptr;
-
-// smask bits: 1 centroid, 2 bandwidth, 4 flatness, 8 rolloff, 16 dominant (only the requested rows are
-// computed and written; MAG_SUM / POWER_SUM / margin ride along with centroid / rolloff)
-// Returns the statistics in the lanes of one register: lane SYG_STAT_x holds row x (every value is wave-uniform when it
-// is formed, so any lane can keep it).  The function does NOT store: a later out-of-line call would wait for the stores
-// at its entry (s_waitcnt vmcnt(0)), the caller writes the rows behind its last call (stats_row_mask() says which).
-__device__ __forceinline__ int stats_row_mask(int smask) {
-  return ((smask & 1) ? (1 << SYG_STAT_CENTROID) | (1 << SYG_STAT_MAG_SUM) : 0) | ((smask & 2) ? (1 << SYG_STAT_BANDWIDTH) : 0) |
-         ((smask & 4) ? (1 << SYG_STAT_FLATNESS) : 0) | ((smask & 16) ? (1 << SYG_STAT_DOMINANT_BIN) : 0) |
-         ((smask & 8) ? (1 << SYG_STAT_ROLLOFF_BIN) | (1 << SYG_STAT_POWER_SUM) | ((smask & 32) ? 0 : (1 << SYG_STAT_ROLLOFF_MARGIN)) : 0);
-}
-__device__ __forceinline__ float row_stats_body(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
-  float res = 0.f;
-#define SYG_PUT(row, val) res = (lane == (row)) ? (val) : res
-  // lane owns the 16 contiguous bins [16 lane, 16 lane + 16) -- 16 consecutive words at 17 lane of the skewed row:
-  // immediate offsets, no bank conflicts -- and lane 63 also the Nyquist bin 1024 as a 17th value (0 in the other
-  // lanes).  The powers are read ONCE and every statistic works on the registers (round 2 re-read the row per pass to
-  // stay inside the caller-saved registers; 17 + 17 values still do).
-  const float EPS = 2.220446049250313e-16f;
-  const bool last = (lane == 63);
-  float p[17];
-  {
-    lds_row pr = prow + 17 * lane;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) p[i] = pr[i];
-    const float nyq = pr[17];                      // ppos(1024) = 17 * 63 + 17 for lane 63 (inside the row's slack elsewhere)
-    p[16] = last ? nyq : 0.f;
-  }
-  float psum = 0.f;
-#pragma unroll
-  for (int i = 0; i < 17; ++i) psum += p[i];
-  const float tot_p = wave_sum(psum);
-  const float kb = (float)(16 * lane);
-  float tot_m = 0.f, cen_bin = 0.f;
-  bool live = false;
-  if (smask & (1 | 2 | 4)) {        // magnitude sums
-    float m[17];
-    float msum = 0.f, fl = 0.f;
-#pragma unroll
-    for (int i = 0; i < 17; ++i) {
-      m[i] = fsqrt(p[i]);
-      msum += m[i];
-      fl = fmaf(m[i], (float)i, fl);               // sum m (k - 16 lane): the lane's base enters once below
-    }
-    tot_m = wave_sum(msum);
-    live = tot_m >= EPS;
-    const float tot_f = wave_sum(fmaf(kb, msum, fl));
-    cen_bin = live ? tot_f * frcp(tot_m) : 0.f;
-    SYG_PUT(SYG_STAT_CENTROID, cen_bin * binhz);
-    SYG_PUT(SYG_STAT_MAG_SUM, tot_m);
-    if (smask & 4) {    // flatness: exp(mean log(m + eps)) / mean(m)
-      float lsum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) lsum += __builtin_amdgcn_logf(m[i] + EPS);
-      const float l16 = __builtin_amdgcn_logf(m[16] + EPS);
-      lsum += last ? l16 : 0.f;
-      const float tot_l = wave_sum(lsum) * 0.69314718055994531f;
-      const float am = tot_m * (1.f / (float)NBIN);
-      SYG_PUT(SYG_STAT_FLATNESS, (am >= EPS) ? fminf(fmaxf(fexp(tot_l * (1.f / (float)NBIN)) * frcp(am), 0.f), 1.f) : 0.f);
-    }
-    if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p);  (m[16] = 0 outside lane 63)
-      const int pmode = (bw_p == 2.f) ? 2 : (bw_p == 1.f) ? 1 : 0;
-      const float d0 = kb - cen_bin;
-      float dsum = 0.f;
-      if (pmode == 2) {
-#pragma unroll
-        for (int i = 0; i < 17; ++i) { const float d = (d0 + (float)i) * binhz; dsum = fmaf(m[i], d * d, dsum); }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 17; ++i) {
-          const float d = fabsf(d0 + (float)i) * binhz;
-          dsum = fmaf(m[i], pmode == 1 ? d : fpow(d, bw_p), dsum);
-        }
-      }
-      const float tot_d = wave_sum(dsum);
-      const float r = live ? fmaxf(tot_d * frcp(tot_m), 0.f) : 0.f;
-      SYG_PUT(SYG_STAT_BANDWIDTH, pmode == 2 ? fsqrt(r) : pmode == 1 ? r : fpow(r, frcp(bw_p)));
-    }
-  }
-  if (smask & 16) {   // argmax of the magnitude == argmax of the power (first occurrence)
-    float pmax = p[0];
-    int amax = 0;
-#pragma unroll
-    for (int i = 1; i < 17; ++i) {
-      const bool up = (i < 16 || last) && p[i] > pmax;
-      pmax = up ? p[i] : pmax; amax = up ? i : amax;
-    }
-    const float gm = wave_max(pmax);
-    const int cand = wave_min_i((pmax == gm) ? 16 * lane + amax : 0x7fffffff);
-    SYG_PUT(SYG_STAT_DOMINANT_BIN, (float)cand);
-  }
-  if (smask & 8) {    // rolloff: first bin with cumsum(power) >= roll * total
-    // The running sum never decreases (powers are >= 0), so the number of a lane's sums below the threshold IS the
-    // position of its first hit; the decision margin is the distance of the threshold to the nearest running sum on
-    // either side (the sum in front of bin 0 excepted).
-    // (SYG_SM_NO_MARGIN: callers that do not read the margin row -- the C4 block -- skip its three instructions per bin.)
-    const float thr = roll_percent * tot_p;
-    float c = wave_excl_scan(psum, lane);
-    int below = 0;
-    float mgw = 0.f;
-    if (smask & 32) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        c += p[i];
-        below += (c < thr) ? 1 : 0;
-      }
-      c += p[16];
-      below += (last && c < thr) ? 1 : 0;
-    } else {
-      float mg = (lane > 0) ? fabsf(c - thr) : 3.4e38f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        c += p[i];
-        below += (c < thr) ? 1 : 0;
-        mg = fminf(mg, fabsf(c - thr));
-      }
-      c += p[16];
-      below += (last && c < thr) ? 1 : 0;
-      mg = fminf(mg, fabsf(c - thr));
-      mgw = wave_min(mg);
-    }
-    const int rb = (below < (last ? 17 : 16)) ? 16 * lane + below : 0x7fffffff;
-    int rbmin = wave_min_i(rb);
-    if (rbmin == 0x7fffffff || tot_p < EPS) rbmin = NBIN - 1;
-    SYG_PUT(SYG_STAT_ROLLOFF_BIN, (float)rbmin);
-    SYG_PUT(SYG_STAT_POWER_SUM, tot_p);
-    SYG_PUT(SYG_STAT_ROLLOFF_MARGIN, (tot_p > 0.f) ? mgw * frcp(tot_p) : 0.f);
-  }
-#undef SYG_PUT
-  return res;
-}
-
-// k-th order statistic of the powers of bins [lo, lo + n) by a 32-step radix select on the float bit patterns
-// (fallback for long bands / large k)
-__device__ __forceinline__ uint32_t row_kth(lds_row prow, int lane, int lo, int n, int kk, bool largest) {
-  uint32_t prefix = 0;
-  int remaining = kk;
-  for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t mask = ~((1u << bit) - 1u);
-    const uint32_t want = largest ? (prefix | (1u << bit)) : prefix;
-    int cnt = 0;
-    for (int i = lane; i < n; i += 64) cnt += ((__float_as_uint(prow[ppos(lo + i)]) & mask) == want) ? 1 : 0;
-    cnt = wave_sum_i(cnt);
-    if (largest) {
-      if (cnt >= remaining) prefix |= (1u << bit); else remaining -= cnt;
-    } else {
-      if (cnt < remaining) { remaining -= cnt; prefix |= (1u << bit); }
-    }
-  }
-  return prefix;
-}
-
-// the kk-th largest over the lanes of two 32-bit values per lane (two independent selections in one loop): bisection
-// from the top bit, per bit and value one vector compare and a scalar popcount.  kk is made scalar here (it arrives in
-// a vector register when the caller is an out-of-line function): thresholds and counts then live on the scalar unit.
-// Only bits 31 .. LOWBIT are decided: the result is the k-th largest ROUNDED DOWN to that precision -- still a value
-// with at least kk lane values at or above it, which is all the selection below needs (a lower threshold only lets a
-// few more candidates through).
-template <int LOWBIT>
-__device__ __forceinline__ void wave_kth_largest2_u32(uint32_t x, uint32_t y, int kk, uint32_t& tx, uint32_t& ty) {
-  const int ks = __builtin_amdgcn_readfirstlane(kk);
-  uint32_t a = 0, b = 0;
-#pragma unroll 4
-  for (int bit = 31; bit >= LOWBIT; --bit) {
-    const uint32_t ca = a | (1u << bit), cb = b | (1u << bit);
-    const int na = __popcll(__ballot(x >= ca)), nb = __popcll(__ballot(y >= cb));
-    a = (na >= ks) ? ca : a;
-    b = (nb >= ks) ? cb : b;
-  }
-  tx = a; ty = b;
-}
-
-// The same over TWO values per lane and side (the kk-th largest of the 128 values x1, x2 / y1, y2): a tighter threshold
-// for callers whose lanes hold sorted lists -- the kk-th largest of the lanes' two top values is much closer to the
-// kk-th largest of everything than the kk-th largest lane MAXIMUM is (a lane with two of the top kk values is common,
-// one with three is rare), so that fewer candidates pass it and have to be taken back one by one.
-// x*: non-negative floats as bits (bit 31 clear), y*: complements of such (bit 31 set): the top bit is known.
-template <int LOWBIT>
-__device__ __forceinline__ void wave_kth_largest2x2_u32(uint32_t x1, uint32_t x2, uint32_t y1, uint32_t y2, int kk, uint32_t& tx,
-                                                        uint32_t& ty) {
-  const int ks = __builtin_amdgcn_readfirstlane(kk);
-  uint32_t a = 0, b = 0x80000000u;
-#pragma unroll 5
-  for (int bit = 30; bit >= LOWBIT; --bit) {
-    const uint32_t ca = a | (1u << bit), cb = b | (1u << bit);
-    const int na = __popcll(__ballot(x1 >= ca)) + __popcll(__ballot(x2 >= ca));
-    const int nb = __popcll(__ballot(y1 >= cb)) + __popcll(__ballot(y2 >= cb));
-    a = (na >= ks) ? ca : a;
-    b = (nb >= ks) ? cb : b;
-  }
-  tx = a; ty = b;
-}
-
-// Data-oblivious sorting networks for the R values a lane holds (Batcher's odd-even merge sort pruned to R wires;
-// checked with the 0-1 principle, tools/sortnet.py).
-template <int R> struct SortNet;
-template <> struct SortNet<1> { static constexpr int N = 0; static constexpr int P[1][2] = {{0, 0}}; };
-template <> struct SortNet<2> { static constexpr int N = 1; static constexpr int P[1][2] = {{0, 1}}; };
-template <> struct SortNet<4> {
-  static constexpr int N = 5;
-  static constexpr int P[5][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}};
-};
-template <> struct SortNet<5> {
-  static constexpr int N = 9;
-  static constexpr int P[9][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {0, 4}, {2, 4}, {1, 2}, {3, 4}};
-};
-template <> struct SortNet<7> {
-  static constexpr int N = 16;
-  static constexpr int P[16][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {4, 6}, {5, 6},
-                                   {0, 4}, {2, 6}, {2, 4}, {1, 5}, {3, 5}, {1, 2}, {3, 4}, {5, 6}};
-};
-template <> struct SortNet<8> {
-  static constexpr int N = 19;
-  static constexpr int P[19][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6},
-                                   {0, 4}, {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}};
-};
-template <> struct SortNet<10> {
-  static constexpr int N = 32;
-  static constexpr int P[32][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4},
-                                   {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {0, 8}, {4, 8},
-                                   {2, 4}, {6, 8}, {1, 9}, {5, 9}, {3, 5}, {7, 9}, {1, 2}, {3, 4}, {5, 6}, {7, 8}};
-};
-template <> struct SortNet<12> {
-  static constexpr int N = 41;
-  static constexpr int P[41][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4},
-                                   {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5}, {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11},
-                                   {8, 10}, {9, 11}, {9, 10}, {0, 8}, {4, 8}, {2, 10}, {6, 10}, {2, 4}, {6, 8}, {1, 9},
-                                   {5, 9}, {3, 11}, {7, 11}, {3, 5}, {7, 9}, {1, 2}, {3, 4}, {5, 6}, {7, 8}, {9, 10}};
-};
-
-// The band sits in R registers per lane (bin lo + 64 r + lane in register r).  Each lane first sorts its own R
-// values (two copies: `up` ascending with -1 in the unused slots, `dn` descending with +huge), so that a lane's
-// candidate for the next largest / smallest is always in its last register.  One extraction is then a wave max / min
-// over those heads, and the first owning lane shifts its list by one: 2 R selects per step instead of the
-// 8 R compare / select operations of a search through unsorted registers.
-template <int R>
-__device__ __forceinline__ void contrast_extract(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
-  float up[R], dn[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = r * 64 + lane;
-    const float p = prow[ppos(lo + (i < n ? i : 0))];
-    up[r] = (i < n) ? p : -1.f;
-    dn[r] = (i < n) ? p : 3.4e38f;
-  }
-#pragma unroll
-  for (int c = 0; c < SortNet<R>::N; ++c) {
-    constexpr auto& P = SortNet<R>::P;
-    const int i = P[c][0], j = P[c][1];
-    const float ua = up[i], ub = up[j], da = dn[i], db = dn[j];
-    up[i] = fminf(ua, ub); up[j] = fmaxf(ua, ub);
-    dn[i] = fmaxf(da, db); dn[j] = fminf(da, db);
-  }
-  spk = 0.f; svl = 0.f;
-  for (int it = 0; it < k; ++it) {
-    float MH = up[R - 1], ML = dn[R - 1];
-    wave_maxmin(MH, ML);
-    const int fh = __ffsll((long long)__ballot(up[R - 1] == MH)) - 1;
-    const int fl = __ffsll((long long)__ballot(dn[R - 1] == ML)) - 1;
-    const bool mh = lane == fh, ml = lane == fl;
-#pragma unroll
-    for (int r = R - 1; r > 0; --r) {
-      up[r] = mh ? up[r - 1] : up[r];
-      dn[r] = ml ? dn[r - 1] : dn[r];
-    }
-    up[0] = mh ? -1.f : up[0];
-    dn[0] = ml ? 3.4e38f : dn[0];
-    spk += fsqrt(MH);
-    svl += fsqrt(ML);
-  }
-}
-
-// Wide bands (R = 12 registers per lane: 449..768 bins, config C4's 751-bin top band with k = 15).  The register form
-// above pays 2 R selects per extraction to shift two sorted lists; here a lane sorts its values ONCE into one
-// ascending list, parks it transposed in a dead part of its own row -- words [0, 64 R) of the row: the bands below
-// this one are finished and this band's values are in registers (the caller guarantees ascending band order and
-// 64 R <= ppos(hi)) -- and an extraction moves a head index and re-reads one word: the largest values are consumed
-// from the top of the list, the smallest from the bottom, independently (as two sorted copies would be).
-template <int R>
-__device__ __forceinline__ void contrast_extract_lds(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
-  typedef __attribute__((address_space(3))) float* lds_wrow;
-  lds_wrow wrow = (lds_wrow)prow;
-  float v[R];
-  // bin lo + lane + 64 r sits at ppos(lo + lane) + 68 r (64 r / 16 = 4 r pad words, no carry): one base, immediate
-  // offsets.  Lanes past the band's end read on (still inside the LDS allocation) and are replaced by the pad.
-  lds_row pr = prow + ppos(lo + lane);
-  const int nrem = n - lane;                      // this lane holds the values r with 64 r < nrem
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float p = pr[68 * r];
-    v[r] = (64 * r < nrem) ? p : 3.4e38f;         // pads sort to the top of the list and are never a head
-  }
-  const int nvu = (nrem + 63) >> 6;
-  const int nv = nvu < 0 ? 0 : (nvu > R ? R : nvu);   // valid values of this lane
-#pragma unroll
-  for (int c = 0; c < SortNet<R>::N; ++c) {
-    constexpr auto& P = SortNet<R>::P;
-    const int i = P[c][0], j = P[c][1];
-    const float a = v[i], b = v[j];
-    v[i] = fminf(a, b); v[j] = fmaxf(a, b);
-  }
-  wave_lds_sync();                                // every lane has read its band values: the row may be overwritten
-#pragma unroll
-  for (int r = 0; r < R; ++r) wrow[r * 64 + lane] = v[r];
-  wave_lds_sync();
-  int ht = nv - 1, hb = 0;                        // head indices: next largest / next smallest of this lane
-  float MHl = (nv > 0) ? wrow[(nv > 0 ? ht : 0) * 64 + lane] : -1.f, MLl = (nv > 0) ? v[0] : 3.4e38f;
-  // Selection instead of k extractions (k >= 8).  The k-th largest of the 64 lane maxima, T, has at least k values of
-  // the band at or above it, all of them in the lanes whose maximum reaches it: count them (C), sum their magnitudes, and
-  // take back the C - k smallest of them -- two or three wave-wide rounds instead of k (the lane maxima of 12 values
-  // each are the top of the band: C - k is small; when it is not, ties or a constant band, the k rounds below run).
-  // T by bisection on the bit patterns (non-negative floats order like their bits): 32 compares + scalar popcounts.
-  if (k >= 8 && n >= 64) {                      // (wave-uniform; every lane holds at least one value)
-    uint32_t Tu, Bu;                              // Bu: k-th smallest of the lane minima = ~(k-th largest of their complements)
-    // 16 of the 32 bits (sign, exponent, 7 mantissa bits: the threshold is within 1 % of the exact order statistic)
-    wave_kth_largest2_u32<16>(__float_as_uint(MHl), ~__float_as_uint(MLl), k, Tu, Bu);
-    Bu = ~Bu;
-    const float Th = __uint_as_float(Tu), Tl = __uint_as_float(Bu);
-    int ch = nv - R, cl = 0;                      // (the pads, +huge, count as >= Th: taken off up front)
-#pragma unroll
-    for (int r = 0; r < R; ++r) { ch += (v[r] >= Th) ? 1 : 0; cl += (v[r] <= Tl) ? 1 : 0; }
-    const int Eh = wave_sum_i(ch) - k, El = wave_sum_i(cl) - k;
-    if (Eh <= 12 && El <= 12) {
-      const int cmax = (int)wave_max((float)(ch > cl ? ch : cl));
-      float ah = 0.f, al = 0.f;
-      for (int t = 0; t < cmax; ++t) {
-        const int ih = nv - 1 - t;
-        const float vh = wrow[(ih > 0 ? ih : 0) * 64 + lane], vl = wrow[(t < R ? t : 0) * 64 + lane];
-        ah += (t < ch) ? fsqrt(vh) : 0.f;
-        al += (t < cl) ? fsqrt(vl) : 0.f;
-      }
-      float Sh = wave_sum(ah), Sl = wave_sum(al);
-      // the extras: the smallest of the upper candidates, the largest of the lower ones
-      const int emax = Eh > El ? Eh : El;
-      for (int e = 0; e < emax; ++e) {
-        float lo_c = (ch > 0) ? wrow[(nv - ch) * 64 + lane] : 3.4e38f;       // this lane's smallest upper candidate
-        float hi_c = (cl > 0) ? wrow[(cl - 1) * 64 + lane] : -1.f;           // its largest lower candidate
-        float MH = hi_c, ML = lo_c;
-        wave_maxmin(MH, ML);
-        const int fh = __ffsll((long long)__ballot(hi_c == MH)) - 1;
-        const int fl = __ffsll((long long)__ballot(lo_c == ML)) - 1;
-        if (e < Eh) { Sh -= fsqrt(ML); ch -= (lane == fl) ? 1 : 0; }
-        if (e < El) { Sl -= fsqrt(MH); cl -= (lane == fh) ? 1 : 0; }
-      }
-      spk = Sh; svl = Sl;
-      return;
-    }
-  }
-  spk = 0.f; svl = 0.f;
-  for (int it = 0; it < k; ++it) {
-    float MH = MHl, ML = MLl;
-    wave_maxmin(MH, ML);
-    const int fh = __ffsll((long long)__ballot(MHl == MH)) - 1;
-    const int fl = __ffsll((long long)__ballot(MLl == ML)) - 1;
-    ht -= (lane == fh) ? 1 : 0;
-    hb += (lane == fl) ? 1 : 0;
-    // (a lane re-reads its heads every round: the address only moves in the two winning lanes)
-    const float nh = wrow[(ht >= 0 ? ht : 0) * 64 + lane], nl = wrow[(hb < nv ? hb : 0) * 64 + lane];
-    MHl = (ht >= 0) ? nh : -1.f;
-    MLl = (hb < nv) ? nl : 3.4e38f;
-    spk += fsqrt(MH);
-    svl += fsqrt(ML);
-  }
-}
-
-// k = 1: the band's largest and smallest power.  Lanes past the band's end re-read its last bin (a duplicate changes
-// neither extreme): no masks.
-__device__ __forceinline__ void contrast_minmax(lds_row prow, int lane, int lo, int n, float& spk, float& svl) {
-  float hi = 0.f, lw = 3.4e38f;
-  for (int r0 = 0; r0 < n; r0 += 64) {
-    const int i = r0 + lane;
-    const float p = prow[ppos(lo + (i < n ? i : n - 1))];
-    hi = fmaxf(hi, p);
-    lw = fminf(lw, p);
-  }
-  wave_maxmin(hi, lw);
-  spk = fsqrt(hi); svl = fsqrt(lw);
-}
-
-// k <= 3 on bands of up to 192 bins: every lane sorts its (up to) three values, then the sorted triples are merged over
-// the wave by a DPP butterfly -- the three largest of the union of two descending triples a, b are
-//   c1 = max(a1, b1)   c2 = max(a2, b2, min(a1, b1))   c3 = max(a3, b3, min(a2, b1), min(a1, b2))
-// (and the mirror image for the three smallest): six steps of ten instructions, no scalar round trip, no loop over k.
-// A merge of a triple with ITSELF is wrong (elements would count twice): the row-broadcast steps leave garbage in the
-// rows they do not write, which no later step reads -- the result is taken from lane 63.
-template <int CTRL, int ROWMASK, bool TOP>
-__device__ __forceinline__ void merge3_step(float& a1, float& a2, float& a3) {
-  float b1, b2, b3;
-  if (ROWMASK == 0xF) { b1 = dpp_f<CTRL>(a1); b2 = dpp_f<CTRL>(a2); b3 = dpp_f<CTRL>(a3); }
-  else { b1 = dpp_rows_f<CTRL, ROWMASK>(a1); b2 = dpp_rows_f<CTRL, ROWMASK>(a2); b3 = dpp_rows_f<CTRL, ROWMASK>(a3); }
-  if (TOP) {
-    const float c3 = fmaxf(fmaxf(a3, b3), fmaxf(fminf(a2, b1), fminf(a1, b2)));
-    const float c2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
-    a1 = fmaxf(a1, b1); a2 = c2; a3 = c3;
-  } else {
-    const float c3 = fminf(fminf(a3, b3), fminf(fmaxf(a2, b1), fmaxf(a1, b2)));
-    const float c2 = fminf(fminf(a2, b2), fmaxf(a1, b1));
-    a1 = fminf(a1, b1); a2 = c2; a3 = c3;
-  }
-}
-template <bool TOP>
-__device__ __forceinline__ void wave_merge3(float& a1, float& a2, float& a3) {
-  merge3_step<DPP_QP_1032, 0xF, TOP>(a1, a2, a3);
-  merge3_step<DPP_QP_2301, 0xF, TOP>(a1, a2, a3);
-  merge3_step<DPP_ROW_HALF_MIRROR, 0xF, TOP>(a1, a2, a3);
-  merge3_step<DPP_ROW_MIRROR, 0xF, TOP>(a1, a2, a3);
-  merge3_step<DPP_ROW_BCAST15, 0xA, TOP>(a1, a2, a3);
-  merge3_step<DPP_ROW_BCAST31, 0xC, TOP>(a1, a2, a3);
-  a1 = rl_f(a1, 63); a2 = rl_f(a2, 63); a3 = rl_f(a3, 63);
-}
-__device__ __forceinline__ void contrast_top3(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
-  float t[3], u[3];                                  // descending with -1 pads / ascending with +huge pads
-  lds_row pr = prow + ppos(lo + lane);              // (bin lo + lane + 64 r at ppos(lo + lane) + 68 r)
-  const int nrem = n - lane;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const float p = pr[68 * r];
-    t[r] = (64 * r < nrem) ? p : -1.f;
-    u[r] = (64 * r < nrem) ? p : 3.4e38f;
-  }
-  auto cx = [](float& hi, float& lw) { const float a = hi, b = lw; hi = fmaxf(a, b); lw = fminf(a, b); };
-  cx(t[0], t[1]); cx(t[1], t[2]); cx(t[0], t[1]);    // t0 >= t1 >= t2
-  cx(u[1], u[0]); cx(u[2], u[1]); cx(u[1], u[0]);    // u0 <= u1 <= u2
-  wave_merge3<true>(t[0], t[1], t[2]);
-  wave_merge3<false>(u[0], u[1], u[2]);
-  spk = fsqrt(t[0]) + (k >= 2 ? fsqrt(t[1]) : 0.f) + (k >= 3 ? fsqrt(t[2]) : 0.f);
-  svl = fsqrt(u[0]) + (k >= 2 ? fsqrt(u[1]) : 0.f) + (k >= 3 ? fsqrt(u[2]) : 0.f);
-}
-
-// Wide bands whose last register is the only partly filled one (64 (R - 1) < n <= 64 R; C4's 751-bin band at 48 kHz,
-// the 728-bin band at 44.1 kHz: R = 12), 4 <= k <= 16: selection on STATIC registers, no parked lists, no re-reads.
-// A lane sorts its R values once (pads +huge on top); its four largest are then v[R-1 .. R-4], one register lower in
-// the lanes that hold a pad, its four smallest v[0 .. 3].  The threshold Th = k-th largest lane maximum (rounded down:
-// wave_kth_largest2_u32) has at least k values at or above it, all of them among the lanes' top values; the first
-// three of each lane are counted and summed, the few extras (count - k) are taken back smallest first, one wave-wide
-// round each.  A lane whose FOURTH value still reaches the threshold might hide a fifth: the function then reports
-// failure and the caller runs the general form (contrast_extract_lds) -- as it does for many extras (ties, constant
-// bands).  Mirror image for the k smallest.
-template <int R>
-__device__ __forceinline__ bool contrast_select(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
-  float v[R];
-  lds_row pr = prow + ppos(lo + lane);            // bin lo + lane + 64 r at ppos(lo + lane) + 68 r
-#pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = pr[68 * r];
-  const bool hp = lane >= n - 64 * (R - 1);       // no value of this lane in the last register
-  v[R - 1] = hp ? 3.4e38f : v[R - 1];
-#pragma unroll
-  for (int c = 0; c < SortNet<R>::N; ++c) {
-    constexpr auto& P = SortNet<R>::P;
-    const int i = P[c][0], j = P[c][1];
-    const float a = v[i], b = v[j];
-    v[i] = fminf(a, b); v[j] = fmaxf(a, b);
-  }
-  const float t1 = hp ? v[R - 2] : v[R - 1], t2 = hp ? v[R - 3] : v[R - 2], t3 = hp ? v[R - 4] : v[R - 3],
-              t4 = hp ? v[R - 5] : v[R - 4];
-  const float b1 = v[0], b2 = v[1], b3 = v[2], b4 = v[3];
-  uint32_t Tu, Bu;
-#if SYG_SEL2
-  wave_kth_largest2x2_u32<SYG_SELBITS>(__float_as_uint(t1), __float_as_uint(t2), ~__float_as_uint(b1), ~__float_as_uint(b2), k, Tu, Bu);
-#else
-  wave_kth_largest2_u32<16>(__float_as_uint(t1), ~__float_as_uint(b1), k, Tu, Bu);
-#endif
-  const float Th = __uint_as_float(Tu), Tl = __uint_as_float(~Bu);
-  if (__ballot(t4 >= Th || b4 <= Tl) != 0) return false;
-  int ch = (t1 >= Th ? 1 : 0) + (t2 >= Th ? 1 : 0) + (t3 >= Th ? 1 : 0);
-  int cl = (b1 <= Tl ? 1 : 0) + (b2 <= Tl ? 1 : 0) + (b3 <= Tl ? 1 : 0);
-  const int Eh = wave_sum_i(ch) - k, El = wave_sum_i(cl) - k;
-  if (Eh > 10 || El > 10) return false;
-  const float q1 = fsqrt(t1), q2 = fsqrt(t2), q3 = fsqrt(t3), r1 = fsqrt(b1), r2 = fsqrt(b2), r3 = fsqrt(b3);
-  float Sh = wave_sum((ch >= 1 ? q1 : 0.f) + (ch >= 2 ? q2 : 0.f) + (ch >= 3 ? q3 : 0.f));
-  float Sl = wave_sum((cl >= 1 ? r1 : 0.f) + (cl >= 2 ? r2 : 0.f) + (cl >= 3 ? r3 : 0.f));
-  const int emax = Eh > El ? Eh : El;
-  for (int e = 0; e < emax; ++e) {
-    // this lane's smallest upper / largest lower candidate (as magnitudes: the order is the same)
-    const float lo_c = ch == 3 ? q3 : ch == 2 ? q2 : ch == 1 ? q1 : 3.4e38f;
-    const float hi_c = cl == 3 ? r3 : cl == 2 ? r2 : cl == 1 ? r1 : -1.f;
-    float MH = hi_c, ML = lo_c;
-    wave_maxmin(MH, ML);
-    const int fh = __ffsll((long long)__ballot(hi_c == MH)) - 1;
-    const int fl = __ffsll((long long)__ballot(lo_c == ML)) - 1;
-    if (e < Eh) { Sh -= ML; ch -= (lane == fl) ? 1 : 0; }
-    if (e < El) { Sl -= MH; cl -= (lane == fh) ? 1 : 0; }
-  }
-  spk = Sh; svl = Sl;
-  return true;
-}
-
-// mean of the k smallest and k largest MAGNITUDES of bins [lo, hi) of one LDS power row (identical to sorting,
-// as librosa does: values are non-negative, selection on power == selection on magnitude).
-//   bands of <= 768 bins with k <= 16 : register extraction, specialised by registers per lane;
-//   otherwise                         : radix select of the k-th order statistic + tail sum closed with the
-//                                       tie count.
-// may_park: the bands come in ascending order and the row's statistics are done, so a wide band may park its sorted
-// lists in the part of the row below its own end (contrast_extract_lds)
-__device__ __forceinline__ float2 band_contrast(lds_row prow, int lane, int lo, int hi, int k, int may_park) {   // (peak, valley)
-  const int n = hi - lo;
-  if (n <= 768 && k <= 16) {
-    float spk, svl;
-    if (k == 1) contrast_minmax(prow, lane, lo, n, spk, svl);
-    else if (k <= 3 && n <= 192) contrast_top3(prow, lane, lo, n, k, spk, svl);
-    else if (n <= 64) contrast_extract<1>(prow, lane, lo, n, k, spk, svl);
-    else if (n <= 128) contrast_extract<2>(prow, lane, lo, n, k, spk, svl);
-    else if (n <= 256) contrast_extract<4>(prow, lane, lo, n, k, spk, svl);
-    else {
-      // Bands of more than 256 bins with k >= 4 whose registers are all full but the last (64 (R - 1) < n <= 64 R for
-      // R = 5, 7, 8, 10, 12 -- the wide bands of the usual sample rates: 298 / 431 bins at 22.05 kHz, 479 at 24 kHz, 616 at
-      // 32 kHz, 728 at 44.1 kHz, 751 at 48 kHz) are taken by selection; whatever it refuses (ties, a lane with more than
-      // three candidates) and every other width by extraction rounds on 7 or 12 registers.
-      bool done = false;
-      if (k >= 4) {
-        if (n > 704) done = contrast_select<12>(prow, lane, lo, n, k, spk, svl);
-        else if (n > 576 && n <= 640) done = contrast_select<10>(prow, lane, lo, n, k, spk, svl);
-        else if (n > 448 && n <= 512) done = contrast_select<8>(prow, lane, lo, n, k, spk, svl);
-        else if (n > 384 && n <= 448) done = contrast_select<7>(prow, lane, lo, n, k, spk, svl);
-        else if (n > 256 && n <= 320) done = contrast_select<5>(prow, lane, lo, n, k, spk, svl);
-      }
-      if (!done) {
-        if (n <= 448) contrast_extract<7>(prow, lane, lo, n, k, spk, svl);
-        else if (may_park && ppos(hi - 1) >= 64 * 12) contrast_extract_lds<12>(prow, lane, lo, n, k, spk, svl);
-        else contrast_extract<12>(prow, lane, lo, n, k, spk, svl);
-      }
-    }
-    const float rk = frcp((float)k);
-    return make_float2(spk * rk, svl * rk);
-  }
-  const uint32_t tlo = row_kth(prow, lane, lo, n, k, false), thi = row_kth(prow, lane, lo, n, k, true);
-  float slo = 0.f, shi = 0.f;
-  int clo = 0, chi = 0;
-  for (int i = lane; i < n; i += 64) {
-    const float p = prow[ppos(lo + i)];
-    const uint32_t u = __float_as_uint(p);
-    const float m = sqrtf(p);
-    if (u < tlo) { slo += m; ++clo; }
-    if (u > thi) { shi += m; ++chi; }
-  }
-  slo = wave_sum(slo); shi = wave_sum(shi);
-  clo = wave_sum_i(clo); chi = wave_sum_i(chi);
-  return make_float2((shi + (float)(k - chi) * sqrtf(__uint_as_float(thi))) / (float)k,
-                     (slo + (float)(k - clo) * sqrtf(__uint_as_float(tlo))) / (float)k);
-}
-
-// Arguments of an out-of-line device function travel in VGPRs; these put the wave-uniform ones back into
-// SGPRs so that the callee's loops and addresses stay scalar.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-template <typename P>
-__device__ __forceinline__ P* uni(P* p) {
-  const uint64_t v = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (P*)(((uint64_t)hi << 32) | lo);
-}
 __device__ __forceinline__ MfccArgs uni(const MfccArgs& a) {
   MfccArgs u;
   u.dct = uni(a.dct); u.lifter = uni(a.lifter); u.out = uni(a.out); u.n_mfcc = uni(a.n_mfcc);
   u.ref_is_max = uni(a.ref_is_max); u.ref_value = uni(a.ref_value); u.amin = uni(a.amin); u.top_db = uni(a.top_db);
   u.tp = uni(a.tp); u.rows_per_clip = uni(a.rows_per_clip);
   return u;
-}
-
-// The LEADING bands with k = 1 that end at or below bin 192 (C4: five of the seven bands, bins 0 ... 135) in ONE pass: the
-// bins sit in three strided registers (bin lane + 64 r); band b's largest power goes to slot 2 b, the negative of its
-// smallest to slot 2 b + 1 (so that all sixteen slots are MAX reductions), and the sixteen slots are reduced over the wave
-// together by a butterfly that halves the number of live slots at every step: at the step with lane distance d the
-// lanes with bit d clear keep the even slot of a pair and hand the odd one to their partner, and vice versa -- 56
-// instructions for sixteen wave-wide reductions instead of sixteen times six.  Afterwards every lane holds the wave's
-// result of slot (lane & 15); lane b fetches its band's two slots through the LDS crossbar.
-// Returns the number of bands taken (0: fewer than two such bands, the caller's loop does everything).
-template <int CTRL>
-__device__ __forceinline__ float dpp_partner(float v) { return dpp_f<CTRL>(v); }
-__device__ __forceinline__ float xor4_partner(float v) {       // lane ^ 4 inside a row: two bank-masked row shifts
-  int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x114 /* row_shr:4 */, 0xF, 0xA, false);
-  t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x104 /* row_shl:4 */, 0xF, 0x5, false);
-  return __int_as_float(t);
-}
-__device__ __forceinline__ int contrast_narrow_group(lds_row prow, int lane, int plo, int phi, int pk, int n_rows,
-                                                     float& rp, float& rv) {
-  // leading run of bands with k == 1 and hi <= 192 (lane = band in plo / phi / pk)
-  const uint64_t okm = __ballot(lane < n_rows && pk == 1 && phi <= 192 && phi > plo);
-  int nb = __ffsll((long long)~okm) - 1;                      // (~okm is never zero: lanes >= 16 are clear)
-  nb = nb > 8 ? 8 : nb;
-#ifdef SYG_NO_NARROW_GROUP
-  return 0;                                                    // (timing variant: every band through the loop)
-#endif
-  if (nb < 2) return 0;
-  lds_row pr = prow + ppos(lane);                              // bin lane + 64 r at ppos(lane) + 68 r
-  const float q0 = pr[0], q1 = pr[68], q2 = pr[136];
-  float v[16];
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    float mx = -3.4e38f, mn = -3.4e38f;
-    if (b < nb) {                                              // (wave-uniform)
-      const int lo = __builtin_amdgcn_readlane(plo, b), n = __builtin_amdgcn_readlane(phi, b) - lo;
-      const bool i0 = (unsigned)(lane - lo) < (unsigned)n, i1 = (unsigned)(lane + 64 - lo) < (unsigned)n,
-                 i2 = (unsigned)(lane + 128 - lo) < (unsigned)n;
-      mx = fmaxf(fmaxf(i0 ? q0 : mx, i1 ? q1 : mx), i2 ? q2 : mx);
-      mn = fmaxf(fmaxf(i0 ? -q0 : mn, i1 ? -q1 : mn), i2 ? -q2 : mn);
-    }
-    v[2 * b] = mx; v[2 * b + 1] = mn;
-  }
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-  float w[8], x[4], y[2];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    w[j] = fmaxf(b0 ? v[2 * j + 1] : v[2 * j], dpp_partner<DPP_QP_1032>(b0 ? v[2 * j] : v[2 * j + 1]));
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    x[j] = fmaxf(b1 ? w[2 * j + 1] : w[2 * j], dpp_partner<DPP_QP_2301>(b1 ? w[2 * j] : w[2 * j + 1]));
-#pragma unroll
-  for (int j = 0; j < 2; ++j) y[j] = fmaxf(b2 ? x[2 * j + 1] : x[2 * j], xor4_partner(b2 ? x[2 * j] : x[2 * j + 1]));
-  float z = fmaxf(b3 ? y[1] : y[0], dpp_partner<0x128 /* row_ror:8 = lane ^ 8 */>(b3 ? y[0] : y[1]));
-  // the four rows: lane ^ 16, then lane ^ 32
-  {
-    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);
-    z = fmaxf(z, __uint_as_float((lane & 16) ? r16[0] : r16[1]));
-    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
-    z = fmaxf(z, __uint_as_float((lane & 32) ? r32[0] : r32[1]));
-  }
-  // slot s sits in every lane with (lane & 15) == s: lane b takes slots 2 b and 2 b + 1
-  const int src = (2 * lane) & 15;
-  const float pmax = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * src, __float_as_int(z)));
-  const float nmin = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (src + 1), __float_as_int(z)));
-  rp = (lane < nb) ? fsqrt(pmax) : rp;
-  rv = (lane < nb) ? fsqrt(-nmin) : rv;
-  return nb;
-}
-
-// All contrast bands of one row in ONE out-of-line call (a call per band paid the entry / exit sequence and the
-// argument traffic seven times).  Band r's (peak, valley) tail means come back in lane r of the two result registers;
-// the caller stores them.  The plan (lo, hi, k per band) is read from its LDS copy: one read per array, lane = band.
-typedef const __attribute__((address_space(3))) int* lds_iptr;
-__device__ __forceinline__ float2 row_contrast_body(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
-  const int n_rows = uni(n_rows_v), may_park = uni(may_park_v);
-  const int lb = lane & (SYG_MAX_BANDS - 1);
-  const int plo = cpl[lb], phi = cpl[SYG_MAX_BANDS + lb], pk = cpl[2 * SYG_MAX_BANDS + lb];
-  float rp = 0.f, rv = 0.f;
-  const int r0 = contrast_narrow_group(prow, lane, plo, phi, pk, n_rows, rp, rv);
-  for (int r = r0; r < n_rows; ++r) {
-    const int lo = __builtin_amdgcn_readlane(plo, r), hi = __builtin_amdgcn_readlane(phi, r),
-              k = __builtin_amdgcn_readlane(pk, r);
-    const float2 pv = band_contrast(prow, lane, lo, hi, k, may_park);
-    rp = (lane == r) ? pv.x : rp;
-    rv = (lane == r) ? pv.y : rv;
-  }
-  return make_float2(rp, rv);
-}
-__device__ __noinline__ float row_trivial(lds_row prow, int lane) { return wave_sum(prow[17 * lane]); }
-__device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
-  return row_stats_body(prow, lane, binhz, roll_percent, bw_p, smask);
-}
-__device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
-  return row_contrast_body(prow, lane, cpl, n_rows_v, may_park_v);
-}
-// Statistics AND contrast of one row in one call (the C4 block asks for both: one entry / exit sequence, one wait for
-// the outstanding memory operations, instead of two).  x: the statistics register of row_stats, y / z: peak / valley.
-__device__ __noinline__ float3 row_features(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask,
-                                            lds_iptr cpl, int n_rows_v, int may_park_v) {
-  const float s = row_stats_body(prow, lane, binhz, roll_percent, bw_p, smask);
-  const float2 pv = row_contrast_body(prow, lane, cpl, n_rows_v, may_park_v);
-  return make_float3(s, pv.x, pv.y);
 }
 
 // MODE 3 clip epilogue (a workgroup's chunk is whole clips): power_to_db + DCT-II (+ lifter) from the LDS mel
@@ -1216,14 +458,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr bool COMPLEX_OUT = (MODE == 2);
-  // MODE 5 = MODE 1 (statistics / contrast rows) + MODE 3 (clip-resident dB + DCT): config C4's four features from ONE
-  // launch -- only samples in, MFCCs + statistics rows + contrast tail means out (the mel matrix never reaches HBM)
-  constexpr bool ROWFN = (MODE == 1 || MODE == 5 || MODE == 7 || MODE == 9);   // per-frame row functions (MODE 1 / 5: behind barrier B)
-  constexpr bool CLIPM = (MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7);   // the clip's mel matrix lives in LDS; epilogue at clip end
+  constexpr bool ROWFN = (MODE == 1 || MODE == 7 || MODE == 9);      // per-frame row functions (MODE 1: behind barrier B)
+  constexpr bool CLIPM = (MODE == 3 || MODE == 6 || MODE == 7);      // the clip's mel matrix lives in LDS; epilogue at clip end
   // MODE 0 / 3 (mel only): the power rows hold 4 |X|^2 (wave_rfft2048<.., X2>); the factor is taken back -- exactly, a
   // power of two -- where mel values leave the kernel (MODE 0: at the store; MODE 3: the dB conversion works on 4 x mel
   // with 4 x amin and 4 x ref, the optional mel copy is scaled at its store).  MODE 1's statistics need the true powers.
   constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || MODE == 6 || MODE == 8);
+#ifdef SYG_DEV_NO_RELC
+  constexpr bool RELC = false;                                       // (timeline builds: round 3's form, for the before / after table)
+#else
+  constexpr bool RELC = (MODE == 7);                                 // lane constants re-made per frame (see the tile loop)
+#endif
   constexpr float MELSC = X2 ? 0.25f : 1.f;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Pbuf = lds + LM::O_P;
@@ -1318,7 +563,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   }
   const int tri_ndct = ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4);
   const int tri_idle = (TRI && !TRIMEL) ? mf.tp - (int)T : 0;
-  const bool tri_defer = TRI && !TRIMEL && tri_idle > 0 && (tri_ndct + tri_idle - 1) / tri_idle <= 3;
+  const bool tri_defer = TRI && !TRIMEL && tri_idle > 0 && (tri_ndct + tri_idle - 1) / (tri_idle > 0 ? tri_idle : 1) <= 3;
   // staged mode: the frame of the NEXT tile is fetched (LDS -> registers) one phase ahead, so that the stage
   // buffer can be refilled behind the FFT phase; direct modes load at the top of the tile loop
   float2 v[16];
@@ -1337,7 +582,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     if (tile_begin + 1 < tile_end) dma(tile_begin + 1);
   }
 
-#if SYG_ABL == 9
+#if SYG_DEV
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
@@ -1351,33 +596,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // MODE 1: the row functions behind barrier B are chains of dependent wave-level steps that hide their latency only
     // behind each other; a wave that is through starts its next transform, whose dense vector work would take the
     // issue slots from the waves still in their row functions (oldest wave first at equal priority) and stretch the
-    // tile.  The row functions therefore run at the top level and the transform one level lower (SYG_TAILPRIO = 1;
-    // 0: all equal -- measured 428 vs 373-390 us per 1024 clips of C4; 2-4: other splits, no better).
-#ifndef SYG_TAILPRIO
-#define SYG_TAILPRIO 1
-#endif
-    // MODE 0 / 3: projection, clip epilogue and slab combine at the top level, the transform one level lower
-    // (SYG_CPRIO = 3: 150.3 vs 151.0 us for the one-launch MFCC at C2; 0: the round-2 levels)
-#ifndef SYG_CPRIO
-#define SYG_CPRIO 3
-#endif
-    constexpr int PD = ROWFN ? (SYG_TAILPRIO == 2 || SYG_TAILPRIO == 3 ? 2 : SYG_TAILPRIO == 1 ? 1 : SYG_TAILPRIO == 4 ? 3 : 0)
-                                   : (SYG_CPRIO == 1 || SYG_CPRIO == 3) ? 1 : 0;
-#ifndef SYG_AGEPRIO
-#define SYG_AGEPRIO 0
-#endif
-    // (wave-uniform; SYG_AGEPRIO = n > 0: the n oldest waves one level lower -- measured SLOWER: 148.0 -> 148.7 / 151.2 /
-    // 152.4 us for n = 4 / 8 / 12; n < 0: the -n youngest waves one level lower)
-    const bool older = (SYG_AGEPRIO > 0 && w < SYG_AGEPRIO) || (SYG_AGEPRIO < 0 && w >= WAVES + SYG_AGEPRIO);
-    SETPRIO_AGE(3 - PD > 0 ? 3 - PD : 0, older);
+    // tile.  The row functions therefore run at the top level and the transform one level lower (all equal: 428 against
+    // 373-390 us per 1024 clips of C4; other splits no better).  MODE 0 / 3: projection, clip epilogue and slab combine at
+    // the top level, the transform one level lower (150.3 against 151.0 us for the one-launch MFCC at C2).
+    constexpr int PD = 1;
+    SETPRIO(3 - PD);
     // The filterbank operands of this wave's slots are the same for every tile but cannot stay resident (the FFT needs
     // all 128 VGPRs): the first NPRE groups of four steps are re-fetched every tile, behind pass 3 of the transform.
-    constexpr int NPRE = 7;            // unconditional: every wave's segment holds >= NPRE groups (zero padded)
-#ifndef SYG_NEARLY
-#define SYG_NEARLY 0
-#endif
-    constexpr int NEARLY = SYG_NEARLY; // ... of which this many may be requested behind pass 3 already (up to 5 fit the registers;
-                                       // measured: no gain -- barrier A's wait covers the latency either way -- so 0)
+    constexpr int NPRE = 7;            // unconditional: every wave's segment holds >= NPRE groups (zero padded); requested
+                                       // in front of barrier A (behind pass 3 already: measured, no gain -- the barrier's
+                                       // wait covers the latency either way)
     const int ng = plan.steps >> 2;
     const float4* wp4w = reinterpret_cast<const float4*>(wpacked) + (int64_t)w * ng * 64;
     float4 apre[NPRE];
@@ -1387,18 +615,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       // loop as ~100 loop-invariant registers that would spill
       int lv = lane;
       asm volatile("" : "+v"(lv));
-#if SYG_ABL == 1
-#pragma unroll
-      for (int a = 0; a < 16; ++a) v[a] = make_float2((float)(lv + a) * 1e-3f, (float)(lv - a) * 1e-3f);
-#endif
-#if SYG_ABL == 5
-      apply_window(v, win2, lv);
-#else
+      // MODE 7 (row functions AND the clip epilogue: the tightest register budget): the 16 integer / constant members of
+      // the lane constants are re-made per frame from the laundered lane id (about 40 integer instructions) -- kept live
+      // across the out-of-line row functions they pushed a register into scratch, and a scratch reload is a memory round
+      // trip that nothing hides (it sat directly behind both call sites: the fixed cost of "any real row function")
+      if (RELC) init_lane_const<false>(lc, lv, twid);
       apply_window(v, winl, lv);
-#endif
       TICK(0, v[0].x);
       float2 xs[2][4], xm[2][4], x512;
-      wave_rfft2048<COMPLEX_OUT ? 0 : NEARLY, PD, X2>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512, wp4w, apre, older TPASS);
+      wave_rfft2048<PD, X2>(v, lc, sc, tw1l, tw2l, lv, xs, xm, x512 TPASS);
       if (COMPLEX_OUT) {
         float2* o = cout + (b * T + t) * NBIN;
 #pragma unroll
@@ -1428,8 +653,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       }
     } else if (!COMPLEX_OUT && !TRI) {
       for (int k = lane; k < P_STRIDE; k += 64) prow[k] = 0.f;
-#pragma unroll
-      for (int q = 0; q < NEARLY; ++q) apre[q] = wp4w[q * 64 + lane];
     }
     SETPRIO(0);
     if (COMPLEX_OUT) continue;
@@ -1440,22 +663,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       // the output tiles of the clip BEFORE while the others transform -- the epilogue then costs nothing; otherwise the
       // first waves form them right behind the clip's last tile, beside the other waves' next transform (which fills
       // the OTHER mel matrix).  Whatever is pending when the workgroup runs out of tiles is formed behind the loop.
-#ifndef SYG_TRIPRIO
-#define SYG_TRIPRIO 3
-#endif
-      SETPRIO(SYG_TRIPRIO);
+      SETPRIO(3);             // projection, clip epilogue and row functions at the top level
       const bool mine = (t < T);
       const bool clip_done = (t0 + TILE_T >= T);
       float* cmc = clipmel + cur * (n_mels * mf.tp);
-      // MODE 6, WHEN a wave projects (SYG_P6SPLIT=1; off: what pays for the row functions of MODE 7 below does not pay
-      // here, the transform is 80 % of the interval): half of the waves of every SIMD (w & 4) behind the two barriers
-      // instead of in front of them, with their next frame already in registers -- their column of the clip's matrix and their share of its
-      // maximum arrive one barrier interval late (before X1 of the NEXT tile), which the deferred epilogue never sees (it
-      // runs a whole clip later; hence: deferred epilogue only, at least two tiles per clip, a barrier in front of the
-      // epilogue behind the loop).  Between two barriers every wave still transforms one frame and projects one row, but
-      // one half projects (latency-bound LDS reads and scans) while the other half transforms.
-      const bool proj_split = SYG_P6SPLIT && !ROWFN && LOAD == 2 && tri_defer && tiles_per_clip >= 2;
-      const bool proj_late = proj_split && ((w >> 2) & 1);
       auto project = [&]() {
         int la = lane;
         asm volatile("" : "+v"(la)::"memory");
@@ -1479,9 +690,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         if (lane == 0) tri_red[cur * WAVES + w] = cm;
       };
       const bool tri_proj = wpacked != nullptr;
+#if SYG_DEV
+      int tdep = lane;
+      TICK(5, tdep);                   // (split + row store)
+#endif
       if (mine) {
-        if (!proj_late && tri_proj) project();
-      } else if (tri_defer && pend_b >= 0 && SYG_TRIX != 1) {
+        if (tri_proj) project();
+      } else if (tri_defer && pend_b >= 0) {
         float* cmp = clipmel + (cur ^ 1) * (n_mels * mf.tp);
         clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmp, (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES),
                         (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)pend_b, w - (WAVES - tri_idle), lane, tri_idle);
@@ -1492,50 +707,44 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       // low words).  WHEN a wave runs them: half of the waves of every SIMD (w & 4) right behind their projection, the
       // other half behind X2 in front of their next transform -- between two barriers every wave does the same work, but
       // one half transforms while the other half runs its chains of dependent reductions, instead of all sixteen doing
-      // the same thing at the same time (all behind X2: SYG_R7SPLIT=0; all in front of X1 was the first build, 832 us).
+      // the same thing at the same time (all behind X2, all in front of X1 -- the first build, 832 us -- measured slower).
+      // Waves w, w + 4, w + 8, w + 12 share a SIMD: two of them early, two late.
       float row_sres = 0.f;
       float2 row_pv = make_float2(0.f, 0.f);
-      const bool row_early = SYG_R7SPLIT && ((w >> SYG_R7SHIFT) & 1);
+      const bool row_early = (w >> 2) & 1;
       auto row_compute = [&]() {
-        if (SYG_R7PRIO != SYG_TRIPRIO) SETPRIO(SYG_R7PRIO);
-        // timing ablations (WRONG results): 1 = a trivial inline stand-in, 2 = a trivial out-of-line function
-#if SYG_R7ABL == 1
-        if (true) { row_sres = wave_sum(prow[17 * lane]); } else
-#elif SYG_R7ABL == 2
-        if (true) { row_sres = row_trivial((lds_row)prow, lane); } else
-#endif
-        if (SYG_ROWBOTH && stats_out != nullptr && contrast_out != nullptr) {
-          const float3 f = row_features((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc, cplan.n_rows,
-                                        cplan.ascending);
+        if (stats_out != nullptr && contrast_out != nullptr) {
+          const float3 f = row_features<NBIN, 0>((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc,
+                                                     cplan.n_rows, cplan.ascending);
           row_sres = f.x; row_pv = make_float2(f.y, f.z);
         } else {
-          if (stats_out != nullptr) row_sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
-          if (contrast_out != nullptr) row_pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
+          if (stats_out != nullptr) row_sres = row_stats<NBIN, 0>((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
+          if (contrast_out != nullptr)
+            row_pv = row_contrast_all<0>((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
         }
       };
+      TICK(6, tdep);                   // projection (or the deferred clip epilogue)
       if (ROWFN && mine && row_early) {
         // (the three result registers wait in the wave's own row, dead until its next transform: live across the fetch of
         // the next frame they cost three spilled registers)
         row_compute();
         prow[lane] = row_sres; prow[64 + lane] = row_pv.x; prow[128 + lane] = row_pv.y;
       }
-      if (CLIPM && clip_done && !proj_late) publish_max();
+      if (CLIPM && clip_done) publish_max();
+      TICK(7, tdep);                   // row functions of the early half
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                  // X1: the clip's columns of this tile are written too
+      TICK(8, tdep);                   // wait at X1
       if (LOAD == 2) {
         have = false;
         if (tile + 1 < tile_end) fetch(tile + 1);
         __syncthreads();                                // X2: every wave holds its next frame
       }
-      if (proj_late) {
-        if (tile + 2 < tile_end) dma(tile + 2);
-        if (mine && tri_proj) project();
-        if (clip_done) publish_max();
-      }
+      TICK(9, tdep);                   // fetch of the next frame + wait at X2
       if (CLIPM && clip_done) {
         // (clip_dct's entry waits for outstanding memory operations, so the refill is issued behind it)
         if (tri_defer) pend_b = mf.n_mfcc > 0 ? (int64_t)b : pend_b;
-        else if (w < tri_ndct && SYG_TRIX != 1)
+        else if (w < tri_ndct)
           clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)cmc, (int)(uintptr_t)(lds_fptr)(tri_red + cur * WAVES),
                           (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels, (int)T, (int)b, w, lane);
         cur ^= 1;
@@ -1543,36 +752,26 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       if (ROWFN && mine) {
         if (!row_early) row_compute();
         else { row_sres = prow[lane]; row_pv = make_float2(prow[64 + lane], prow[128 + lane]); }
+        TICK(10, tdep);                // row functions of the late half (+ the clip epilogue where it is not deferred)
         if (contrast_out != nullptr) {
           if (lane < cplan.n_rows) {
             contrast_out[((b * 2 + 0) * cplan.n_rows + lane) * T + t] = row_pv.x;
             contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = row_pv.y;
           }
         }
+#if SYG_DEV
+        if (stats_out != nullptr && row_sres == 12345.678f)      // (timeline build: stats_out carries the phase counters)
+#else
         if (stats_out != nullptr && lane < SYG_NSTAT && ((stats_row_mask(smask) >> lane) & 1))
+#endif
           stats_out[(b * SYG_NSTAT + lane) * T + t] = row_sres;
       }
-      if (LOAD == 2 && !proj_late && tile + 2 < tile_end) dma(tile + 2);
+      if (LOAD == 2 && tile + 2 < tile_end) dma(tile + 2);
+      TICK(11, tdep);                  // the tile's stores + the stage refill
       SETPRIO(0);
       continue;
     }
-#if SYG_ABL == 10 || SYG_ABL == 11
-    // ablation (WRONG results): free-running waves -- no projection, no slab, no reduce, no workgroup barrier; the
-    // stage hand-over is unsynchronised.  Lower bound for a design whose waves never meet (10), or meet once per
-    // tile (11).
-    if (LOAD == 2) {
-      have = false;
-      if (tile + 1 < tile_end) fetch(tile + 1);
-#if SYG_ABL == 11
-      __syncthreads();
-#endif
-      if (tile + 2 < tile_end) dma(tile + 2);
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    }
-    if (lane == 0 && mel_out != nullptr && t < T) mel_out[(b * n_mels) * T + t] = prow[5];
-    continue;
-#endif
-#if SYG_ABL == 9
+#if SYG_DEV
     int tdep = lane;
     TICK(5, tdep);
 #endif
@@ -1580,22 +779,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     asm volatile("" : "+v"(la)::"memory");
     const float4* wp4 = wp4w + la;
 #pragma unroll
-    for (int q = NEARLY; q < NPRE; ++q) apre[q] = wp4[q * 64];
+    for (int q = 0; q < NPRE; ++q) apre[q] = wp4[q * 64];
     const int pslot = mtab[w * 4 + (la >> 4)];          // row POSITION (skewed, see ppos()) of this lane's slot
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (staged mode: the next tile's samples have landed too)
     __syncthreads();                                    // barrier A: rows complete
     TICK(6, tdep);
-    if (!ROWFN && SYG_CPRIO == 3) SETPRIO(3);           // projection (+ clip epilogue) at the top level
+    if (!ROWFN) SETPRIO(3);                             // projection (+ clip epilogue) at the top level
     if (CLIPM && pend_b >= 0) {
-#ifndef SYG_DCTSHIFT
-#define SYG_DCTSHIFT 0
-#endif
-      {
-        const int wd = (w + WAVES - SYG_DCTSHIFT) % WAVES;       // output tile wd is formed by wave (wd + SYG_DCTSHIFT) mod WAVES
-        if (wd < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6 && SYG_ABL != 7)
-          clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp),
-                          (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp + WAVES), mf, n_mels, (int)T, (int)pend_b, wd, lane);
-      }
+      if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4))    // output tile w is formed by wave w
+        clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp),
+                        (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp + WAVES), mf, n_mels, (int)T, (int)pend_b, w, lane);
       pend_b = -1;
       TICK(10, tdep);
     }
@@ -1654,7 +847,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     }
     __syncthreads();                // barrier B: slab complete (and every wave has read its staged frame)
     TICK(8, tdep);
-    if (!ROWFN && (SYG_CPRIO == 1 || SYG_CPRIO == 2)) SETPRIO(3);         // experiment: the slab combine at the top level
     const bool clip_done = CLIPM && (t0 + TILE_T >= T);
     // MODE 1 runs out-of-line row functions below: a function entry waits for EVERY outstanding memory operation
     // (s_waitcnt vmcnt(0) -- the callee cannot know the caller's counters), so nothing may be in flight when they are
@@ -1667,13 +859,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     // valid until the next tile's projection -- so that their entry does not wait for these stores.)
     auto combine = [&]() {
       constexpr int GL = 4 * TILE_T;               // outputs per group and tile (64 at 16 frames)
-#ifndef SYG_REDSHIFT
-#define SYG_REDSHIFT 6
-#endif
-      // group g is combined by wave (g + SYG_REDSHIFT) mod WAVES.  Ten groups at 40 mels: with shift 0 the ten OLDEST waves
-      // carry the combine and the six youngest -- which the arbiter already serves last -- none; shift 6 gives it to
-      // the waves 6 .. 15 (148.5 vs 150.8 us for the one-launch MFCC at C2; 3: 149.1, 10: slower than 6)
-      for (int g = (w + WAVES - SYG_REDSHIFT) % WAVES; g < plan.n_groups; g += WAVES) {
+      // group g is combined by wave (g + 6) mod WAVES.  Ten groups at 40 mels: with shift 0 the ten OLDEST waves carry
+      // the combine and the six youngest -- which the arbiter already serves last -- none; shift 6 gives it to the
+      // waves 6 .. 15 (148.5 vs 150.8 us for the one-launch MFCC at C2; 3: 149.1, 10: slower than 6)
+      constexpr int REDSHIFT = 6;
+      for (int g = (w + WAVES - REDSHIFT) % WAVES; g < plan.n_groups; g += WAVES) {
         const int first = __builtin_amdgcn_readfirstlane(mtab[128 + g]);
         const int cnt = __builtin_amdgcn_readfirstlane(mtab[192 + g]);
         int lq = lane;                    // laundered (see lv above): no hoisted per-lane addresses that would spill
@@ -1695,7 +885,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
               clipmel[mel * mf.tp + (int)t0 + tt] = sum;     // frames >= T hold 0 (rows were cleared)
               cmax = fmaxf(cmax, sum);                        // power is non-negative
             }
-            if (SYG_ABL != 9 && mel_out != nullptr && mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = MELSC * sum;
+            if (!SYG_DEV && mel_out != nullptr && mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = MELSC * sum;
           } else {
             if (mel < n_mels && t0 + tt < T) mel_out[(b * n_mels + mel) * T + t0 + tt] = MELSC * sum;
           }
@@ -1718,29 +908,20 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
     TICK(9, tdep);
     // ---- phase 2b: per-frame statistics / contrast means from the same LDS rows
     if (ROWFN && (stats_out != nullptr || contrast_out != nullptr)) {
-      if (SYG_TAILPRIO == 1 || SYG_TAILPRIO == 3 || SYG_TAILPRIO == 4) SETPRIO(3);
-      if (SYG_TAILPRIO == 2) { if (w >= WAVES / 2) SETPRIO(3); else SETPRIO(2); }   // the younger half would otherwise run on leftovers
+      SETPRIO(3);
       if (t < T) {
         // statistics first (a wide contrast band parks its lists in the row's low words); every result waits in a lane
         // of a register and is stored behind the last call
         float sres = 0.f, pk = 0.f, vl = 0.f;
-        // timing ablations (WRONG results): 20 = no row function is called, 21 = a trivial inline stand-in
-#if SYG_ABL == 20
-        if (false) {
-#elif SYG_ABL == 21
-        if (stats_out != nullptr) sres = wave_sum(prow[17 * lane]);
-        if (false) {
-#else
-        const bool both = SYG_ROWBOTH && stats_out != nullptr && contrast_out != nullptr;
+        const bool both = stats_out != nullptr && contrast_out != nullptr;
         if (both) {
-          const float3 f = row_features((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc, cplan.n_rows,
-                                        cplan.ascending);
+          const float3 f = row_features<NBIN, 0>((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc,
+                                                     cplan.n_rows, cplan.ascending);
           sres = f.x; pk = f.y; vl = f.z;
-        } else if (stats_out != nullptr) sres = row_stats((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
+        } else if (stats_out != nullptr) sres = row_stats<NBIN, 0>((lds_row)prow, lane, binhz, roll_percent, bw_p, smask);
         if (contrast_out != nullptr) {
-#endif
           if (!both) {
-            const float2 pv = row_contrast_all((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
+            const float2 pv = row_contrast_all<0>((lds_row)prow, lane, (lds_iptr)cplc, cplan.n_rows, cplan.ascending);
             pk = pv.x; vl = pv.y;
           }
           if (lane < cplan.n_rows) {
@@ -1748,7 +929,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
             contrast_out[((b * 2 + 1) * cplan.n_rows + lane) * T + t] = vl;
           }
         }
-#if SYG_ABL == 9
+#if SYG_DEV
         if (stats_out != nullptr && sres == 12345.678f)      // (timeline build: stats_out carries the phase counters)
 #else
         if (stats_out != nullptr && lane < SYG_NSTAT && ((stats_row_mask(smask) >> lane) & 1))
@@ -1759,7 +940,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       // row finished before barrier B, and the row is next written by this wave's own FFT: no barrier needed)
     }
     if (TAIL) {
-      if (SYG_TAILPRIO != 0) SETPRIO(0);
+      SETPRIO(0);
       TICK(11, tdep);
       combine();
       if (clip_done) publish();
@@ -1769,23 +950,21 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   if (TRIMEL) {
     // (no clip epilogue: the mel columns are in HBM)
   } else if (TRI) {
-    // (deferred epilogue: the last clip's matrix is complete behind X1 of its last tile -- or, with the projections of half
-    // of the waves behind the barriers, behind one more)
-    if (SYG_P6SPLIT && !ROWFN && LOAD == 2 && tri_defer && tiles_per_clip >= 2) __syncthreads();
-    if (pend_b >= 0 && w < tri_ndct && SYG_TRIX != 1)
+    // (deferred epilogue: the last clip's matrix is complete behind X1 of its last tile)
+    if (pend_b >= 0 && w < tri_ndct)
       clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)(clipmel + (cur ^ 1) * (n_mels * mf.tp)),
                       (int)(uintptr_t)(lds_fptr)(tri_red + (cur ^ 1) * WAVES), (int)(uintptr_t)(lds_fptr)tri_dct, mf, n_mels,
                       (int)T, (int)pend_b, w, lane);
   } else if (CLIPM && pend_b >= 0) {
     __syncthreads();
-    if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4) && SYG_ABL != 6)
+    if (w < ((mf.n_mfcc + 15) >> 4) * (mf.tp >> 4))
       clip_dct<WAVES>((int)(uintptr_t)(lds_fptr)clipmel, (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp),
                       (int)(uintptr_t)(lds_fptr)(clipmel + n_mels * mf.tp + WAVES), mf, n_mels, (int)T, (int)pend_b, w, lane);
   }
-#if SYG_ABL == 9
+#if SYG_DEV
   if (MODE == 3 && lane < 12)
     mel_out[((int64_t)blockIdx.x * WAVES + w) * 16 + lane] = (float)tacc[lane] / (float)(tile_end - tile_begin);
-  if (MODE == 1 && lane < 12)
+  if ((MODE == 1 || MODE == 7 || MODE == 9) && stats_out != nullptr && lane < 12)
     stats_out[((int64_t)blockIdx.x * WAVES + w) * 16 + lane] = (float)tacc[lane] / (float)(tile_end - tile_begin);
 #endif
 }
@@ -1853,7 +1032,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   constexpr bool TRI = (MODE == 6 || MODE == 7);
   size_t lds = TRIMEL ? lds_bytes<WAVES, false, 4>() : lds_bytes<WAVES, !TRI>();
   if (TRIMEL) mf.tp = tiles * WAVES;
-  if (MODE == 3 || MODE == 5 || TRI) {
+  if (MODE == 3 || TRI) {
     // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
     int cw = 0, cper = 0;
     persistent_grid(B, WAVES, cw, cper);
@@ -1876,7 +1055,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   {
     // set at every launch: the attribute belongs to the (function, device) pair, and a per-process "already set"
     // flag would leave a second device without it
-    const size_t cap = (MODE == 3 || MODE == 5 || TRI) ? LDS_LIMIT : TRIMEL ? lds_bytes<WAVES, false, 4>() : lds_bytes<WAVES>();
+    const size_t cap = (MODE == 3 || TRI) ? LDS_LIMIT : TRIMEL ? lds_bytes<WAVES, false, 4>() : lds_bytes<WAVES>();
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
@@ -2040,7 +1219,7 @@ extern "C" int syg_stft2048_mfcc_tri_f32(const float* y, int64_t B, int64_t L, i
                        0.f, 0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
 }
 
-// MODE 7: syg_stft2048_features_f32 (MODE 5: MFCC rows + statistics rows + contrast tail means from ONE launch) with the
+// MODE 7: MFCC rows + statistics rows + contrast tail means from ONE launch, with the
 // segment-sum projection of syg_stft2048_mfcc_tri_f32 -- BASELINE config C4 without a mel matrix in HBM and without
 // the projection's barriers; the clip epilogue runs on the waves that have no frame (see MODE 6).
 extern "C" int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
@@ -2139,43 +1318,6 @@ extern "C" int syg_stft2048_stats_f32(const float* y, int64_t B, int64_t L, int6
   mf.amin = 1e-10f; mf.top_db = -1.f;
   return launch<16, 7>(2, y, B, L, ldy, hop, center, T, window, twiddle, nullptr, plan, 0, nullptr, sr / (float)NFFT,
                        roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr, (hipStream_t)stream, mf);
-}
-
-// MODE 5: the statistics / contrast rows of syg_stft2048_mel_f32 AND the clip-resident MFCC of syg_stft2048_mfcc_f32
-// from one launch (BASELINE config C4: extract_features(["mfcc", "spectral_centroid", "spectral_rolloff",
-// "spectral_contrast"]), manager.py:289-371).  mfcc_out rows of clip b start at (b * mfcc_rows_per_clip) * T, so the
-// MFCCs can be written straight into the head of a wider per-clip block.
-extern "C" int syg_stft2048_features_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
-                                         const float* window, const float* twiddle, const float* wpacked,
-                                         const int32_t* plan_host, int n_mels, const float* dct, int n_mfcc,
-                                         const float* lifter, float amin, float top_db, int ref_is_max, float ref_value,
-                                         float sr, float roll_percent, float bw_p, int stats_mask, float* stats_out,
-                                         const int32_t* cplan_host, float* contrast_out, float* mel_out, float* mfcc_out,
-                                         int mfcc_rows_per_clip, void* stream) {
-  SYG_REQUIRE(wpacked && plan_host && dct && mfcc_out, "stft2048_features: null pointer argument");
-  SYG_REQUIRE(stats_out || contrast_out, "stft2048_features: no statistics requested (use syg_stft2048_mfcc_f32)");
-  MelPlan plan;
-  int rc = parse_mel_plan("stft2048_features", plan_host, n_mels, plan);
-  if (rc) return rc;
-  SYG_REQUIRE(plan_host[1] == 16, "stft2048_features: needs a 16-wave plan (got %d)", plan_host[1]);
-  rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
-  if (rc) return rc;
-  SYG_REQUIRE(n_mfcc >= 1 && n_mfcc <= n_mels && mfcc_rows_per_clip >= n_mfcc, "stft2048_features: need 1 <= n_mfcc <= n_mels "
-              "and mfcc_rows_per_clip >= n_mfcc");
-  SYG_REQUIRE(amin >= 1.17549435e-38f, "stft2048_features: amin must be strictly positive (a normal float)");
-  SYG_REQUIRE(ref_is_max == 0 || ref_is_max == 1, "stft2048_features: ref_is_max must be 0 or 1");
-  SYG_REQUIRE(T < ((int64_t)1 << 24), "stft2048_features: clip too long");
-  ContrastPlan cp;
-  rc = parse_contrast_plan(contrast_out, cplan_host, cp);
-  if (rc) return rc;
-  if (stats_out) SYG_REQUIRE(sr > 0.f && roll_percent >= 0.f && roll_percent <= 1.f && bw_p > 0.f && (stats_mask & 31) != 0 &&
-                                 stats_mask > 0 && stats_mask < 64, "stft2048_features: invalid statistics parameters");
-  MfccArgs mf;
-  mf.dct = dct; mf.lifter = lifter; mf.out = mfcc_out; mf.n_mfcc = n_mfcc; mf.ref_is_max = ref_is_max;
-  mf.ref_value = ref_value; mf.amin = amin; mf.top_db = top_db; mf.tp = 0; mf.rows_per_clip = mfcc_rows_per_clip;
-  return launch<16, 5>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, wpacked, plan, n_mels, mel_out,
-                       sr / (float)NFFT, roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr,
-                       (hipStream_t)stream, mf);
 }
 
 extern "C" int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,

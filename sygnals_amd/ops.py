@@ -338,6 +338,45 @@ def stft_mel_w1024_seg(y: torch.Tensor, sr: float, hop: int = 256, center: bool 
     return out
 
 
+def stft_rows_w1024(y: torch.Tensor, sr: float, hop: int = 256, center: bool = True, window="hann", win_length=None,
+                    n_mels: Optional[int] = None, fmin: float = 0.0, fmax=None, want_stats=False, roll_percent: float = 0.85,
+                    bw_p: float = 2.0, contrast: Optional[np.ndarray] = None):
+    """frame_length 1024: the statistics / contrast rows of stft2048_mel from the segment-sum kernel's launch
+    (syg_stft_rows_w1024_f32), with the mel power block when n_mels is given (needs a piece table: w1024_segtab).
+    Returns (mel [B, M, T] | None, stats [B, 8, T] | None, contrast_pv [B, 2, R, T] | None)."""
+    smask = 31 if want_stats is True else int(want_stats or 0)
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if not smask and contrast is None:
+        raise ValueError("stft_rows_w1024: no statistics requested (stft_mel_w1024_seg gives the mel block alone)")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    tab = None
+    if n_mels is not None:
+        tab = w1024_segtab(sr, n_mels, fmin, fmax)
+        if tab is None:
+            raise SygnalsHipError("stft_rows_w1024: no piece table for this filterbank")
+    B, L = y.shape
+    Tn = num_frames(L, 1024, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device) if tab is not None else None
+    stats = torch.zeros((B, 8, Tn), dtype=torch.float32, device=y.device) if smask else None
+    cpv = cplan_p = None
+    if contrast is not None:
+        cplan = np.ascontiguousarray(contrast, dtype=np.int32)
+        cpv = torch.empty((B, 2, int(cplan[0]), Tn), dtype=torch.float32, device=y.device)
+        cplan_p = cplan.ctypes.data_as(C.c_void_p)
+    rc = lib().syg_stft_rows_w1024_f32(_ptr(y), B, L, _ld(y), hop, int(center), Tn,
+                                       _ptr(window_dev(window, win_length or 1024, 1024)), _ptr(twiddle_dev(1024)), _ptr(tab),
+                                       int(tab.numel()) if tab is not None else 0, int(n_mels or 0), _ptr(mel), float(sr),
+                                       float(roll_percent), float(bw_p), smask, _ptr(stats), cplan_p, _ptr(cpv),
+                                       C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_rows_w1024_f32")
+    return mel, stats, cpv
+
+
 _SMALL_ROW_WORDS = {512: 296, 256: 160}
 
 
@@ -381,6 +420,16 @@ def stft_mel_wseg_small(y: torch.Tensor, sr: float, n_fft: int, hop: int, center
                                            _ptr(tab), int(tab.numel()), n_mels, _ptr(out), C.c_void_p(_stream_ptr()))
     check(rc, "syg_stft_mel_wseg_small_f32")
     return out
+
+
+def stft_rows_seg(y, sr, n_fft, hop, center=True, window="hann", win_length=None, n_mels=None, fmin=0.0, fmax=None,
+                  want_stats=False, roll_percent=0.85, bw_p=2.0, contrast=None):
+    """Statistics / contrast rows (+ the mel power block when n_mels is given) from the segment-sum kernel of frame length
+    1024 (one launch).  Returns (mel | None, stats | None, contrast_pv | None); raises SygnalsHipError for frame lengths
+    without such a kernel."""
+    if n_fft == 1024:
+        return stft_rows_w1024(y, sr, hop, center, window, win_length, n_mels, fmin, fmax, want_stats, roll_percent, bw_p, contrast)
+    raise SygnalsHipError(f"stft_rows_seg: no row functions in the fused kernel of frame length {n_fft}")
 
 
 def stft_mel_segments(y, sr, n_fft, hop, center, window, win_length, n_mels, fmin, fmax):
@@ -443,8 +492,12 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
     if projection not in ("auto", "segments", "matrix"):
         raise ValueError("projection must be 'auto', 'segments' or 'matrix'")
     tri = cfg.segtab4 is not None and fused_waves() == 16 and Tn * n_mels < (1 << 29) and projection != "matrix"
-    if projection == "auto" and cfg.segtab is not None and cfg.wpacked is not None:
-        tri = False       # few pieces (a two-pass table exists, e.g. 40 bands): four passes would be half idle -- matrix form
+    if projection == "auto" and cfg.wpacked is not None:
+        # measured (profiles/r04_rows_start.json vs r04b): the matrix form wins wherever it has a plan -- 128 bands 0.206 ms per
+        # 1024 clips (mel + dB / DCT launch) against 0.241 for four passes of masked segment sums (about 380 vector
+        # instructions per frame), 64 bands 0.178 against 0.214 -- so "auto" keeps it; the segment form serves the plans the
+        # matrix form cannot hold (8-wave development mode beyond 128 bands) and stays selectable
+        tri = False
     if projection == "segments" and not tri:
         raise SygnalsHipError("stft2048_mel: no four-pass piece table for this filterbank (projection='segments')")
     if not tri and cfg.wpacked is None:

@@ -39,7 +39,6 @@ fn = {"mfcc": lambda: ops.stft2048_mfcc(y, 48000, 512, True, "hann", 40, 13),
       "c4blk22k": lambda: FB(y2, 22050),        # the C4 block at other sample rates: contrast bands of 298 + 431 bins (k = 6, 9),
       "c4blk24k": lambda: FB(y2, 24000),        # 273 + 479 (5, 10),
       "c4blk32k": lambda: FB(y2, 32000),        # 206 + 616 (4, 12)
-      "c4blk5": lambda: FB(y2, 48000, one_launch="matrix"),
       "c4blk2": lambda: FB(y2, 48000, one_launch=False),
       "mel256seg": lambda: ops.stft_mel_wseg_small(y, 48000, 256, 64, True, "hann", None, 40),
       "mel512seg": lambda: ops.stft_mel_wseg_small(y, 48000, 512, 128, True, "hann", None, 40),

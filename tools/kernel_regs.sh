@@ -14,7 +14,8 @@ for blk in txt.split('- .agpr_count')[1:]:
     name=re.search(r'\.name:\s+(\S+)',blk).group(1)
     try: dem=subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt',name],capture_output=True,text=True).stdout.strip().split('(')[0]
     except Exception: dem=name
-    if os.environ["PAT"] and os.environ["PAT"] not in dem and os.environ["PAT"] not in name: continue
+    pat=os.environ.get('PAT','')
+    if pat and pat not in dem and pat not in name: continue
     g=lambda k: re.search(k+r':\s+(\d+)',blk).group(1)
     print(f'{dem[:70]:70s} vgpr {g(\".vgpr_count\"):>3s} vspill {g(\".vgpr_spill_count\"):>2s} sgpr {g(\".sgpr_count\"):>3s} sspill {g(\".sgpr_spill_count\"):>3s} scratch {g(\".private_segment_fixed_size\"):>4s} lds {g(\".group_segment_fixed_size\")}')
 "

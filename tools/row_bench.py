@@ -54,7 +54,7 @@ if want("C1 one clip"):
            256 * 160000, 256 * (4 * 160000 + 4 * 13 * 313), n=20)
     del y1, y1b
 # the reference's own manager tests: frame_length=1024 with spectral features (tests/test_features_manager.py:58-62,167-174)
-if want("n_fft=1024 manager"):
+if not ONLY or any("1024" in a or "c4-style" in a for a in ONLY):
     from sygnals_amd.core.features.manager import extract_features_batch
     T4 = 1 + L // 256
     report("a6-a9 n_fft=1024 hop=256: centroid + rolloff through extract_features_batch (device resident), 1024 clips",
