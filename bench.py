@@ -86,6 +86,21 @@ def _cpu_worker(args):
     return el
 
 
+def _cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (None: unlimited / unknown)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())         # cgroup v1
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(target_seconds=10.0, all_cores_seconds=4.0):
     """The oracle (float64 NumPy/SciPy port of the reference CPU path) on the host cores of this box.
 
@@ -99,6 +114,7 @@ def cpu_baseline(target_seconds=10.0, all_cores_seconds=4.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    quota = _cgroup_cpu_quota()               # cores this process can actually get (a 1-GPU box: 16 of the host's 256)
     cores = max(1, min(avail, 16))          # a 1-GPU box's CPU share is 16 cores (the box's own count is reported too)
     _cpu_worker((1, 4))                       # warm-up (imports, FFT plan caches)
     probe = _cpu_worker((2, 16))
@@ -115,11 +131,20 @@ def cpu_baseline(target_seconds=10.0, all_cores_seconds=4.0):
                      f"one clip per call, {cores} processes x 1 thread side by side, slowest worker {max(els):.1f} s in the chain "
                      f"({wall:.1f} s wall with start-up and clip synthesis)",
            "single_core_value": round(L / per_clip / 1e6, 3), "cores_available": avail}
-    if avail > cores:
+    out["cpu_quota_cores"] = quota
+    usable = avail if quota is None else min(avail, int(quota + 0.5))
+    if usable <= cores and avail > cores:
+        out["all_cores_note"] = (f"the affinity mask shows {avail} cores but the cgroup CPU quota is {quota:.1f}: the {cores}-process "
+                                 "figure IS the all-core figure of this box share (256 processes on it: 96 Msamples/s, "
+                                 "profiles/r04_bench_driver_flags.json of round 4's first run -- oversubscribed)")
+    if usable > cores:
         # SURVEY 8(d) "(ii) all host cores": one process per core the affinity mask shows (a box's cgroup share may be
         # smaller than its mask -- the figure is what this process can actually get), a shorter second run
-        n_all = min(avail, 256)
-        n_each = max(4, min(n_per, int(all_cores_seconds / per_clip)))
+        n_all = min(usable, 256)
+        # sized so that the run stays near `all_cores_seconds` even if the extra cores are not really there (a mask of 256
+        # on a 16-core share): the parallelism the first pool actually got decides
+        got = clips * per_clip / max(els)
+        n_each = max(4, min(n_per, int(all_cores_seconds * got / (n_all * per_clip))))
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(n_all) as pool:
             els = pool.map(_cpu_worker, [(1000 + i, n_each) for i in range(n_all)], chunksize=1)

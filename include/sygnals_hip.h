@@ -163,19 +163,21 @@ int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t L, int64_t 
                                   float bw_p, int stats_mask, float* stats_out, const int32_t* cplan_host,
                                   float* contrast_out, float* mfcc_out, int mfcc_rows_per_clip, void* stream);
 
-/* The TILE form of the segment-sum projection with a FOUR-pass piece table (up to 256 pieces): the filterbanks that have
- * no two-pass table -- the reference's default of 128 bands (sygnals/core/features/manager.py:214; `sygnals features extract
- * -f mfcc`, cli/features_cmd.py:82-90, always runs it), 64 ... 128 bands at the usual sample rates.  Samples in, mel POWER
- * out; replaces librosa.stft + np.abs + **2 + librosa.feature.melspectrogram (manager.py:184-187, 198, 219-222) like
- * syg_stft2048_mel_f32, without a weight matrix and without the projection's barriers.  Optional statistics / contrast
- * rows as in syg_stft2048_mel_f32 (manager.py:289-343).  Any hop; tiles are shared out evenly over the CUs.
- *   segtab    device, 16-byte aligned: sygnals_amd._tables.pack_mel_segments(sr, 2048, n_mels, fmin, fmax, n_pass=4,
- *             row_base=4) -- [4][2][64][4] 32-bit words; n_segtab = 2048
+/* The TILE form of the segment-sum projection: samples in, mel POWER out; replaces librosa.stft + np.abs + **2 +
+ * librosa.feature.melspectrogram (manager.py:184-187, 198, 219-222) like syg_stft2048_mel_f32, without a weight matrix and
+ * without the projection's barriers.  Optional statistics / contrast rows as in syg_stft2048_mel_f32 (manager.py:289-343).
+ * Any hop; tiles are shared out evenly over the CUs.
+ *   segtab    device, 16-byte aligned.  n_segtab = 2048: sygnals_amd._tables.pack_mel_segments(sr, 2048, n_mels, fmin, fmax,
+ *             n_pass=4, row_base=4), [4][2][64][4] 32-bit words -- up to 256 pieces: the reference's default of 128 bands
+ *             (sygnals/core/features/manager.py:214; `sygnals features extract -f mfcc`, cli/features_cmd.py:82-90, always
+ *             runs it), 64 ... 200 bands at the usual rates.  n_segtab = 1024: the two-pass table of
+ *             syg_stft2048_mfcc_tri_f32 (up to 128 pieces, e.g. 40 bands)
+ *   waves     16 (one workgroup per CU) or 8 (two per CU)
  *   mel_out   [B, n_mels, T]; stats_out / cplan_host / contrast_out as in syg_stft2048_mel_f32 (NULL to skip) */
 int syg_stft2048_mel_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                              const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
                              float* mel_out, float sr, float roll_percent, float bw_p, int stats_mask, float* stats_out,
-                             const int32_t* cplan_host, float* contrast_out, void* stream);
+                             const int32_t* cplan_host, float* contrast_out, int waves, void* stream);
 
 /* The per-frame statistics / contrast tail means of syg_stft2048_mel_f32 WITHOUT the mel spectrogram: spectral_centroid /
  * bandwidth / flatness / rolloff / contrast (manager.py:289-343 -> frequency_domain.py:25-212) only need |X|.  The kernel of

@@ -33,7 +33,7 @@ SIGNATURES = {
     "syg_stft2048_mfcc_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _p, _i, _p, _i, _p, _f, _f, _i, _f, _p, _p, _p]),
     "syg_stft2048_features_tri_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _i, _i, _p, _i, _p, _f, _f, _i, _f, _f, _f, _f, _i, _p, _p,
                                            _p, _p, _i, _p]),
-    "syg_stft2048_mel_tri_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _i, _i, _p, _f, _f, _f, _i, _p, _p, _p, _p]),
+    "syg_stft2048_mel_tri_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _i, _i, _p, _f, _f, _f, _i, _p, _p, _p, _i, _p]),
     "syg_stft2048_stats_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _f, _f, _f, _i, _p, _p, _p, _p]),
     "syg_stft_mel_w4096_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _i, _i, _p, _p]),
     "syg_stft_mel_w1024_seg_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _i, _i, _p, _p]),

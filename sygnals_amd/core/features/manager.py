@@ -381,7 +381,8 @@ TRI_FEATURES_DEFAULT = True
 
 
 def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: int = 13, roll_percent: float = 0.85,
-                  n_bands: int = 6, fmin_contrast: float = 200.0, quantile: float = 0.02, out=None, one_launch=None):
+                  n_bands: int = 6, fmin_contrast: float = 200.0, quantile: float = 0.02, out=None, one_launch=None,
+                  projection: str = "auto", tri_waves: int = 16):
     """BASELINE config C4 on the device: y [B, L] float32 device clips -> [B, n_mfcc + 2 + (n_bands + 1), T] float32,
     rows = mfcc_0..mfcc_{n-1}, spectral_centroid (Hz), spectral_rolloff (Hz), contrast_band_0..{n_bands-1},
     contrast_delta -- the columns `extract_features(["mfcc", "spectral_centroid", "spectral_rolloff",
@@ -430,8 +431,10 @@ def feature_block(y, sr: int, hop_length: int = 512, n_mels: int = 40, n_mfcc: i
                                          ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out), st)
         check(rc, "syg_feature_block_f32")
         return out
-    mel, stats, cpv = ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8, roll_percent,
-                                       2.0, cplan)
+    # two launches: mel + rows (matrix form, or -- projection="segments" -- the tile form of the segment-sum projection with
+    # `tri_waves` waves per workgroup), then the block kernel
+    mel, stats, cpv = ops.stft2048_mel(y, sr, hop_length, True, "hann", 2048, n_mels, 0.0, None, 1 | 8 | 32, roll_percent,
+                                       2.0, cplan, projection, tri_waves)
     rc = lib().syg_feature_block_f32(ops._ptr(mel), B, n_mels, Tn, ops._ptr(dct), n_mfcc, 1e-10, 80.0, ops._ptr(stats),
                                      float(sr) / 2048.0, ops._ptr(cpv), R, 1e-10, 80.0, ops._ptr(out), st)
     check(rc, "syg_feature_block_f32")

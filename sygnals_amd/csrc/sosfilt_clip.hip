@@ -61,10 +61,102 @@ __device__ __noinline__ void store4(float* __restrict__ yb, int L, int n0, float
   if (n0 + 3 >= 0 && n0 + 3 < L) yb[n0 + 3] = v.w;
 }
 
+// a double moved between lanes: through the DPP network inside a row of 16 lanes (zero where the source lane lies outside
+// the row: the scan's "no chunk that far back"), through the LDS crossbar (ds_bpermute: no LDS memory, no barrier) across rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double bperm_d(double v, int src_lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src_lane, (int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src_lane, (int)(unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Inclusive prefix of the chunk end states over the scan order (REV: lanes from 255 down to 0): s_l <- s_l + M^(2^k)
+// s_(l - 2^k), k = 0 .. 7.  The first six rounds stay INSIDE the wave -- distances 1, 2, 4, 8 on the DPP network (row
+// shifts with zero fill), 16 and 32 through the LDS crossbar -- with no LDS memory and no barrier (round 3 ran all eight
+// rounds through LDS arrays, one workgroup barrier each: 2 x 11-15 us per clip); distances 64 and 128 cross waves and keep
+// the LDS form, as does the hand-over of lane l - 1's result.  On exit (z0, z1) = the true state this lane's chunk starts
+// from (`start` for the first chunk of the sweep).  PW: M^(2^k) row-major, k-th matrix at PW + k D D (LDS broadcasts).
+template <int S, bool REV>
+__device__ __forceinline__ void scan_states(double (&z0)[S], double (&z1)[S], const double* __restrict__ PW,
+                                            double* __restrict__ ex, int tid, int lane, const double (&start)[2 * S]) {
+  constexpr int D = 2 * S;
+  double a[D];
+#pragma unroll
+  for (int s = 0; s < S; ++s) { a[2 * s] = z0[s]; a[2 * s + 1] = z1[s]; }
+  auto apply = [&](const double* Mk, const double (&v)[D]) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) {              // (fully unrolled: a[] stays in registers; Mk reads are LDS broadcasts)
+      double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; k += 2) {
+        p0 = fma(Mk[r * D + k], v[k], p0);
+        p1 = fma(Mk[r * D + k + 1], v[k + 1], p1);
+      }
+      a[r] += p0 + p1;
+    }
+  };
+  {
+    double v[D];
+#define SOSC_DPP_ROUND(KK, FWD, BWD)                                           \
+    _Pragma("unroll") for (int k = 0; k < D; ++k) v[k] = REV ? dpp_d<BWD>(a[k]) : dpp_d<FWD>(a[k]); \
+    apply(PW + (KK) * D * D, v);                                               \
+    __builtin_amdgcn_sched_barrier(0);
+    SOSC_DPP_ROUND(0, 0x111, 0x101)            // row_shr:1 / row_shl:1
+    SOSC_DPP_ROUND(1, 0x112, 0x102)
+    SOSC_DPP_ROUND(2, 0x114, 0x104)
+    SOSC_DPP_ROUND(3, 0x118, 0x108)
+#undef SOSC_DPP_ROUND
+#pragma unroll 1
+    for (int kk = 4; kk < 6; ++kk) {
+      const int off = 1 << kk;
+      const int src = REV ? lane + off : lane - off;
+      const bool ok = REV ? (src < 64) : (src >= 0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double t = bperm_d(a[k], src & 63);
+        v[k] = ok ? t : 0.0;
+      }
+      apply(PW + kk * D * D, v);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int ord = REV ? NL - 1 - tid : tid;
+  int kk = 6;
+#pragma unroll 1
+  for (int off = 64; off < NL; off <<= 1, ++kk) {
+    double* exk = ex + (kk & 1) * NL * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) exk[d * NL + ord] = a[d];
+    __syncthreads();
+    if (ord >= off) {
+      double v[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v[k] = exk[k * NL + ord - off];
+      apply(PW + kk * D * D, v);
+    }
+  }
+  double* exk = ex + (kk & 1) * NL * D;         // (the array the last round did not read)
+#pragma unroll
+  for (int d = 0; d < D; ++d) exk[d * NL + ord] = a[d];
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    z0[s] = ord > 0 ? exk[(2 * s) * NL + ord - 1] : start[2 * s];
+    z1[s] = ord > 0 ? exk[(2 * s + 1) * NL + ord - 1] : start[2 * s + 1];
+  }
+}
+
 template <int S, int CS>
 __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const float* __restrict__ x, int64_t ldx, int L,
                                                                        int pad, SosClipParams P, float* __restrict__ y,
-                                                                       int64_t ldy) {
+                                                                       int64_t ldy, int64_t B) {
   constexpr int D = 2 * S;
   constexpr int NT = CS / 32;                    // 32-sample tiles per chunk
   static_assert(CS % 32 == 0, "chunk length must be a multiple of the tile");
@@ -72,10 +164,15 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
   __shared__ double ex[2 * NL * D];
   __shared__ double PW[8 * D * D];
   __shared__ float ylast;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t b = blockIdx.x;
-  const float* xb = x + b * ldx;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int w0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  // the ids every address is formed from are made opaque once per clip (below): inside the clip loop the compiler would
+  // otherwise hoist the thousands of loop-invariant piece addresses of the unrolled passes out of it and spill them
+  int tid = tid0, lane = lane0, w = w0;
+  // PERSISTENT workgroup: clips blockIdx.x, blockIdx.x + gridDim.x, ... (the grid is what the chip holds at once: C3's 1024
+  // clips are two per workgroup).  The NEXT clip's samples are requested tile by tile during the current clip's last pass,
+  // into the registers that pass has just stored from, so that only the first clip of a workgroup waits for its load.
+  int64_t b = blockIdx.x;
   const int lext = L + 2 * pad;
   float xs[CS];
   SOSC_STAMP(0);
@@ -85,22 +182,23 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
   // every load of the clip is issued before the first transposition (one trip to HBM per clip, not one per tile): the
   // 16-byte pieces land in the registers that will hold the samples, tile t's eight pieces in xs[32 t .. 32 t + 31]
   float* tl = tile[w];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  auto load_tile = [&](const float* __restrict__ xq, int t) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int ch = r * 8 + (lane >> 3), part = lane & 7;
       const int i0 = (w * 64 + ch) * CS + 32 * t + 4 * part;          // sequence index of the piece's first sample
       float4 q;
       if (i0 >= pad && i0 + 3 < pad + L) {
-        const f4u u = *reinterpret_cast<const f4u*>(xb + (i0 - pad));
+        const f4u u = *reinterpret_cast<const f4u*>(xq + (i0 - pad));
         q = make_float4(u.x, u.y, u.z, u.w);
       } else {
-        q = ext4(xb, L, pad, lext, i0);
+        q = ext4(xq, L, pad, lext, i0);
       }
       xs[32 * t + 4 * r] = q.x; xs[32 * t + 4 * r + 1] = q.y; xs[32 * t + 4 * r + 2] = q.z; xs[32 * t + 4 * r + 3] = q.w;
     }
-  }
+  };
+#pragma unroll
+  for (int t = 0; t < NT; ++t) load_tile(x + b * ldx, t);
   // tile t of the registers from piece order (8 lanes x 16 bytes per lane's row) to lane order (a lane's own 32 samples)
   auto to_lane_order = [&](int t) {
     wave_lds_sync();                             // the previous tile has been read
@@ -144,48 +242,15 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
     }
     __syncthreads();
   }
-  // inclusive prefix of the chunk end states over the scan order `ord` (0 = first chunk of the sweep); on exit
-  // (z0, z1) = the true state this lane's chunk starts from (`start` for ord 0).  One barrier per round: the states
-  // alternate between two LDS arrays (component-major: a lane's neighbours sit in the next banks).
-  auto scan = [&](int ord, const double (&start)[D]) {
-    double a[D];
-#pragma unroll
-    for (int s = 0; s < S; ++s) { a[2 * s] = z0[s]; a[2 * s + 1] = z1[s]; }
-    int kk = 0;
 #pragma unroll 1
-    for (int off = 1; off < NL; off <<= 1, ++kk) {
-      double* exk = ex + (kk & 1) * NL * D;
-#pragma unroll
-      for (int d = 0; d < D; ++d) exk[d * NL + ord] = a[d];
-      __syncthreads();
-      if (ord >= off) {
-        const double* Mk = PW + kk * D * D;
-        double v[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) v[k] = exk[k * NL + ord - off];
-#pragma unroll
-        for (int r = 0; r < D; ++r) {            // (fully unrolled: a[] stays in registers; Mk reads are LDS broadcasts)
-          double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-          for (int k = 0; k < D; k += 2) {
-            p0 = fma(Mk[r * D + k], v[k], p0);
-            p1 = fma(Mk[r * D + k + 1], v[k + 1], p1);
-          }
-          a[r] += p0 + p1;
-        }
-      }
-    }
-    double* exk = ex + (kk & 1) * NL * D;       // (eight rounds: the array the last round did not read)
-#pragma unroll
-    for (int d = 0; d < D; ++d) exk[d * NL + ord] = a[d];
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      z0[s] = ord > 0 ? exk[(2 * s) * NL + ord - 1] : start[2 * s];
-      z1[s] = ord > 0 ? exk[(2 * s + 1) * NL + ord - 1] : start[2 * s + 1];
-    }
-  };
-
+  for (; b < B; b += gridDim.x) {
+  lane = lane0; w = w0;
+  asm volatile("" : "+v"(lane), "+s"(w));
+  tid = w * 64 + lane;
+  tl = tile[w];
+  const float* xb = x + b * ldx;
+  const int64_t bnext = b + gridDim.x;
+  __syncthreads();                               // (the previous clip's last scan has been read by every wave)
   // ---- forward sweep
   double start[D];
   {
@@ -210,7 +275,7 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
 #pragma unroll
   for (int j = 0; j < CS; ++j) asm volatile("" : "+v"(xs[j]));
   SOSC_STAMP(2);
-  scan(tid, start);
+  scan_states<S, false>(z0, z1, PW, ex, tid, lane, start);
   SOSC_STAMP(3);
 #pragma unroll
   for (int j = 0; j < (SOSC_TRUE_PASS ? CS : 0); ++j) {
@@ -223,7 +288,8 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
   SOSC_STAMP(4);
   // ---- the last forward output, and the fill of the positions behind it
   {
-    const int il = lext - 1;
+    int il = lext - 1;
+    asm volatile("" : "+s"(il));                   // (per clip: hoisted out of the clip loop, its CS comparisons were spilled)
     if (tid == il / CS) {
       float v = 0.f;
 #pragma unroll
@@ -232,7 +298,8 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
     }
     __syncthreads();
     const float yl = ylast;
-    const int nvalid = lext - tid * CS;          // positions j < nvalid of this lane are samples
+    int nvalid = lext - tid * CS;                // positions j < nvalid of this lane are samples
+    asm volatile("" : "+v"(nvalid));
 #pragma unroll
     for (int j = 0; j < CS; ++j) xs[j] = (j < nvalid) ? xs[j] : yl;
 #pragma unroll
@@ -250,11 +317,12 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
 #pragma unroll
   for (int j = 0; j < CS; ++j) asm volatile("" : "+v"(xs[j]));
   SOSC_STAMP(5);
-  scan(ord, start);
+  scan_states<S, true>(z0, z1, PW, ex, tid, lane, start);
   SOSC_STAMP(6);
   // the true backward pass, a tile at a time from the top; a finished tile goes out (y[n] = result at sequence index
   // n + pad) while the next one is computed
   float* yb = y + b * ldy;
+  const float* xnext = x + (bnext < B ? bnext : b) * ldx;       // (no next clip: the loads are skipped below)
 #pragma unroll
   for (int t = NT - 1; t >= 0; --t) {
 #pragma unroll
@@ -282,19 +350,22 @@ __global__ __launch_bounds__(NL, CS <= 192 ? 2 : 1) void sos_clip_kernel(const f
         store4(yb, L, n0, v);
       }
     }
+    // the tile's registers are free: the next clip's tile t is requested into them (wave-uniform condition)
+    if (bnext < B) load_tile(xnext, t);
     __builtin_amdgcn_sched_barrier(0);
   }
   SOSC_STAMP(7);
+  }
 }
 
 template <int S>
 int launch_s(int cs, dim3 grid, hipStream_t st, const float* x, int64_t ldx, int L, int pad, const SosClipParams& P, float* y,
-             int64_t ldy) {
+             int64_t ldy, int64_t B) {
   switch (cs) {
-    case 64: hipLaunchKernelGGL((sos_clip_kernel<S, 64>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy); break;
-    case 128: hipLaunchKernelGGL((sos_clip_kernel<S, 128>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy); break;
-    case 192: hipLaunchKernelGGL((sos_clip_kernel<S, 192>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy); break;
-    default: hipLaunchKernelGGL((sos_clip_kernel<S, 256>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy); break;
+    case 64: hipLaunchKernelGGL((sos_clip_kernel<S, 64>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy, B); break;
+    case 128: hipLaunchKernelGGL((sos_clip_kernel<S, 128>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy, B); break;
+    case 192: hipLaunchKernelGGL((sos_clip_kernel<S, 192>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy, B); break;
+    default: hipLaunchKernelGGL((sos_clip_kernel<S, 256>), grid, dim3(NL), 0, st, x, ldx, L, pad, P, y, ldy, B); break;
   }
   return 0;
 }
@@ -314,12 +385,20 @@ bool sos_clip_supported(int n_sections) { return n_sections >= 1 && n_sections <
 
 void sos_clip_launch(const float* x, int64_t B, int L, int64_t ldx, const SosClipParams& P, int n_sections, int cs, int pad,
                      float* y, int64_t ldy, hipStream_t st) {
-  const dim3 grid((unsigned)B);
+  // persistent workgroups: as many as the chip holds at once (two per CU up to 192 samples per lane, else one), each
+  // walking clips b, b + grid, ...; a batch that fits one round keeps one clip per workgroup
+  int dev = 0, n_cu = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+    n_cu = 256;
+  const int64_t resident = (int64_t)n_cu * (cs <= 192 ? 2 : 1);
+  // equal shares: ceil(B / rounds) workgroups, so that no workgroup gets a round more than another for nothing
+  const int64_t rounds = (B + resident - 1) / resident;
+  const dim3 grid((unsigned)((B + rounds - 1) / rounds));
   switch (n_sections) {
-    case 1: launch_s<1>(cs, grid, st, x, ldx, L, pad, P, y, ldy); break;
-    case 2: launch_s<2>(cs, grid, st, x, ldx, L, pad, P, y, ldy); break;
-    case 3: launch_s<3>(cs, grid, st, x, ldx, L, pad, P, y, ldy); break;
-    default: launch_s<4>(cs, grid, st, x, ldx, L, pad, P, y, ldy); break;
+    case 1: launch_s<1>(cs, grid, st, x, ldx, L, pad, P, y, ldy, B); break;
+    case 2: launch_s<2>(cs, grid, st, x, ldx, L, pad, P, y, ldy, B); break;
+    case 3: launch_s<3>(cs, grid, st, x, ldx, L, pad, P, y, ldy, B); break;
+    default: launch_s<4>(cs, grid, st, x, ldx, L, pad, P, y, ldy, B); break;
   }
 }
 

@@ -450,20 +450,23 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   // default 128 bands, 64 bands at 44.1 / 48 kHz), every frame's mel column written straight to HBM (a 128-band clip
   // matrix does not fit the LDS beside the rows; syg_logmel_dct_f32 is the second launch), tiles shared out evenly over
   // the workgroups (no whole-clip chunks: one long clip fills the chip); MODE 9: MODE 8 + the row functions of MODE 7
-  constexpr bool TRIMEL = (MODE == 8 || MODE == 9);
+  // MODE 10 / 11: MODE 8 / 9 with a TWO-pass table (filterbanks of up to 128 pieces, e.g. 40 bands) -- the tile form of
+  // MODE 6 / 7 without the clip-resident epilogue; with 8 waves two workgroups share a CU and drift out of phase
+  constexpr bool TRIMEL = (MODE >= 8 && MODE <= 11);
   constexpr bool TRI = (MODE == 6 || MODE == 7 || TRIMEL);
-  constexpr int NPASS = TRIMEL ? 4 : 2;
+  constexpr int NPASS = (MODE == 8 || MODE == 9) ? 4 : 2;
+  constexpr int TRI_ROW_BASE = (NPASS == 4) ? TRI4_ROW_BASE : 0;
   typedef Lds<WAVES, !TRI, NPASS> LM;
   constexpr int SEG_WORDS = LM::SEG_WORDS;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int TILE_T = WAVES;                                    // one frame per wave per tile
   constexpr bool COMPLEX_OUT = (MODE == 2);
-  constexpr bool ROWFN = (MODE == 1 || MODE == 7 || MODE == 9);      // per-frame row functions (MODE 1: behind barrier B)
+  constexpr bool ROWFN = (MODE == 1 || MODE == 7 || MODE == 9 || MODE == 11);   // per-frame row functions (MODE 1: behind barrier B)
   constexpr bool CLIPM = (MODE == 3 || MODE == 6 || MODE == 7);      // the clip's mel matrix lives in LDS; epilogue at clip end
   // MODE 0 / 3 (mel only): the power rows hold 4 |X|^2 (wave_rfft2048<.., X2>); the factor is taken back -- exactly, a
   // power of two -- where mel values leave the kernel (MODE 0: at the store; MODE 3: the dB conversion works on 4 x mel
   // with 4 x amin and 4 x ref, the optional mel copy is scaled at its store).  MODE 1's statistics need the true powers.
-  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || MODE == 6 || MODE == 8);
+  constexpr bool X2 = X2_MEL && (MODE == 0 || MODE == 3 || MODE == 6 || MODE == 8 || MODE == 10);
 #ifdef SYG_DEV_NO_RELC
   constexpr bool RELC = false;                                       // (timeline builds: round 3's form, for the before / after table)
 #else
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
         // (the table's band word was turned into the band's BYTE offset inside a mel matrix when the workgroup copied it)
         if (TRIMEL) {
           char* colg = reinterpret_cast<char*>(mel_out + (b * n_mels) * T + t);
-          tri_project<4>(prow - TRI4_ROW_BASE, reinterpret_cast<const float4*>(cpl), la, tri_scan8,
+          tri_project<NPASS>(prow - TRI_ROW_BASE, reinterpret_cast<const float4*>(cpl), la, tri_scan8,
                          [&](int boff, float v) { *reinterpret_cast<float*>(colg + boff) = MELSC * v; });
         } else {
           char* colb = reinterpret_cast<char*>(cmc + (int)t);
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
       // Waves w, w + 4, w + 8, w + 12 share a SIMD: two of them early, two late.
       float row_sres = 0.f;
       float2 row_pv = make_float2(0.f, 0.f);
-      const bool row_early = (w >> 2) & 1;
+      const bool row_early = (w >> 2) & 1;               // (8 waves: w, w + 4 share a SIMD -- one early, one late)
       auto row_compute = [&]() {
         if (stats_out != nullptr && contrast_out != nullptr) {
           const float3 f = row_features<NBIN, 0>((lds_row)prow, lane, binhz, roll_percent, bw_p, smask, (lds_iptr)cplc,
@@ -964,7 +967,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
 #if SYG_DEV
   if (MODE == 3 && lane < 12)
     mel_out[((int64_t)blockIdx.x * WAVES + w) * 16 + lane] = (float)tacc[lane] / (float)(tile_end - tile_begin);
-  if ((MODE == 1 || MODE == 7 || MODE == 9) && stats_out != nullptr && lane < 12)
+  if (ROWFN && stats_out != nullptr && lane < 12)
     stats_out[((int64_t)blockIdx.x * WAVES + w) * 16 + lane] = (float)tacc[lane] / (float)(tile_end - tile_begin);
 #endif
 }
@@ -1028,9 +1031,10 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   const int64_t total_tiles = B * tiles;
   int wgs = 0, per = 0;
   persistent_grid(total_tiles, WAVES, wgs, per);
-  constexpr bool TRIMEL = (MODE == 8 || MODE == 9);      // tile form of the segment-sum projection, four-pass table
+  constexpr bool TRIMEL = (MODE >= 8 && MODE <= 11);     // tile form of the segment-sum projection
+  constexpr int TRIMEL_NPASS = (MODE == 8 || MODE == 9) ? 4 : 2;
   constexpr bool TRI = (MODE == 6 || MODE == 7);
-  size_t lds = TRIMEL ? lds_bytes<WAVES, false, 4>() : lds_bytes<WAVES, !TRI>();
+  size_t lds = TRIMEL ? lds_bytes<WAVES, false, TRIMEL_NPASS>() : lds_bytes<WAVES, !TRI>();
   if (TRIMEL) mf.tp = tiles * WAVES;
   if (MODE == 3 || TRI) {
     // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
@@ -1055,7 +1059,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   {
     // set at every launch: the attribute belongs to the (function, device) pair, and a per-process "already set"
     // flag would leave a second device without it
-    const size_t cap = (MODE == 3 || TRI) ? LDS_LIMIT : TRIMEL ? lds_bytes<WAVES, false, 4>() : lds_bytes<WAVES>();
+    const size_t cap = (MODE == 3 || TRI) ? LDS_LIMIT : TRIMEL ? lds_bytes<WAVES, false, TRIMEL_NPASS>() : lds_bytes<WAVES>();
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) {
       set_error("stft2048: cannot reserve %zu B LDS: %s", cap, hipGetErrorString(e));
@@ -1255,22 +1259,28 @@ extern "C" int syg_stft2048_features_tri_f32(const float* y, int64_t B, int64_t 
                        (hipStream_t)stream, mf);
 }
 
-// MODE 8 / 9: the TILE form of the segment-sum projection with a FOUR-pass piece table (up to 256 pieces: the reference's
-// default filterbank of 128 bands, manager.py:214, and 64 ... 128 bands at the usual sample rates, which have no two-pass
-// table) -- samples in, mel POWER out [B, n_mels, T] (no weight matrix, no projection barriers, every frame's column written
-// by the wave that transformed it); syg_logmel_dct_f32 is the second launch of an MFCC.  Optional statistics / contrast
-// rows from the same launch (MODE 9: the row functions of syg_stft2048_features_tri_f32).  Tiles are shared out evenly
-// over the workgroups, so one long clip (BASELINE config C1) fills the chip.
-//   segtab   pack_mel_segments(..., n_pass=4, row_base=4): [4][2][64][4] words, n_segtab = 2048
+// MODE 8 ... 11: the TILE form of the segment-sum projection -- samples in, mel POWER out [B, n_mels, T] (no weight matrix,
+// no projection barriers, every frame's column written by the wave that transformed it); syg_logmel_dct_f32 /
+// syg_feature_block_f32 is the second launch of an MFCC.  Optional statistics / contrast rows from the same launch (the row
+// functions of syg_stft2048_features_tri_f32).  Tiles are shared out evenly over the workgroups, so one long clip
+// (BASELINE config C1) fills the chip.
+//   segtab   n_segtab = 2048: pack_mel_segments(..., n_pass=4, row_base=4), [4][2][64][4] words -- up to 256 pieces: the
+//            reference's default filterbank of 128 bands (manager.py:214), 64 ... 200 bands at the usual sample rates;
+//            n_segtab = 1024: the two-pass table of syg_stft2048_mfcc_tri_f32 (up to 128 pieces, e.g. 40 bands)
+//   waves    16 (one workgroup per CU) or 8 (two per CU, each with its own tile barriers: they drift out of phase, so that
+//            one's transforms run beside the other's LDS exchanges)
 extern "C" int syg_stft2048_mel_tri_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
                                         const float* window, const float* twiddle, const float* segtab, int n_segtab,
                                         int n_mels, float* mel_out, float sr, float roll_percent, float bw_p, int stats_mask,
-                                        float* stats_out, const int32_t* cplan_host, float* contrast_out, void* stream) {
+                                        float* stats_out, const int32_t* cplan_host, float* contrast_out, int waves,
+                                        void* stream) {
   SYG_REQUIRE(segtab && mel_out, "stft2048_mel_tri: null pointer argument");
-  SYG_REQUIRE(n_segtab == SEGTAB4_WORDS, "stft2048_mel_tri: the piece table has %d words, this library reads %d "
-              "(sygnals_amd._tables.pack_mel_segments(..., n_pass=4, row_base=4))", n_segtab, SEGTAB4_WORDS);
+  SYG_REQUIRE(n_segtab == SEGTAB4_WORDS || n_segtab == SEGTAB_WORDS, "stft2048_mel_tri: the piece table has %d words, this "
+              "library reads %d (four passes, row_base 4) or %d (two passes) -- sygnals_amd._tables.pack_mel_segments", n_segtab,
+              SEGTAB4_WORDS, SEGTAB_WORDS);
   SYG_REQUIRE(((uintptr_t)segtab) % 16 == 0, "stft2048_mel_tri: the piece table must be 16-byte aligned");
-  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, 16);
+  SYG_REQUIRE(waves == 8 || waves == 16, "stft2048_mel_tri: waves must be 8 or 16 (got %d)", waves);
+  int rc = check_common(y, B, L, ldy, hop, center, T, window, twiddle, waves);
   if (rc) return rc;
   SYG_REQUIRE(n_mels >= 1 && n_mels <= 255, "stft2048_mel_tri: need 1 <= n_mels <= 255 (got %d)", n_mels);
   SYG_REQUIRE(T * (int64_t)n_mels < ((int64_t)1 << 29), "stft2048_mel_tri: clip too long (32-bit byte offsets inside a clip's mel block)");
@@ -1285,12 +1295,19 @@ extern "C" int syg_stft2048_mel_tri_f32(const float* y, int64_t B, int64_t L, in
   memset(&mf, 0, sizeof(mf));
   mf.amin = 1e-10f; mf.top_db = -1.f;
   const bool extra = stats_out != nullptr || contrast_out != nullptr;
-  if (extra)
-    return launch<16, 9>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, mel_out,
-                         sr / (float)NFFT, roll_percent, bw_p, stats_mask, stats_out, cp, contrast_out, nullptr,
-                         (hipStream_t)stream, mf);
-  return launch<16, 8>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, mel_out, 0.f, 0.f,
-                       0.f, 0, nullptr, cp, nullptr, nullptr, (hipStream_t)stream, mf);
+  const bool four = n_segtab == SEGTAB4_WORDS;
+  const float binhz = extra ? sr / (float)NFFT : 0.f;
+  if (!extra) { roll_percent = 0.f; bw_p = 0.f; stats_mask = 0; }
+#define SYG_LAUNCH(W, M)                                                                                               \
+  launch<W, M>(load_mode(), y, B, L, ldy, hop, center, T, window, twiddle, segtab, plan, n_mels, mel_out, binhz, roll_percent, \
+               bw_p, stats_mask, stats_out, cp, contrast_out, nullptr, (hipStream_t)stream, mf)
+  if (waves == 16) {
+    if (four) return extra ? SYG_LAUNCH(16, 9) : SYG_LAUNCH(16, 8);
+    return extra ? SYG_LAUNCH(16, 11) : SYG_LAUNCH(16, 10);
+  }
+  if (four) return extra ? SYG_LAUNCH(8, 9) : SYG_LAUNCH(8, 8);
+  return extra ? SYG_LAUNCH(8, 11) : SYG_LAUNCH(8, 10);
+#undef SYG_LAUNCH
 }
 
 // MODE 7 without a filterbank: the per-frame statistics / contrast tail means alone (spectral_centroid / bandwidth /

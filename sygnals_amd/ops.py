@@ -471,13 +471,13 @@ def stft_mel_w4096(y: torch.Tensor, sr: float, hop: int = 1024, center: bool = T
 def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True, window="hann",
                  win_length: int = 2048, n_mels: int = 128, fmin: float = 0.0, fmax=None,
                  want_stats=False, roll_percent: float = 0.85, bw_p: float = 2.0,
-                 contrast: Optional[np.ndarray] = None, projection: str = "auto"):
+                 contrast: Optional[np.ndarray] = None, projection: str = "auto", tri_waves: int = 16):
     """Fused STFT(2048) -> power -> mel.  Returns (mel [B, M, T], stats [B, 8, T] | None,
     contrast_pv [B, 2, R, T] | None).  `want_stats`: False, True (all rows) or a bit mask (1 centroid,
     2 bandwidth, 4 flatness, 8 rolloff, 16 dominant): only the selected rows are computed / written.
-    projection: "segments" (syg_stft2048_mel_tri_f32: per-wave segment sums, four-pass table, no barriers in the
-    projection), "matrix" (syg_stft2048_mel_f32: block-sparse weights on the matrix cores), "auto": segments where the
-    filterbank has a table and the 16-wave kernel is selected."""
+    projection: "segments" (syg_stft2048_mel_tri_f32: per-wave segment sums -- the two-pass table where the filterbank has
+    one, else the four-pass table -- no barriers in the projection; tri_waves = 16 | 8 waves per workgroup), "matrix"
+    (syg_stft2048_mel_f32: block-sparse weights on the matrix cores), "auto": the matrix form wherever it has a plan."""
     smask = 31 if want_stats is True else int(want_stats or 0)
     require_gpu()
     if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
@@ -491,7 +491,8 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
     cfg = mel_config(sr, 2048, n_mels, fmin, fmax)
     if projection not in ("auto", "segments", "matrix"):
         raise ValueError("projection must be 'auto', 'segments' or 'matrix'")
-    tri = cfg.segtab4 is not None and fused_waves() == 16 and Tn * n_mels < (1 << 29) and projection != "matrix"
+    tab = cfg.segtab if cfg.segtab is not None else cfg.segtab4
+    tri = tab is not None and fused_waves() == 16 and Tn * n_mels < (1 << 29) and projection != "matrix"
     if projection == "auto" and cfg.wpacked is not None:
         # measured (profiles/r04_rows_start.json vs r04b): the matrix form wins wherever it has a plan -- 128 bands 0.206 ms per
         # 1024 clips (mel + dB / DCT launch) against 0.241 for four passes of masked segment sums (about 380 vector
@@ -499,7 +500,7 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
         # matrix form cannot hold (8-wave development mode beyond 128 bands) and stays selectable
         tri = False
     if projection == "segments" and not tri:
-        raise SygnalsHipError("stft2048_mel: no four-pass piece table for this filterbank (projection='segments')")
+        raise SygnalsHipError("stft2048_mel: no piece table for this filterbank (projection='segments')")
     if not tri and cfg.wpacked is None:
         raise SygnalsHipError("fused path: no block-sparse plan for this filterbank (n_mels <= 256; <= 128 with 8 waves)")
     win = window_dev(window, win_length, 2048)
@@ -514,9 +515,9 @@ def stft2048_mel(y: torch.Tensor, sr: float, hop: int = 512, center: bool = True
         cplan_p = cplan.ctypes.data_as(C.c_void_p)
     if tri:
         rc = lib().syg_stft2048_mel_tri_f32(
-            _ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(cfg.segtab4), int(cfg.segtab4.numel()),
+            _ptr(y), B, L, _ld(y), hop, int(center), Tn, _ptr(win), _ptr(tw), _ptr(tab), int(tab.numel()),
             n_mels, _ptr(mel), float(sr), float(roll_percent), float(bw_p), smask, _ptr(stats), cplan_p, _ptr(cpv),
-            C.c_void_p(_stream_ptr()))
+            int(tri_waves), C.c_void_p(_stream_ptr()))
         check(rc, "syg_stft2048_mel_tri_f32")
         return mel, stats, cpv
     rc = lib().syg_stft2048_mel_f32(
