@@ -135,8 +135,8 @@ def cpu_baseline(target_seconds=10.0, all_cores_seconds=4.0):
     usable = avail if quota is None else min(avail, int(quota + 0.5))
     if usable <= cores and avail > cores:
         out["all_cores_note"] = (f"the affinity mask shows {avail} cores but the cgroup CPU quota is {quota:.1f}: the {cores}-process "
-                                 "figure IS the all-core figure of this box share (256 processes on it: 96 Msamples/s, "
-                                 "profiles/r04_bench_driver_flags.json of round 4's first run -- oversubscribed)")
+                                 "figure IS the all-core figure of this box share (256 processes on it, measured once: 96 Msamples/s "
+                                 "in 290 s -- oversubscribed; profiles/r04_cpu_all_cores_256proc.json)")
     if usable > cores:
         # SURVEY 8(d) "(ii) all host cores": one process per core the affinity mask shows (a box's cgroup share may be
         # smaller than its mask -- the figure is what this process can actually get), a shorter second run

@@ -225,6 +225,16 @@ int syg_stft_mel_wseg_small_f32(const float* y, int64_t B, int64_t L, int64_t ld
                                 int64_t T, const float* window, const float* twiddle, const float* segtab,
                                 int n_segtab, int n_mels, float* mel_out, void* stream);
 
+/* The per-frame statistics / contrast rows of syg_stft2048_mel_f32 for frame lengths 512 and 256 (bins 0 .. n_fft / 2, bin
+ * frequency k sr / n_fft) from the transform of syg_stft_mel_wseg_small_f32, nothing projected: extract_features(
+ * frame_length=512 | 256, [spectral features]) -- 256 is the frame length of the reference's short-signal tests
+ * (tests/test_features_manager.py:183-220; manager.py:289-343 over frequency_domain.py:24-386) -- without a spectrogram in
+ * HBM.  stats_out [B, SYG_NSTAT, T] (rows selected by stats_mask) and / or cplan_host + contrast_out [B, 2, n_rows, T]:
+ * at least one.  window [n_fft]; twiddle: W_1024^k, k = 0 .. 1023. */
+int syg_stft_rows_wsmall_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int center, int64_t T,
+                             const float* window, const float* twiddle, float sr, float roll_percent, float bw_p,
+                             int stats_mask, float* stats_out, const int32_t* cplan_host, float* contrast_out, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at
  * manager.py:223 and librosa.feature.mfcc(S=..) at cepstral.py:106-115.

@@ -181,6 +181,16 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 if want_mfcc and not seg_mel:
                     mel = ops.stft_mel_pow2(yd, sr, 1024, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
                 t_stft = Tn
+            elif (frame_length in (512, 256) and (want_stats or want_contrast) and
+                  (not want_mfcc or (power in (1.0, 2.0) and ops.fused_pow2_ok(frame_length, n_mels)))):
+                # frame lengths 512 / 256 (256: the reference's short-signal tests): the rows from the segment-sum kernel's
+                # transform (one launch, no spectrogram in HBM); the mel block, if an MFCC is asked for too, from its own launch
+                stats, cpv = ops.stft_rows_wsmall(yd, sr, frame_length, hop_length, center, window, None, want_stats, roll, bw_p, cplan)
+                if want_mfcc:
+                    mel = ops.stft_mel_segments(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax) if power == 2.0 else None
+                    if mel is None:
+                        mel = ops.stft_mel_pow2(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
+                t_stft = Tn
             elif (want_mfcc and not (want_stats or want_contrast) and power == 2.0 and
                   (mel := ops.stft_mel_segments(yd, sr, frame_length, hop_length, center, window, None, n_mels, fmin, fmax)) is not None):
                 # only the mel spectrogram is needed: the segment-sum kernel of this frame length (1024 / 512 / 256 / 4096)

@@ -60,6 +60,10 @@ if not ONLY or any("1024" in a or "c4-style" in a for a in ONLY):
     report("a6-a9 n_fft=1024 hop=256: centroid + rolloff through extract_features_batch (device resident), 1024 clips",
            lambda: extract_features_batch(y, SR, ["spectral_centroid", "spectral_rolloff"], 1024, 256, to_host=False), B * L,
            B * (4 * L + 4 * 2 * T4), n=5, warm=2)
+    for nf, hp in ((512, 128), (256, 64)):
+        report(f"a6-a9 n_fft={nf} hop={hp}: centroid + rolloff through extract_features_batch (device resident), 1024 clips",
+               lambda: extract_features_batch(y, SR, ["spectral_centroid", "spectral_rolloff"], nf, hp, to_host=False), B * L,
+               B * (4 * L + 4 * 2 * (1 + L // hp)), n=5, warm=2)
     report("C4-style block n_fft=1024 hop=256: mfcc(40) + centroid + rolloff + contrast through extract_features_batch, 1024 clips",
            lambda: extract_features_batch(y, SR, ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"], 1024, 256,
                                           feature_params={"mfcc": {"n_mels": 40}}, to_host=False), B * L, B * (4 * L + 4 * 22 * T4), n=5, warm=2)
