@@ -208,9 +208,10 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the configuration's)")
-    ap.add_argument("--reserve-cus", default="0",
-                    help="N > 1: leave this many CUs to RCCL (two-launch form, capped p2p channels); `auto`: time the plain "
-                         "form first and, when a step costs more than 1.15 x its compute, once more with 32 CUs set aside")
+    ap.add_argument("--reserve-cus", default="auto",
+                    help="N > 1: leave this many CUs to RCCL (two-launch form, capped p2p channels); `auto` (default): time the "
+                         "plain form -- that is `value` -- and, when a step costs more than 1.15 x its compute, once more with 32 CUs "
+                         "set aside, reported beside it as `reserve_cus_retry`")
     a = ap.parse_args()
     reserve_auto = a.reserve_cus == "auto"
     a.reserve_cus = 0 if reserve_auto else int(a.reserve_cus)

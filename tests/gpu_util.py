@@ -54,3 +54,25 @@ def assert_contrast_parity(cdb, C64, valley64, floor, tol=1e-5, what="contrast")
     assert (err[~sure] <= np.maximum(bound[~sure], tol * cmax)).all(), \
         f"{what}: a below-margin cell exceeds the propagated one-floor bound (worst ratio {(err[~sure] / bound[~sure]).max():.2f})"
     return int((~sure).sum()), int(sure.size)
+
+
+def assert_flatness_parity(flat, ref, S, tol=1e-5, what="flatness"):
+    """Margin-qualified gate for the spectral flatness exp(mean log(m + eps)) / mean m, a LOG-domain statistic: an error of
+    one fp32 FFT floor on bin k moves log m_k by floor / m_k, so a frame with a bin near a spectral null (|X| of the order of
+    the floor: one in a few thousand noise frames has one) carries the relative uncertainty u_t = mean_k(floor_t / (m_k +
+    floor_t)) whatever the kernel does.  The floor is a conservative figure (fft_floor: measured errors stay below 0.4 of it,
+    and a noise frame without a null has u_t of 4e-6 ... 2e-5): frames with u_t <= 20 tol are *sure* and held to tol of the
+    row's peak (the north-star gate, unchanged); the others -- a bin within a few floors of zero -- to one propagated floor,
+    2 u_t of their own value.  Returns (unsure, frames)."""
+    flat = np.asarray(flat, dtype=np.float64)
+    S = np.asarray(S, dtype=np.float64)
+    assert flat.shape == ref.shape and np.isfinite(flat).all(), what
+    floor = fft_floor(S)
+    u = np.mean(floor[None, :] / (S + floor[None, :] + 1e-300), axis=0)
+    pk = max(float(np.max(np.abs(ref))), 1e-300)
+    err = np.abs(flat - ref)
+    sure = u <= 20.0 * tol
+    assert (err[sure] <= tol * pk).all(), f"{what}: sure frames off by {err[sure].max() / pk:.2e} peak-relative (> {tol:g})"
+    assert (err[~sure] <= np.maximum(2.0 * u[~sure] * np.abs(ref[~sure]), tol * pk)).all(), \
+        f"{what}: a below-margin frame exceeds the propagated one-floor bound"
+    return int((~sure).sum()), int(sure.size)
