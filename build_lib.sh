@@ -2,7 +2,7 @@
 # Build libsygnals_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 #   SYG_LIB_OUT=<path>        output library (default: the product path sygnals_amd/lib/libsygnals_hip.so);
 #                             development variants (ablations, timeline builds) MUST go somewhere else
-#   EXTRA_HIPCC_FLAGS="..."   extra compiler flags (e.g. -DSYG_ABL=n; such a build reports itself through
+#   EXTRA_HIPCC_FLAGS="..."   extra compiler flags (e.g. -DSYG_DEV=1: per-phase stamps; such a build reports itself through
 #                             syg_build_variant() and sygnals_amd._lib refuses to load it as the product)
 #   SYG_BUILD_JOBS=n          parallel compile jobs (default 8)
 set -e
@@ -21,7 +21,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -fno-strict-aliasing -fno-slp-vectorize -
 compile_one() {
   s="sygnals_amd/csrc/$1.hip"; o="$OBJ/$1.o"
   [ -f "$s" ] || exit 0
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ sygnals_amd/csrc/common.h -nt "$o" ] || [ sygnals_amd/csrc/mel_segments.h -nt "$o" ] || [ sygnals_amd/csrc/wave_fft.h -nt "$o" ] || [ include/sygnals_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ sygnals_amd/csrc/common.h -nt "$o" ] || [ sygnals_amd/csrc/mel_segments.h -nt "$o" ] || [ sygnals_amd/csrc/wave_fft.h -nt "$o" ] || [ sygnals_amd/csrc/row_features.h -nt "$o" ] || [ sygnals_amd/csrc/stft_dev.h -nt "$o" ] || [ include/sygnals_hip.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$s" -o "$o" 2> >(grep -v "is not a recognized feature for this target" >&2)
   fi
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SYGNALS_AMD_LIB: development only (tools/ablate.sh, timeline builds) -- a library built somewhere else
+# SYGNALS_AMD_LIB: development only (timeline builds, A/B of a kernel against an earlier one) -- a library built somewhere else
 LIB_PATH = os.environ.get("SYGNALS_AMD_LIB") or os.path.join(_HERE, "lib", "libsygnals_hip.so")
 
 _p = C.c_void_p
@@ -109,7 +109,7 @@ def lib() -> C.CDLL:
             raise SygnalsHipError(f"libsygnals_hip.so ABI version {ver} != 1")
         var = h.syg_build_variant()
         if var != 0 and os.environ.get("SYGNALS_AMD_ALLOW_VARIANT") != str(var):
-            raise SygnalsHipError(f"{LIB_PATH} is a development variant (SYG_ABL={var}: results wrong by design); "
+            raise SygnalsHipError(f"{LIB_PATH} is a development variant (syg_build_variant() = {var}: stamps or ablations, results not for use); "
                                   "rebuild the product library with build_lib.sh")
         _lib = h
     return _lib
