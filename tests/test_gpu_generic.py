@@ -188,6 +188,29 @@ def test_sosfiltfilt_section_counts(ops, order, kind, cut):
         assert_parity(y[i], O.apply_sos_filter(sos, x[i].astype(np.float64)), TOL, f"order {order} {kind} row {i}")
 
 
+@pytest.mark.parametrize("kind", ["ellip", "cheby2", "scaled"])
+def test_sosfiltfilt_general_numerators(ops, kind):
+    """The clip-resident kernel has a form for cascades whose sections behind the first have b0 = b2 = 1 (zeros on the unit
+    circle with the gain in the first section, as zpk2sos lays out Butterworth, elliptic and Chebyshev-II designs: b1 is
+    free) and a general one, which a cascade with the gain moved between its sections takes: the same oracle on both sides
+    of the switch."""
+    import scipy.signal
+    if kind == "ellip":
+        sos = scipy.signal.ellip(6, 0.5, 60.0, [300.0, 3400.0], btype="bandpass", fs=48000.0, output="sos")[:4]
+    elif kind == "cheby2":
+        sos = scipy.signal.cheby2(6, 50.0, 2500.0, btype="lowpass", fs=48000.0, output="sos")
+    else:
+        sos = O.design_butterworth_sos((300.0, 3400.0), 48000.0, 4, "bandpass").copy()
+        sos[0, :3] *= 4.0; sos[2, :3] *= 0.25
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    pad = O.sosfiltfilt_padlen(sos)
+    rng = np.random.default_rng(len(kind))
+    x = (rng.normal(0, 0.5, (3, 30000)) + np.sin(np.arange(30000) * 0.02)).astype(np.float32)
+    y = ops.sosfiltfilt(ops.to_device_f32(x), sos, O.sosfilt_zi(sos), pad).cpu().numpy()
+    for i in range(3):
+        assert_parity(y[i], O.apply_sos_filter(sos, x[i].astype(np.float64)), TOL, f"{kind} row {i}")
+
+
 @pytest.mark.parametrize("L", [65536 - 54, 65537, 200001, 1 << 20])
 def test_sosfiltfilt_long_signals(ops, L):
     """More than 256 chunks per signal: every thread of the chunk-state prefix owns several consecutive chunks
