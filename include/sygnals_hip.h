@@ -235,6 +235,17 @@ int syg_stft_rows_wsmall_f32(const float* y, int64_t B, int64_t L, int64_t ldy, 
                              const float* window, const float* twiddle, float sr, float roll_percent, float bw_p,
                              int stats_mask, float* stats_out, const int32_t* cplan_host, float* contrast_out, void* stream);
 
+/* The same rows for frame length 4096 (2049 bins, bin frequency k sr / 4096) from the launch of syg_stft_mel_w4096_f32
+ * (one wave per frame): extract_features(frame_length=4096, [spectral features (+ mfcc)]) -- manager.py:289-343 over
+ * frequency_domain.py:24-386 -- without a spectrogram in HBM.  stats_out [B, SYG_NSTAT, T] (rows selected by stats_mask)
+ * and / or cplan_host + contrast_out [B, 2, n_rows, T]: at least one; with segtab (2048 words, as for
+ * syg_stft_mel_w4096_f32) and mel_out [B, n_mels, T] also the mel power block, with segtab NULL nothing is projected.
+ * window [4096]; twiddle: W_4096^k, k = 0 .. 4095. */
+int syg_stft_rows_w4096_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center, int64_t T,
+                            const float* window, const float* twiddle, const float* segtab, int n_segtab, int n_mels,
+                            float* mel_out, float sr, float roll_percent, float bw_p, int stats_mask, float* stats_out,
+                            const int32_t* cplan_host, float* contrast_out, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * power_to_db + DCT-II (+ lifter): librosa.power_to_db(S_mel, ref=np.max) at
  * manager.py:223 and librosa.feature.mfcc(S=..) at cepstral.py:106-115.

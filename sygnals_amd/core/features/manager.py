@@ -181,6 +181,12 @@ def extract_features_batch(y, sr: int, features: List[str], frame_length: int = 
                 if want_mfcc and not seg_mel:
                     mel = ops.stft_mel_pow2(yd, sr, 1024, hop_length, center, window, None, n_mels, fmin, fmax, int(power))
                 t_stft = Tn
+            elif (frame_length == 4096 and (want_stats or want_contrast) and
+                  (not want_mfcc or (power == 2.0 and ops.w4096_segtab(sr, n_mels, fmin, fmax) is not None))):
+                # frame length 4096: rows (and the mel block, power 2 with a piece table) from the one-wave-per-frame launch
+                mel, stats, cpv = ops.stft_rows_w4096(yd, sr, hop_length, center, window, None, n_mels if want_mfcc else None,
+                                                      fmin, fmax, want_stats, roll, bw_p, cplan)
+                t_stft = Tn
             elif (frame_length in (512, 256) and (want_stats or want_contrast) and
                   (not want_mfcc or (power in (1.0, 2.0) and ops.fused_pow2_ok(frame_length, n_mels)))):
                 # frame lengths 512 / 256 (256: the reference's short-signal tests): the rows from the segment-sum kernel's

@@ -2,7 +2,7 @@
 // sygnals/core/features/frequency_domain.py:24-386 (centroid, bandwidth, flatness, rolloff, dominant frequency; driven per
 // frame by manager.py:289-316) and the tail means of librosa.feature.spectral_contrast (frequency_domain.py:147-212,
 // manager.py:318-343).  Shared by the fused kernels of every frame length (stft_mel.hip: 1025 bins; stft_mel_w1024_seg.hip:
-// 513; stft_mel_wseg_small.hip: 257 / 129): NBIN = bins per row (16 NL + 1), PS: the row holds 4^PS |X|^2 (the kernels that
+// 513; stft_mel_wseg_small.hip: 257 / 129; stft_mel_w4096.hip: 2049): NBIN = bins per row (16 NL + 1), PS: the row holds 4^PS |X|^2 (the kernels that
 // pack 2 / 4 / 8 real frames into one complex transform leave the halvings of the split out; the factor -- a power of two
 // -- is taken back here, exactly).
 // Rows are skewed: bin k sits at word ppos(k) = k + k / 16.  Included inside namespace syg { namespace { ... } } after common.h.
@@ -48,43 +48,47 @@ __device__ __forceinline__ float row_stats_body(lds_row prow, int lane, float bi
   // immediate offsets, no bank conflicts -- and the last owning lane (63 of a 1025-bin row) also the Nyquist bin as a 17th
   // value (0 in the other lanes).  Rows of 513 / 257 / 129 bins: the lanes 32 / 16 / 8 ... 63 own nothing (zeros: no
   // contribution to any sum, never an extreme unless the row is all zero -- lane 0 then wins, as numpy's argmax does).
+  // Rows of 2049 bins (frame length 4096): G = 2 blocks of 16 bins per lane, 34 words apart per lane, Nyquist the 33rd value.
   // The powers are read ONCE and every statistic works on the registers (round 2 re-read the row per pass to
   // stay inside the caller-saved registers; 17 + 17 values still do).
-  constexpr int NL = (NBIN - 1) / 16;            // lanes that own bins
-  static_assert(NBIN == 16 * NL + 1 && NL >= 1 && NL <= 64, "rows of 16 NL + 1 bins, at most 1025");
+  constexpr int NG = (NBIN - 1) / 16;            // 16-bin blocks of the row
+  constexpr int G = NG > 64 ? 2 : 1;             // blocks per lane
+  constexpr int NL = NG / G;                     // lanes that own bins
+  constexpr int NV = 16 * G;                     // bins per lane (+ the Nyquist slot)
+  static_assert(NBIN == 16 * G * NL + 1 && NL >= 1 && NL <= 64, "rows of 16 NL + 1 bins (at most 1025), or 2049");
   constexpr bool FULL = (NL == 64);
   const float EPS = 2.220446049250313e-16f;
   const bool last = (lane == NL - 1);
   const bool own = FULL || lane < NL;
-  float p[17];
+  float p[NV + 1];
   {
-    lds_row pr = prow + 17 * (own ? lane : 0);
+    lds_row pr = prow + 17 * G * (own ? lane : 0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) p[i] = pr[i];
-    const float nyq = pr[17];                      // ppos(16 NL) = 17 (NL - 1) + 17 for the last owning lane (inside the row's slack elsewhere)
+    for (int i = 0; i < NV; ++i) p[i] = pr[i + (i >> 4)];
+    const float nyq = pr[17 * G];                  // ppos(16 G NL) = 17 G (NL - 1) + 17 G for the last owning lane (inside the row's slack elsewhere)
     if (!FULL) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) p[i] = own ? p[i] : 0.f;
+      for (int i = 0; i < NV; ++i) p[i] = own ? p[i] : 0.f;
     }
-    p[16] = last ? nyq : 0.f;
+    p[NV] = last ? nyq : 0.f;
     if (PS > 0) {
       constexpr float PSC = 1.f / (float)(1 << (2 * PS));
 #pragma unroll
-      for (int i = 0; i < 17; ++i) p[i] *= PSC;
+      for (int i = 0; i < NV + 1; ++i) p[i] *= PSC;
     }
   }
   float psum = 0.f;
 #pragma unroll
-  for (int i = 0; i < 17; ++i) psum += p[i];
+  for (int i = 0; i < NV + 1; ++i) psum += p[i];
   const float tot_p = wave_sum(psum);
-  const float kb = (float)(16 * lane);
+  const float kb = (float)(NV * lane);
   float tot_m = 0.f, cen_bin = 0.f;
   bool live = false;
   if (smask & (1 | 2 | 4)) {        // magnitude sums
-    float m[17];
+    float m[NV + 1];
     float msum = 0.f, fl = 0.f;
 #pragma unroll
-    for (int i = 0; i < 17; ++i) {
+    for (int i = 0; i < NV + 1; ++i) {
       m[i] = fsqrt(p[i]);
       msum += m[i];
       fl = fmaf(m[i], (float)i, fl);               // sum m (k - 16 lane): the lane's base enters once below
@@ -98,24 +102,24 @@ __device__ __forceinline__ float row_stats_body(lds_row prow, int lane, float bi
     if (smask & 4) {    // flatness: exp(mean log(m + eps)) / mean(m)
       float lsum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) lsum += __builtin_amdgcn_logf(m[i] + EPS);
-      const float l16 = __builtin_amdgcn_logf(m[16] + EPS);
+      for (int i = 0; i < NV; ++i) lsum += __builtin_amdgcn_logf(m[i] + EPS);
+      const float l16 = __builtin_amdgcn_logf(m[NV] + EPS);
       if (!FULL) lsum = own ? lsum : 0.f;
       lsum += last ? l16 : 0.f;
       const float tot_l = wave_sum(lsum) * 0.69314718055994531f;
       const float am = tot_m * (1.f / (float)NBIN);
       SYG_PUT(SYG_STAT_FLATNESS, (am >= EPS) ? fminf(fmaxf(fexp(tot_l * (1.f / (float)NBIN)) * frcp(am), 0.f), 1.f) : 0.f);
     }
-    if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p);  (m[16] = 0 outside lane 63)
+    if (smask & 2) {    // bandwidth: (sum m |f - c|^p / sum m)^(1/p);  (m[NV] = 0 outside the last owning lane)
       const int pmode = (bw_p == 2.f) ? 2 : (bw_p == 1.f) ? 1 : 0;
       const float d0 = kb - cen_bin;
       float dsum = 0.f;
       if (pmode == 2) {
 #pragma unroll
-        for (int i = 0; i < 17; ++i) { const float d = (d0 + (float)i) * binhz; dsum = fmaf(m[i], d * d, dsum); }
+        for (int i = 0; i < NV + 1; ++i) { const float d = (d0 + (float)i) * binhz; dsum = fmaf(m[i], d * d, dsum); }
       } else {
 #pragma unroll
-        for (int i = 0; i < 17; ++i) {
+        for (int i = 0; i < NV + 1; ++i) {
           const float d = fabsf(d0 + (float)i) * binhz;
           dsum = fmaf(m[i], pmode == 1 ? d : fpow(d, bw_p), dsum);
         }
@@ -129,12 +133,12 @@ __device__ __forceinline__ float row_stats_body(lds_row prow, int lane, float bi
     float pmax = p[0];
     int amax = 0;
 #pragma unroll
-    for (int i = 1; i < 17; ++i) {
-      const bool up = (i < 16 || last) && p[i] > pmax;
+    for (int i = 1; i < NV + 1; ++i) {
+      const bool up = (i < NV || last) && p[i] > pmax;
       pmax = up ? p[i] : pmax; amax = up ? i : amax;
     }
     const float gm = wave_max(pmax);
-    const int cand = wave_min_i((pmax == gm) ? 16 * lane + amax : 0x7fffffff);
+    const int cand = wave_min_i((pmax == gm) ? NV * lane + amax : 0x7fffffff);
     SYG_PUT(SYG_STAT_DOMINANT_BIN, (float)cand);
   }
   if (smask & 8) {    // rolloff: first bin with cumsum(power) >= roll * total
@@ -148,26 +152,26 @@ __device__ __forceinline__ float row_stats_body(lds_row prow, int lane, float bi
     float mgw = 0.f;
     if (smask & 32) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < NV; ++i) {
         c += p[i];
         below += (c < thr) ? 1 : 0;
       }
-      c += p[16];
+      c += p[NV];
       below += (last && c < thr) ? 1 : 0;
     } else {
       float mg = (lane > 0) ? fabsf(c - thr) : 3.4e38f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < NV; ++i) {
         c += p[i];
         below += (c < thr) ? 1 : 0;
         mg = fminf(mg, fabsf(c - thr));
       }
-      c += p[16];
+      c += p[NV];
       below += (last && c < thr) ? 1 : 0;
       mg = fminf(mg, fabsf(c - thr));
       mgw = wave_min(mg);
     }
-    const int rb = (below < (last ? 17 : 16)) ? 16 * lane + below : 0x7fffffff;
+    const int rb = (below < (last ? NV + 1 : NV)) ? NV * lane + below : 0x7fffffff;
     int rbmin = wave_min_i(rb);
     if (rbmin >= NBIN || tot_p < EPS) rbmin = NBIN - 1;      // (no hit: 0x7fffffff, or a lane that owns nothing)
     SYG_PUT(SYG_STAT_ROLLOFF_BIN, (float)rbmin);
@@ -529,6 +533,59 @@ __device__ __forceinline__ bool contrast_select(lds_row prow, int lane, int lo, 
   return true;
 }
 
+// Bands of 769 ... 1536 bins (the upper octave bands of frame length 4096: 1502 bins with k = 30 at 48 kHz): the band
+// sits in R = 24 registers per lane as bit patterns (non-negative floats order like their bits).  The k-th largest lane
+// MAXIMUM, rounded down to 16 bits, has at least k values of the band at or above it -- a few dozen candidates out of
+// 1500; they are compacted (lane counts, exclusive scan, predicated LDS writes) into words [0, 128) of the row -- the
+// bands below are finished and this band's values are in registers: the caller guarantees ascending band order and
+// ppos(lo) >= 256 -- so that the exact order statistic is a bisection over TWO values per lane (31 bits, two compares
+// each) instead of 24, and the tail sum is closed with the tie count.  The k smallest the same way on the complements, in
+// words [128, 256).  More than 128 candidates on a side (ties, a constant band): false, the caller's radix select runs.
+template <int R>
+__device__ __forceinline__ bool contrast_compact(lds_row prow, int lane, int lo, int n, int k, float& spk, float& svl) {
+  typedef __attribute__((address_space(3))) uint32_t* lds_urow;
+  lds_urow wrow = (lds_urow)prow;
+  constexpr uint32_t PAD = 0xffffffffu;
+  uint32_t v[R];
+  lds_row pr = prow + ppos(lo + lane);            // bin lo + lane + 64 r at ppos(lo + lane) + 68 r
+  const int nrem = n - lane;
+  uint32_t mx = 0, mn = PAD;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool in = 64 * r < nrem;
+    const uint32_t u = __float_as_uint(pr[in ? 68 * r : 0]);
+    v[r] = in ? u : PAD;
+    mx = in ? (u > mx ? u : mx) : mx;
+    mn = v[r] < mn ? v[r] : mn;
+  }
+  uint32_t Tu, Bu;
+  wave_kth_largest2_u32<16>(mx, ~mn, k, Tu, Bu);
+  Bu = ~Bu;                                       // at least k lane minima at or below it
+  int ch = 0, cl = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) { ch += (v[r] >= Tu && v[r] != PAD) ? 1 : 0; cl += (v[r] <= Bu) ? 1 : 0; }
+  if (wave_sum_i(ch) > 128 || wave_sum_i(cl) > 128) return false;
+  int oh = (int)wave_excl_scan((float)ch, lane), ol = 128 + (int)wave_excl_scan((float)cl, lane);
+  wave_lds_sync();                                // every lane has read its band values: the row's head may be overwritten
+  wrow[lane] = 0u; wrow[64 + lane] = 0u; wrow[128 + lane] = PAD; wrow[192 + lane] = PAD;
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (v[r] >= Tu && v[r] != PAD) { wrow[oh] = v[r]; ++oh; }
+    if (v[r] <= Bu) { wrow[ol] = v[r]; ++ol; }
+  }
+  wave_lds_sync();
+  const uint32_t x1 = wrow[lane], x2 = wrow[64 + lane], y1 = ~wrow[128 + lane], y2 = ~wrow[192 + lane];   // (pads: 0 on both sides)
+  uint32_t tx, ty;
+  wave_kth_largest2x2_u32<0>(x1, x2, y1, y2, k, tx, ty);
+  const float sh = (x1 > tx ? fsqrt(__uint_as_float(x1)) : 0.f) + (x2 > tx ? fsqrt(__uint_as_float(x2)) : 0.f);
+  const float sl = (y1 > ty ? fsqrt(__uint_as_float(~y1)) : 0.f) + (y2 > ty ? fsqrt(__uint_as_float(~y2)) : 0.f);
+  const int nh = (x1 > tx ? 1 : 0) + (x2 > tx ? 1 : 0), nl = (y1 > ty ? 1 : 0) + (y2 > ty ? 1 : 0);
+  spk = wave_sum(sh) + (float)(k - wave_sum_i(nh)) * fsqrt(__uint_as_float(tx));
+  svl = wave_sum(sl) + (float)(k - wave_sum_i(nl)) * fsqrt(__uint_as_float(~ty));
+  return true;
+}
+
 // mean of the k smallest and k largest MAGNITUDES of bins [lo, hi) of one LDS power row (identical to sorting,
 // as librosa does: values are non-negative, selection on power == selection on magnitude).
 //   bands of <= 768 bins with k <= 16 : register extraction, specialised by registers per lane;
@@ -536,6 +593,9 @@ __device__ __forceinline__ bool contrast_select(lds_row prow, int lane, int lo, 
 //                                       tie count.
 // may_park: the bands come in ascending order and the row's statistics are done, so a wide band may park its sorted
 // lists in the part of the row below its own end (contrast_extract_lds)
+// WIDE: rows of more than 1025 bins (the 24-register form of bands of 769 ... 1536 bins is only built into their kernels:
+// inside the row functions of the 2048-sample kernels it would cost registers on a path their rows never take)
+template <bool WIDE>
 __device__ __forceinline__ float2 band_contrast(lds_row prow, int lane, int lo, int hi, int k, int may_park) {   // (peak, valley)
   const int n = hi - lo;
   if (n <= 768 && k <= 16) {
@@ -566,6 +626,13 @@ __device__ __forceinline__ float2 band_contrast(lds_row prow, int lane, int lo, 
     }
     const float rk = frcp((float)k);
     return make_float2(spk * rk, svl * rk);
+  }
+  if (WIDE && n <= 64 * 24 && n >= 64 && k <= 64 && may_park && ppos(lo) >= 256) {
+    float spk, svl;
+    if (contrast_compact<24>(prow, lane, lo, n, k, spk, svl)) {
+      const float rk = frcp((float)k);
+      return make_float2(spk * rk, svl * rk);
+    }
   }
   const uint32_t tlo = row_kth(prow, lane, lo, n, k, false), thi = row_kth(prow, lane, lo, n, k, true);
   float slo = 0.f, shi = 0.f;
@@ -663,7 +730,7 @@ __device__ __forceinline__ int contrast_narrow_group(lds_row prow, int lane, int
 // argument traffic seven times).  Band r's (peak, valley) tail means come back in lane r of the two result registers;
 // the caller stores them.  The plan (lo, hi, k per band) is read from its LDS copy: one read per array, lane = band.
 typedef const __attribute__((address_space(3))) int* lds_iptr;
-template <int PS>
+template <int PS, bool WIDE>
 __device__ __forceinline__ float2 row_contrast_body(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
   const int n_rows = uni(n_rows_v), may_park = uni(may_park_v);
   const int lb = lane & (SYG_MAX_BANDS - 1);
@@ -673,7 +740,7 @@ __device__ __forceinline__ float2 row_contrast_body(lds_row prow, int lane, lds_
   for (int r = r0; r < n_rows; ++r) {
     const int lo = __builtin_amdgcn_readlane(plo, r), hi = __builtin_amdgcn_readlane(phi, r),
               k = __builtin_amdgcn_readlane(pk, r);
-    const float2 pv = band_contrast(prow, lane, lo, hi, k, may_park);
+    const float2 pv = band_contrast<WIDE>(prow, lane, lo, hi, k, may_park);
     rp = (lane == r) ? pv.x : rp;
     rv = (lane == r) ? pv.y : rv;
   }
@@ -687,9 +754,9 @@ template <int NBIN, int PS>
 __device__ __noinline__ float row_stats(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask) {
   return row_stats_body<NBIN, PS>(prow, lane, binhz, roll_percent, bw_p, smask);
 }
-template <int PS>
+template <int PS, bool WIDE = false>
 __device__ __noinline__ float2 row_contrast_all(lds_row prow, int lane, lds_iptr cpl, int n_rows_v, int may_park_v) {
-  return row_contrast_body<PS>(prow, lane, cpl, n_rows_v, may_park_v);
+  return row_contrast_body<PS, WIDE>(prow, lane, cpl, n_rows_v, may_park_v);
 }
 // Statistics AND contrast of one row in one call (the C4 block asks for both: one entry / exit sequence, one wait for
 // the outstanding memory operations, instead of two).  x: the statistics register of row_stats, y / z: peak / valley.
@@ -697,6 +764,6 @@ template <int NBIN, int PS>
 __device__ __noinline__ float3 row_features(lds_row prow, int lane, float binhz, float roll_percent, float bw_p, int smask,
                                             lds_iptr cpl, int n_rows_v, int may_park_v) {
   const float s = row_stats_body<NBIN, PS>(prow, lane, binhz, roll_percent, bw_p, smask);
-  const float2 pv = row_contrast_body<PS>(prow, lane, cpl, n_rows_v, may_park_v);
+  const float2 pv = row_contrast_body<PS, (NBIN > 1025)>(prow, lane, cpl, n_rows_v, may_park_v);
   return make_float3(s, pv.x, pv.y);
 }

@@ -454,13 +454,54 @@ def stft_rows_wsmall(y: torch.Tensor, sr: float, n_fft: int, hop: int, center: b
     return stats, cpv
 
 
+def stft_rows_w4096(y: torch.Tensor, sr: float, hop: int = 1024, center: bool = True, window="hann", win_length=None,
+                    n_mels: Optional[int] = None, fmin: float = 0.0, fmax=None, want_stats=False, roll_percent: float = 0.85,
+                    bw_p: float = 2.0, contrast: Optional[np.ndarray] = None):
+    """frame_length 4096: the statistics / contrast rows of stft2048_mel from the one-wave-per-frame kernel's launch
+    (syg_stft_rows_w4096_f32), with the mel power block when n_mels is given (needs a piece table: w4096_segtab).
+    Returns (mel [B, M, T] | None, stats [B, 8, T] | None, contrast_pv [B, 2, R, T] | None)."""
+    smask = 31 if want_stats is True else int(want_stats or 0)
+    require_gpu()
+    if y.dim() != 2 or y.dtype != torch.float32 or not y.is_cuda:
+        raise ValueError("y must be a float32 CUDA tensor of shape [B, L]")
+    if not smask and contrast is None:
+        raise ValueError("stft_rows_w4096: no statistics requested (stft_mel_w4096 gives the mel block alone)")
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    tab = None
+    if n_mels is not None:
+        tab = w4096_segtab(sr, n_mels, fmin, fmax)
+        if tab is None:
+            raise SygnalsHipError("stft_rows_w4096: no piece table for this filterbank")
+    B, L = y.shape
+    Tn = num_frames(L, 4096, hop, center)
+    if Tn <= 0:
+        raise ValueError("signal too short for one frame")
+    mel = torch.empty((B, n_mels, Tn), dtype=torch.float32, device=y.device) if tab is not None else None
+    stats = torch.zeros((B, 8, Tn), dtype=torch.float32, device=y.device) if smask else None
+    cpv = cplan_p = None
+    if contrast is not None:
+        cplan = np.ascontiguousarray(contrast, dtype=np.int32)
+        cpv = torch.empty((B, 2, int(cplan[0]), Tn), dtype=torch.float32, device=y.device)
+        cplan_p = cplan.ctypes.data_as(C.c_void_p)
+    rc = lib().syg_stft_rows_w4096_f32(_ptr(y), B, L, _ld(y), hop, int(center), Tn,
+                                       _ptr(window_dev(window, win_length or 4096, 4096)), _ptr(twiddle_dev(4096)), _ptr(tab),
+                                       int(tab.numel()) if tab is not None else 0, int(n_mels or 0), _ptr(mel), float(sr),
+                                       float(roll_percent), float(bw_p), smask, _ptr(stats), cplan_p, _ptr(cpv),
+                                       C.c_void_p(_stream_ptr()))
+    check(rc, "syg_stft_rows_w4096_f32")
+    return mel, stats, cpv
+
+
 def stft_rows_seg(y, sr, n_fft, hop, center=True, window="hann", win_length=None, n_mels=None, fmin=0.0, fmax=None,
                   want_stats=False, roll_percent=0.85, bw_p=2.0, contrast=None):
     """Statistics / contrast rows (+ the mel power block when n_mels is given) from the segment-sum kernels of frame lengths
-    1024 (one launch) and 512 / 256 (the rows from one launch, the mel block -- power 2 -- from the projection form's).
+    1024 / 4096 (one launch) and 512 / 256 (the rows from one launch, the mel block -- power 2 -- from the projection form's).
     Returns (mel | None, stats | None, contrast_pv | None); raises SygnalsHipError for other frame lengths."""
     if n_fft == 1024:
         return stft_rows_w1024(y, sr, hop, center, window, win_length, n_mels, fmin, fmax, want_stats, roll_percent, bw_p, contrast)
+    if n_fft == 4096:
+        return stft_rows_w4096(y, sr, hop, center, window, win_length, n_mels, fmin, fmax, want_stats, roll_percent, bw_p, contrast)
     if n_fft in (512, 256):
         stats, cpv = stft_rows_wsmall(y, sr, n_fft, hop, center, window, win_length, want_stats, roll_percent, bw_p, contrast)
         mel = None

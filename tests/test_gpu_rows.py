@@ -97,6 +97,47 @@ def test_rows_frame_lengths_512_256(ops, n_fft, hop, sr, L, center, n_mels):
     check_rows(ops, n_fft, hop, sr, L, center, n_mels, B=5 if L > 512 else 2)
 
 
+@pytest.mark.parametrize("hop,sr,L,center,n_mels", [
+    (1024, 48000, 30011, True, 40),        # 2049-bin rows (two 16-bin blocks per lane), top contrast band of 1502 bins (radix select)
+    (2048, 22050, 22050, True, None),      # statistics only, nothing projected
+    (1024, 22050, 20000, True, 128),       # the default filterbank
+    (1000, 44100, 9000, False, 64),        # center=False, a hop that is no power of two
+    (1024, 16000, 512, True, None),        # a clip shorter than the frame: one frame of mostly padding
+])
+def test_rows_frame_length_4096(ops, hop, sr, L, center, n_mels):
+    check_rows(ops, 4096, hop, sr, L, center, n_mels, B=5 if L > 512 else 2)
+
+
+def test_manager_frame_4096_takes_the_rows_kernel(ops, monkeypatch):
+    """extract_features_batch(frame_length=4096, spectral features + mfcc): rows and mel block from ONE launch."""
+    from sygnals_amd.core.features.manager import extract_features_batch
+    called = []
+    real = ops.stft_any
+    monkeypatch.setattr(ops, "stft_any", lambda *a, **k: (called.append(1), real(*a, **k))[1])
+    sr = 48000
+    Y = O.synth_clips(2, 30000, sr, seed=5)
+    feats = ["spectral_centroid", "spectral_bandwidth", "spectral_flatness", "spectral_rolloff", "spectral_contrast", "mfcc"]
+    fp = {"mfcc": {"n_mels": 40}}
+    d = extract_features_batch(Y, sr, feats, frame_length=4096, hop_length=1024, feature_params=fp)
+    assert not called
+    for b in range(2):
+        ref = O.extract_features(Y[b].astype(np.float64), sr, feats, frame_length=4096, hop_length=1024, feature_params=fp)
+        S = np.abs(O.stft(Y[b].astype(np.float64), 4096, 1024))
+        st = O.spectral_stats_frames(S, O.fft_frequencies(sr, 4096))
+        for k in ref:
+            if k == "time":
+                assert np.allclose(d[k], ref[k], rtol=0, atol=1e-12)
+            elif k == "spectral_rolloff":
+                m = st["rolloff_margin"] > 1e-6
+                assert np.array_equal(d[k][b][m], ref[k][m]), k
+            elif k == "spectral_flatness":
+                assert_flatness_parity(d[k][b], ref[k], S, TOL, k)
+            elif k.startswith("contrast"):
+                assert peak_rel(d[k][b], ref[k]) <= 20 * TOL, k
+            else:
+                assert_parity(d[k][b], ref[k], TOL, k)
+
+
 def test_manager_frame_1024_takes_the_rows_kernel(ops, monkeypatch):
     """extract_features_batch(frame_length=1024, spectral features [+ mfcc]) runs ONE fused launch for the rows (plus the
     dB / DCT launch for the MFCC): no complex STFT in HBM.  Columns against the oracle's."""

@@ -54,7 +54,7 @@ if want("C1 one clip"):
            256 * 160000, 256 * (4 * 160000 + 4 * 13 * 313), n=20)
     del y1, y1b
 # the reference's own manager tests: frame_length=1024 with spectral features (tests/test_features_manager.py:58-62,167-174)
-if not ONLY or any("1024" in a or "c4-style" in a for a in ONLY):
+if not ONLY or any("1024" in a or "c4-style" in a or "4096" in a for a in ONLY):
     from sygnals_amd.core.features.manager import extract_features_batch
     T4 = 1 + L // 256
     report("a6-a9 n_fft=1024 hop=256: centroid + rolloff through extract_features_batch (device resident), 1024 clips",
@@ -64,6 +64,13 @@ if not ONLY or any("1024" in a or "c4-style" in a for a in ONLY):
         report(f"a6-a9 n_fft={nf} hop={hp}: centroid + rolloff through extract_features_batch (device resident), 1024 clips",
                lambda: extract_features_batch(y, SR, ["spectral_centroid", "spectral_rolloff"], nf, hp, to_host=False), B * L,
                B * (4 * L + 4 * 2 * (1 + L // hp)), n=5, warm=2)
+    report("a6-a9 n_fft=4096 hop=1024: centroid + rolloff through extract_features_batch (device resident), 1024 clips",
+           lambda: extract_features_batch(y, SR, ["spectral_centroid", "spectral_rolloff"], 4096, 1024, to_host=False), B * L,
+           B * (4 * L + 4 * 2 * (1 + L // 1024)), n=5, warm=2)
+    report("C4-style block n_fft=4096 hop=1024: mfcc(40) + centroid + rolloff + contrast through extract_features_batch, 1024 clips",
+           lambda: extract_features_batch(y, SR, ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"], 4096, 1024,
+                                          feature_params={"mfcc": {"n_mels": 40}}, to_host=False), B * L,
+           B * (4 * L + 4 * 22 * (1 + L // 1024)), n=5, warm=2)
     report("C4-style block n_fft=1024 hop=256: mfcc(40) + centroid + rolloff + contrast through extract_features_batch, 1024 clips",
            lambda: extract_features_batch(y, SR, ["mfcc", "spectral_centroid", "spectral_rolloff", "spectral_contrast"], 1024, 256,
                                           feature_params={"mfcc": {"n_mels": 40}}, to_host=False), B * L, B * (4 * L + 4 * 22 * T4), n=5, warm=2)
