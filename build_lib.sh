@@ -12,7 +12,7 @@ mkdir -p "$(dirname "$OUT")"
 TAG=$(echo "$EXTRA_HIPCC_FLAGS" | md5sum | cut -c1-8)
 OBJ="build/obj-$TAG"
 mkdir -p "$OBJ"
-SRCS="capi stft_mel stft_mel_pow2 stft_mel_w4096 stft_mel_w1024_seg stft_mel_wseg_small logmel_dct fft_generic spectral sosfilt sosfilt_clip cqt frame_stats dsp_extra ingest ml_utils fft_mixed welch_wave"
+SRCS="capi stft_mel stft_mel_pow2 stft_mel_w4096 stft_mel_w1024_seg stft_mel_wseg_small logmel_dct fft_generic spectral sosfilt sosfilt_clip cqt cqt_fused frame_stats dsp_extra ingest ml_utils fft_mixed welch_wave"
 # -load-store-opt off (an AMDGPU feature; the host pass ignores it with a warning): keeps LDS accesses as single
 # ds_read_b64 / ds_write_b64.  The merged forms (ds_read2_b64 ...) run at half the LDS rate on gfx950 and bank on 32
 # instead of 64 dwords, which turns the conflict-free FFT exchange patterns into 2-way conflicts

@@ -477,6 +477,18 @@ int syg_cqt_octave_gemm_f32(const float* y, int64_t B, int64_t L, int64_t ldy, i
  *   float32(G[32 s + 8 (lane >> 4) + j][16 mt + (lane & 15)]); 16-byte aligned.  */
 int syg_cqt_octave_bf16x3_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
                               const void* gsplit, int n_filt, float* out, int64_t out_bstride, int row0, void* stream);
+
+/* The whole transform of compute_cqt (sygnals/core/dsp.py:231-289) in ONE launch for its usual shape -- hop_length 512, one
+ * early decimation, n_oct <= 7 octaves of n_filt <= 16 filters at frame length 256 and hop 256 >> o that share one operand
+ * table (sygnals_amd.ops.cqt_pack_bf16x3: [3][2][8][64] 16-byte entries): the stream is read once, every decimation level
+ * lives in LDS only (syg_decimate2_chain_f32 + n_oct x syg_cqt_octave_bf16x3_f32 write and re-read them through HBM), the
+ * same values to the rounding of the float32 sums (the decimator's symmetric taps are paired, the products' k range is
+ * summed in four parts).  taps: the 41-tap half-band decimator (zero at the even offsets from its centre, symmetric);
+ * scale: sqrt(2); row0_host[n_oct]: first output row of octave o; out [B, n_bins, T] complex (float pairs),
+ * out_bstride in complex elements, T <= the smallest centred frame count over the octaves (1 + L_o / hop_o). */
+int syg_cqt_fused_f32(const float* y, int64_t B, int64_t L, int64_t ldy, const float* taps, int ntaps, float scale,
+                      const void* gsplit, int n_filt, int n_oct, const int32_t* row0_host, int64_t T, float* out,
+                      int64_t out_bstride, void* stream);
 int syg_cqt_octave_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int n_fft, int hop, int64_t T,
                        const float* twiddle, const float* basis, int n_filt, const int32_t* hull_host,
                        float* out, int64_t out_bstride, int row0, void* stream);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "syg_stft_mel_wseg_small_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _l, _p, _p, _p, _i, _i, _p, _p]),
     "syg_stft_rows_wsmall_f32": (_i, [_p, _l, _l, _l, _i, _i, _i, _l, _p, _p, _f, _f, _f, _i, _p, _p, _p, _p]),
     "syg_stft_rows_w4096_f32": (_i, [_p, _l, _l, _l, _i, _i, _l, _p, _p, _p, _i, _i, _p, _f, _f, _f, _i, _p, _p, _p, _p]),
+    "syg_cqt_fused_f32": (_i, [_p, _l, _l, _l, _p, _i, _f, _p, _i, _i, _p, _l, _p, _l, _p]),
     "syg_mel_mfcc_f32": (_i, [_p, _l, _i, _l, _p, _i, _p, _f, _f, _i, _f, _p, _p]),
     "syg_fft_pow2_strided_ex_f32": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _l, _l, _l, _l, _l, _l, _f, _i, _l, _l, _p]),
     "syg_fft_mixed_strided_ex_f32": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _l, _l, _l, _l, _l, _l, _f, _i, _l, _l, _p]),

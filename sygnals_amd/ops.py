@@ -97,12 +97,14 @@ class _Settings:
       cqt_mode              "bf16x3" (default) | "gemm" | "fft": octave kernel of compute_cqt
       cqt_streams           1 | 2: octave products on a side stream (measured: no gain)
       cqt_chain             True: up to three decimation levels per pass; False: one launch per level
+      cqt_fused             True: the one-launch form (syg_cqt_fused_f32) where the plan has its shape; False: level by level
       one_launch_features   True: extract_features routes MFCC + statistics / contrast requests to the one-launch kernels
     Options that live in the library (syg_set_option): reserved_cus, stft_load, sos_clip, cqt_staged."""
     waves = T.WAVES
     cqt_mode = "bf16x3"
     cqt_streams = 1
     cqt_chain = True
+    cqt_fused = True
     one_launch_features = True
 
 
@@ -1701,6 +1703,16 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
             o["gsplit_dev"] = (torch.from_numpy(cqt_pack_bf16x3(b, o["n_fft"]).view(np.int16)).to(require_gpu())
                                if o["n_fft"] in (128, 256) and len(b) <= 16 else None)
         p.taps_dev = _dev(decimation_taps().astype(np.float32))
+        # the one-launch form (syg_cqt_fused_f32): hop 512, one early decimation, <= 7 octaves at frame length 256 and hop
+        # 256 >> o, no clipped octave, and ONE operand table -- the octaves' bases are the same matrix up to rounding
+        # (the decimator's sqrt(2) and the plan's scalings cancel)
+        oc = p.octaves
+        b0 = oc[0]["basis"]
+        p.fused_ok = (int(hop_length) == 512 and p.early == 1 and 1 <= len(oc) <= 7 and oc[0].get("gsplit_dev") is not None
+                      and all(o["n_fft"] == 256 and o["hop"] == (256 >> i) and o["skip"] == 0 and o["n"] == oc[0]["n"]
+                              and o["basis"].shape == b0.shape
+                              and np.abs(o["basis"] - b0).max() <= 1e-12 * np.abs(b0).max() for i, o in enumerate(oc)))
+        p.row0 = np.ascontiguousarray([o["row0"] for o in oc], dtype=np.int32)
         return p
     plan = _cached(key, build)
     if y.stride(1) != 1:
@@ -1719,6 +1731,13 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
             Lc = (Lc + 1) // 2
     out = torch.empty((B, plan.n_bins, Tn, 2), dtype=torch.float32, device=y.device)      # every row is written
     s2 = float(np.sqrt(2.0))
+    if settings.cqt_fused and settings.cqt_mode == "bf16x3" and plan.fused_ok and Tn >= 1:
+        rc = lib().syg_cqt_fused_f32(_ptr(y), B, L, _ld(y), _ptr(plan.taps_dev), plan.taps_dev.numel(), s2,
+                                     _ptr(plan.octaves[0]["gsplit_dev"]), plan.octaves[0]["n"], len(plan.octaves),
+                                     plan.row0.ctypes.data_as(C.c_void_p), Tn, _ptr(out), plan.n_bins * Tn,
+                                     C.c_void_p(_stream_ptr()))
+        check(rc, "syg_cqt_fused_f32")
+        return out
     # octave kernel: "bf16x3" (default: the framed product with bfloat16-split operands, fp32-equivalent), "gemm" (the
     # single-instruction fp32 MFMA form), "fft" (rfft x sparse rows; also what other frame lengths take)
     mode = settings.cqt_mode

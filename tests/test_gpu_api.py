@@ -294,6 +294,7 @@ def test_cqt_staged_frames_identical(sr, hop, n_bins, L, B, monkeypatch):
     rng = np.random.default_rng(L)
     x = ops.to_device_f32(rng.normal(0, 0.3, (B, L)).astype(np.float32))
     monkeypatch.setattr(ops.settings, "cqt_mode", "bf16x3")
+    monkeypatch.setattr(ops.settings, "cqt_fused", False)      # (the level-by-level kernels are the subject here)
     with ops.override(cqt_staged=2):                            # 2: also where hop = n_fft / 2 (not the default there)
         a = ops.cqt(x, sr, hop_length=hop, n_bins=n_bins)
     with ops.override(cqt_staged=1):
@@ -342,9 +343,64 @@ def test_cqt_chain_and_level_by_level_identical(monkeypatch):
     from sygnals_amd import ops
     import torch
     x = ops.to_device_f32(np.random.default_rng(3).normal(0, 0.3, (2, 48000 * 5 + 3)).astype(np.float32))
-    a = ops.cqt(x, 48000)
-    with ops.override(cqt_chain=False):
-        assert torch.equal(a, ops.cqt(x, 48000))
+    with ops.override(cqt_fused=False):
+        a = ops.cqt(x, 48000)
+        with ops.override(cqt_chain=False):
+            assert torch.equal(a, ops.cqt(x, 48000))
+
+
+@pytest.mark.parametrize("sr,n_bins,fmin,L,B", [
+    (48000, 84, None, 48000 * 2 + 77, 1),     # one segment, ragged level lengths
+    (48000, 84, None, 48000 * 9 + 5, 2),      # several segments per signal, a batch with an odd row stride
+    (48000, 84, None, 3000, 1), (48000, 84, None, 1, 1), (48000, 84, None, 511, 3), (48000, 84, None, 512, 1),
+    (48000, 84, None, 65536 * 3, 1),          # frames exactly on segment borders
+    (48000, 36, 523.25, 48000 * 3 + 1, 1),    # three octaves
+    (48000, 48, 261.63, 100003, 2),           # four octaves
+    (44100, 84, None, 44100 * 4, 1),
+    (48000, 60, None, 48000 + 1, 1)])         # (three early decimations: not this form's shape -- the level-by-level kernels)
+def test_cqt_one_launch_form(sr, n_bins, fmin, L, B):
+    """syg_cqt_fused_f32 (every decimation level in LDS only, all octaves' products in the same launch) against the
+    level-by-level kernels -- the same operands; the float32 sums are grouped differently (symmetric tap pairs, the
+    products' k range in four parts): 2e-6 of the peak -- and against the oracle at 1e-5: segment borders, lead-in at the
+    signal's start, level lengths that round up, signals shorter than a frame, fewer than seven octaves."""
+    from sygnals_amd import ops
+    rng = np.random.default_rng(L + B)
+    t = np.arange(L) / sr
+    x = (rng.normal(0, 0.2, (B, L)) + 0.4 * np.sin(2 * np.pi * 110.0 * t) + 0.3 * np.sin(2 * np.pi * 2500.0 * t)).astype(np.float32)
+    xd = ops.to_device_f32(x)
+    a = ops.cqt(xd, sr, n_bins=n_bins, fmin=fmin).cpu().numpy()
+    with ops.override(cqt_fused=False):
+        b = ops.cqt(xd, sr, n_bins=n_bins, fmin=fmin).cpu().numpy()
+    assert a.shape == b.shape
+    pk = np.abs(b).max()
+    assert np.abs(a - b).max() <= 2e-6 * pk + 1e-30
+    if L <= 48000 * 3 + 1:
+        ref = O.cqt(x[0].astype(np.float64), sr, n_bins=n_bins, fmin=fmin)
+        assert peak_rel(a[0, ..., 0] + 1j * a[0, ..., 1], ref) <= TOL
+
+
+def test_cqt_one_launch_form_is_taken(monkeypatch):
+    """The default call of compute_cqt's shape (48 kHz, hop 512, 84 bins) runs ONE launch; other shapes (hop 1024: two
+    early decimations) keep the level-by-level kernels."""
+    from sygnals_amd import ops
+    calls = []
+    lib = ops.lib()
+    real = lib.syg_cqt_fused_f32
+    x = ops.to_device_f32(np.random.default_rng(1).normal(0, 0.3, (1, 48000)).astype(np.float32))
+
+    class Spy:
+        def __getattr__(self, name):
+            if name == "syg_cqt_fused_f32":
+                return lambda *a: (calls.append(name), real(*a))[1]
+            if name.startswith("syg_cqt_octave") or name.startswith("syg_decimate2"):
+                calls.append(name)
+            return getattr(lib, name)
+    monkeypatch.setattr(ops, "lib", lambda: Spy())
+    ops.cqt(x, 48000)
+    assert calls == ["syg_cqt_fused_f32"]
+    calls.clear()
+    ops.cqt(x, 48000, hop_length=1024)
+    assert calls and "syg_cqt_fused_f32" not in calls
 
 
 def test_cqt_batch_long_stream_consistency():
