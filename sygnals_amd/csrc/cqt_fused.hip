@@ -243,27 +243,39 @@ __device__ __forceinline__ cf_v4f cf_product(const float* lds, int lane, const c
       for (int q = 0; q < 4; ++q) { bh[q] = x0[q]; bh[4 + q] = x1[q]; bm[q] = m0[q]; bm[4 + q] = m1[q]; bl[q] = l0[q]; bl[4 + q] = l1[q]; }
     }
   };
-  // two k-steps at a time, their matrix instructions alternating between the two accumulators: a wave's consecutive
-  // instructions are independent (small terms first per accumulator, the order of cqt_bf16x3_kernel).  The operand reads
-  // are left to the compiler's order (each a few instructions ahead of its use): issuing a pair or the whole block ahead
-  // was measured slower (1.45 -> 1.83 us per product phase: eight waves' bursts queue up in the LDS).
+  // Two k-steps at a time, their matrix instructions alternating between the two accumulators: a wave's consecutive
+  // instructions are independent (small terms first per accumulator, the order of cqt_bf16x3_kernel).  The six operand
+  // reads of the NEXT pair are issued one behind each of the first six matrix instructions of the current pair
+  // (sched_group_barrier: the compiler's own order put every read directly in front of its use -- a wave then pays the
+  // LDS latency once per read -- and reads issued as a burst ahead of the block queue up behind the other waves').
+  cf_v8bf bh[2][2], bm[2][2], bl[2][2];
+  auto pair = [&](int g, int q) { operand(2 * g, bh[q][0], bm[q][0], bl[q][0]); operand(2 * g + 1, bh[q][1], bm[q][1], bl[q][1]); };
+  pair(0, 0);
 #pragma unroll
-  for (int s = 0; s < 8; s += 2) {
-    cf_v8bf bh0, bm0, bl0, bh1, bm1, bl1;
-    operand(s, bh0, bm0, bl0);
-    operand(s + 1, bh1, bm1, bl1);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[2][s], bh0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[2][s + 1], bh1, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bl0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bl1, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bm0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s + 1], bm1, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bh0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s + 1], bh1, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bm0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bm1, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bh0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bh1, acc[1], 0, 0, 0);
+  for (int g = 0; g < 4; ++g) {
+    const int q = g & 1, s = 2 * g;
+    if (g + 1 < 4) pair(g + 1, q ^ 1);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[2][s], bh[q][0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[2][s + 1], bh[q][1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bl[q][0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bl[q][1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bm[q][0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s + 1], bm[q][1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bh[q][0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s + 1], bh[q][1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bm[q][0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bm[q][1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bh[q][0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bh[q][1], acc[1], 0, 0, 0);
+    if (g + 1 < 4) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   return acc[0] + acc[1];
 }
