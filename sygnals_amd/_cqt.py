@@ -105,3 +105,18 @@ class CqtPlan:
             o["basis"] = o["basis"][o["skip"]:] * scale[rows][:, None]
             o["n"] = len(rows)
         self.freqs = freqs
+        self.hop_length = int(hop_length)
+
+    def one_launch_shape(self) -> bool:
+        """True when syg_cqt_fused_f32 can take the whole transform: hop_length 512, one early decimation, at most seven
+        octaves at frame length 256 and hop 256 >> o with the same number (<= 16) of unclipped filters, and ONE operand
+        table -- the octaves' bases are the same matrix up to rounding (the decimator's sqrt(2) and the scalings above
+        cancel).  48 / 44.1 kHz with the default 84 bins qualify; 22.05 kHz (no early decimation) and hop 1024 do not."""
+        oc = self.octaves
+        if self.hop_length != 512 or self.early != 1 or not 1 <= len(oc) <= 7 or not 1 <= oc[0]["n"] <= 16:
+            return False
+        b0 = oc[0]["basis"]
+        tol = 1e-12 * float(np.abs(b0).max())
+        return all(o["n_fft"] == 256 and o["hop"] == (256 >> i) and o["skip"] == 0 and o["n"] == oc[0]["n"]
+                   and o["basis"].shape == b0.shape and float(np.abs(o["basis"] - b0).max()) <= tol
+                   for i, o in enumerate(oc))

@@ -1703,15 +1703,9 @@ def cqt(y: torch.Tensor, sr: float, hop_length: int = 512, fmin=None, n_bins: in
             o["gsplit_dev"] = (torch.from_numpy(cqt_pack_bf16x3(b, o["n_fft"]).view(np.int16)).to(require_gpu())
                                if o["n_fft"] in (128, 256) and len(b) <= 16 else None)
         p.taps_dev = _dev(decimation_taps().astype(np.float32))
-        # the one-launch form (syg_cqt_fused_f32): hop 512, one early decimation, <= 7 octaves at frame length 256 and hop
-        # 256 >> o, no clipped octave, and ONE operand table -- the octaves' bases are the same matrix up to rounding
-        # (the decimator's sqrt(2) and the plan's scalings cancel)
+        # the one-launch form (syg_cqt_fused_f32) where the plan has its shape (CqtPlan.one_launch_shape)
         oc = p.octaves
-        b0 = oc[0]["basis"]
-        p.fused_ok = (int(hop_length) == 512 and p.early == 1 and 1 <= len(oc) <= 7 and oc[0].get("gsplit_dev") is not None
-                      and all(o["n_fft"] == 256 and o["hop"] == (256 >> i) and o["skip"] == 0 and o["n"] == oc[0]["n"]
-                              and o["basis"].shape == b0.shape
-                              and np.abs(o["basis"] - b0).max() <= 1e-12 * np.abs(b0).max() for i, o in enumerate(oc)))
+        p.fused_ok = p.one_launch_shape() and oc[0].get("gsplit_dev") is not None
         p.row0 = np.ascontiguousarray([o["row0"] for o in oc], dtype=np.int32)
         return p
     plan = _cached(key, build)

@@ -431,3 +431,19 @@ def test_mel_segment_table_four_passes_for_the_default_filterbank(sr, n_mels, fm
     bands = ti[:, 0, :, 1].ravel()
     assert sorted(bands[bands >= 0].tolist()) == list(range(n_mels))
     assert int(ti[3, 0, 63, 1]) < 0                                        # the last lane never stores a band
+
+
+def test_cqt_one_launch_shape():
+    """Which plans syg_cqt_fused_f32 takes (ops.cqt asks CqtPlan.one_launch_shape): compute_cqt's usual call at 48 / 44.1 kHz
+    and its variants with fewer octaves; not a plan without (22.05 kHz) or with more (hop 1024, 60 bins) early
+    decimations, another frame length (32 kHz) or a clipped last octave."""
+    from sygnals_amd._cqt import CqtPlan
+    assert CqtPlan(48000, 512, None, 84).one_launch_shape()
+    assert CqtPlan(44100, 512, None, 84).one_launch_shape()
+    assert CqtPlan(48000, 512, 523.25, 36).one_launch_shape()
+    assert CqtPlan(48000, 512, 261.63, 48).one_launch_shape()
+    assert not CqtPlan(22050, 512, None, 84).one_launch_shape()
+    assert not CqtPlan(48000, 1024, None, 84).one_launch_shape()
+    assert not CqtPlan(48000, 512, None, 60).one_launch_shape()
+    assert not CqtPlan(32000, 512, None, 72).one_launch_shape()
+    assert not CqtPlan(48000, 512, None, 80).one_launch_shape()      # 80 bins: the lowest octave is clipped to 8 filters
