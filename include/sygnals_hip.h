@@ -123,11 +123,13 @@ int syg_stft2048_c2c_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int 
  *   amin, top_db (< 0: no clamp), ref_is_max (1: per-clip max, 0: ref_value): as syg_logmel_dct_f32
  *   mel_out    optional [B, n_mels, T] copy of the mel POWER (NULL = not stored)
  *   mfcc_out   [B, n_mfcc, T]
- * Fails (SYG_E_ARG) when n_mels * 16*ceil(T/16) floats do not fit the ~21 KiB of LDS left beside the
- * transform buffers (e.g. n_mels=40: T <= 128 frames); callers then use the two-launch form
+ * Fails (SYG_E_ARG) when n_mels * 16*ceil(T/16) floats do not fit the LDS left beside the transform buffers: ~21 KiB
+ * beside the tile stage buffer (e.g. n_mels=40: T <= 128 frames), ~60 KiB in its place -- the launch then loads its frames
+ * straight from global memory (n_mels=128: T <= 112); callers otherwise use the two-launch form
  * syg_stft2048_mel_f32 + syg_logmel_dct_f32.
  * ------------------------------------------------------------------------------- */
-int syg_stft2048_mfcc_fits(int n_mels, int64_t T, int n_mfcc);   /* 1: the shape fits the one-launch form */
+/* 0: the shape does not fit the one-launch form; 2: it fits beside the stage buffer; 1: in the stage buffer's place */
+int syg_stft2048_mfcc_fits(int n_mels, int64_t T, int n_mfcc);
 int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,
                           int64_t T, const float* window, const float* twiddle, const float* wpacked,
                           const int32_t* plan_host, int n_mels, const float* dct, int n_mfcc,

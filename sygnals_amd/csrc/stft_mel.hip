@@ -482,7 +482,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft2048_kernel(
   int* cplc = TRI ? cpl + SEG_WORDS : cpl;           // contrast plan (MODE 6 ... 9: behind the piece table)
   float2* winl = reinterpret_cast<float2*>(lds + LM::O_WIN);
   float* stage = lds + LM::O_STAGE;
-  float* clipmel = lds + LM::TOTAL;                 // MODE 3: [n_mels][mf.tp], red[WAVES], dct rows, lifter
+  // MODE 3: [n_mels][mf.tp], red[WAVES], dct rows, lifter -- behind the fixed map; a launch that does not stage its tiles
+  // (LOAD != 2) has no stage buffer, the clip's matrix starts there (128-band matrices only fit that way)
+  float* clipmel = lds + (LOAD == 2 ? LM::TOTAL : LM::O_STAGE);
   // MODE 6: two mel matrices (the DCT of a clip runs beside the first tile of the next), red[2][WAVES], dct rows, lifter
   float* tri_red = clipmel + 2 * n_mels * mf.tp;
   float* tri_dct = tri_red + 2 * WAVES;
@@ -1035,6 +1037,7 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
   constexpr int TRIMEL_NPASS = (MODE == 8 || MODE == 9) ? 4 : 2;
   constexpr bool TRI = (MODE == 6 || MODE == 7);
   size_t lds = TRIMEL ? lds_bytes<WAVES, false, TRIMEL_NPASS>() : lds_bytes<WAVES, !TRI>();
+  size_t clip_extra = 0;
   if (TRIMEL) mf.tp = tiles * WAVES;
   if (MODE == 3 || TRI) {
     // whole clips per workgroup; the clip's mel matrix [n_mels][tiles * WAVES] sits behind the fixed LDS map
@@ -1044,15 +1047,21 @@ int launch(int load, const float* y, int64_t B, int64_t L, int64_t ldy, int hop,
     wgs = cw;
     mf.tp = tiles * WAVES;
     if (X2_MEL && (MODE == 3 || MODE == 6)) { mf.amin *= 4.f; mf.ref_value *= 4.f; }     // the clip's mel matrix holds 4 x mel (exact scaling)
-    lds += ((size_t)(TRI ? 2 : 1) * ((size_t)n_mels * mf.tp + WAVES) + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
-    SYG_REQUIRE(lds <= LDS_LIMIT, "stft2048_mfcc: the clip's mel matrix (%d x %d) does not fit the LDS left over (%zu B > %zu B); "
-                "use syg_stft2048_mel_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
+    clip_extra = ((size_t)(TRI ? 2 : 1) * ((size_t)n_mels * mf.tp + WAVES) + (size_t)mf.n_mfcc * (n_mels + 1)) * sizeof(float);
   }
   // staged tiles (LDS-DMA) need the tile's sample run to fit the stage buffer and 32-bit byte offsets
-  const bool can_stage = (MODE != 2) && hop <= 512 && L < ((int64_t)1 << 28);
+  bool can_stage = (MODE != 2) && hop <= 512 && L < ((int64_t)1 << 28);
+  // a clip matrix that does not fit behind the stage buffer takes the buffer's place: frames straight from global memory
+  constexpr size_t STAGE_BYTES = (size_t)Lds<WAVES, !TRI>::STAGE_FLOATS * sizeof(float);
+  if ((MODE == 3 || TRI) && !TRIMEL && lds + clip_extra > LDS_LIMIT) can_stage = false;
   if (load == 2 && !can_stage) load = 1;
   const bool vec2 = (hop % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)y) % 8 == 0);
   if (load == 1 && !vec2) load = 0;
+  if ((MODE == 3 || TRI) && !TRIMEL) {
+    lds = lds - (load != 2 ? STAGE_BYTES : 0) + clip_extra;
+    SYG_REQUIRE(lds <= LDS_LIMIT, "stft2048_mfcc: the clip's mel matrix (%d x %d) does not fit the LDS left over (%zu B > %zu B); "
+                "use syg_stft2048_mel_f32 + syg_logmel_dct_f32", n_mels, mf.tp, lds, LDS_LIMIT);
+  }
   const int dma_wide = (hop % 4 == 0) && (pad % 4 == 0) && (ldy % 4 == 0) && (L % 4 == 0) && (((uintptr_t)y) % 16 == 0);
   auto kern = load == 2 ? stft2048_kernel<WAVES, 2, MODE>
                         : load == 1 ? stft2048_kernel<WAVES, 1, MODE> : stft2048_kernel<WAVES, 0, MODE>;
@@ -1154,8 +1163,11 @@ extern "C" int syg_stft2048_mel_f32(const float* y, int64_t B, int64_t L, int64_
 extern "C" int syg_stft2048_mfcc_fits(int n_mels, int64_t T, int n_mfcc) {
   if (n_mels < 1 || n_mels > 16 * MAXW || T < 1 || n_mfcc < 1 || n_mfcc > n_mels) return 0;
   const int64_t tp = ((T + MAXW - 1) / MAXW) * MAXW;
-  const int64_t bytes = (int64_t)lds_bytes<16>() + ((int64_t)n_mels * tp + 16 + (int64_t)n_mfcc * (n_mels + 1)) * 4;
-  return bytes <= (int64_t)LDS_LIMIT ? 1 : 0;
+  // 2: beside the stage buffer; 1: in the stage buffer's place (the launch then loads its frames straight from global
+  // memory: 128 bands x 94 frames; measured 186 against 196 us for the two-launch form there, 176 against 166 at 64 bands)
+  const int64_t extra = ((int64_t)n_mels * tp + 16 + (int64_t)n_mfcc * (n_mels + 1)) * 4;
+  if ((int64_t)lds_bytes<16>() + extra <= (int64_t)LDS_LIMIT) return 2;
+  return (int64_t)lds_bytes<16>() - (int64_t)Lds<16>::STAGE_FLOATS * 4 + extra <= (int64_t)LDS_LIMIT ? 1 : 0;
 }
 
 extern "C" int syg_stft2048_mfcc_f32(const float* y, int64_t B, int64_t L, int64_t ldy, int hop, int center,

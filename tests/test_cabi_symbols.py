@@ -60,7 +60,8 @@ def test_argument_errors_are_reported_without_device_work():
     assert h.syg_welch_work_bytes(1, 4096) == 1 * 2048 * 2049 * 4 + 1 * 16 * 2049 * 8
     assert h.syg_welch_work_bytes(1024, 256) == 1024 * 16 * 129 * 4 + 1024 * 16 * 129 * 8
     # the one-launch MFCC form: the library owns the LDS-fit rule
-    assert h.syg_stft2048_mfcc_fits(40, 94, 13) == 1 and h.syg_stft2048_mfcc_fits(128, 313, 13) == 0
+    assert h.syg_stft2048_mfcc_fits(40, 94, 13) == 2 and h.syg_stft2048_mfcc_fits(128, 313, 13) == 0
+    assert h.syg_stft2048_mfcc_fits(128, 94, 13) == 1          # in the stage buffer's place
     assert h.syg_stft2048_mfcc_fits(40, 94, 41) == 0 and h.syg_stft2048_mfcc_fits(0, 94, 1) == 0
     with pytest.raises(_lib.SygnalsHipError, match="padlen"):
         _lib.check(-1, "x")

@@ -380,6 +380,27 @@ def test_mfcc_segment_projection_variants(ops, clips):
     assert mel is not None and mf.shape == (8, 13, 94)
 
 
+def test_mfcc_one_launch_default_filterbank_in_the_stage_buffers_place(ops):
+    """The reference's default 128 bands (manager.py:214): a 128 x 96 clip matrix does not fit beside the tile stage buffer
+    but does in its place -- the launch then loads its frames straight from global memory.  Against the oracle and the
+    two-launch form; 64 bands fit the same way (the default call keeps two launches there: measured faster)."""
+    lib = ops.lib()
+    assert lib.syg_stft2048_mfcc_fits(128, 94, 13) == 1 and lib.syg_stft2048_mfcc_fits(64, 94, 13) == 1
+    assert lib.syg_stft2048_mfcc_fits(40, 94, 13) == 2 and lib.syg_stft2048_mfcc_fits(128, 120, 13) == 0
+    assert ops.mfcc_fused_pays(128, 94) and not ops.mfcc_fused_pays(64, 94) and ops.mfcc_fused_pays(40, 94)
+    Y = O.synth_clips(130, 48000, 48000, seed=12)
+    y = ops.to_device_f32(Y)
+    for nm in (128, 64):
+        one = ops.mfcc_batch(y, 48000, n_mels=nm, fused=True).cpu().numpy()
+        two = ops.mfcc_batch(y, 48000, n_mels=nm, fused=False).cpu().numpy()
+        assert np.abs(one - two).max() <= 2e-6 * np.abs(two).max()
+        idx = [0, 77, 129]
+        ref = O.mfcc_batch(Y[idx], 48000, n_mels=nm, n_mfcc=13)
+        for j, i in enumerate(idx):
+            assert_parity(one[i], ref[j], TOL, f"{nm} bands clip {i}")
+    assert np.array_equal(ops.mfcc_batch(y, 48000, n_mels=128).cpu().numpy(), ops.mfcc_batch(y, 48000, n_mels=128, fused=True).cpu().numpy())
+
+
 def test_mfcc_one_launch_rejects_oversized_clip(ops):
     y = ops.to_device_f32(np.zeros((2, 160000), np.float32))
     assert not ops.mfcc_fused_fits(128, 313)
