@@ -110,7 +110,8 @@ report("C3 filtfilt + MFCC", lambda: ops.mfcc_batch(FL.apply_sos_filter_batch(so
 if want("C4 share"):
     from sygnals_amd.core.features.manager import feature_block
     y4 = ops.to_device_f32(np.tile(Y, (2048 // 64, 1)))
-    report("C4 share: MFCC + centroid + rolloff + contrast -> [2048, 22, 94] block", lambda: feature_block(y4, SR), 2048 * L, 2048 * (4 * L + 4 * 22 * Tn))
+    for _ in range(100): feature_block(y4, SR)           # (the clock and the allocator settle: 20 calls from cold read 10 % high)
+    report("C4 share: MFCC + centroid + rolloff + contrast -> [2048, 22, 94] block", lambda: feature_block(y4, SR), 2048 * L, 2048 * (4 * L + 4 * 22 * Tn), n=100)
     del y4
 report("a6-a9 all five spectral statistics + mel, 1024 clips", lambda: ops.stft2048_mel(y, SR, n_mels=40, want_stats=31), B * L, B * (4 * L + 4 * (40 + 5) * Tn))
 report("a6-a9 all five spectral statistics, no mel (syg_stft2048_stats_f32), 1024 clips", lambda: ops.stft2048_stats(y, SR, want_stats=31), B * L, B * (4 * L + 4 * 5 * Tn))
