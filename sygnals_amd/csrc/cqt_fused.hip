@@ -5,7 +5,8 @@
 // HBM, one framed matrix product per octave that reads it back) move 2.6 GB for a stream of 0.69 GB; here the stream is
 // read once and only the transform leaves the chip.
 //
-// A workgroup of eight waves owns a segment of the signal and streams through it in steps of 8192 samples.  Per step:
+// A workgroup owns a segment of the signal and streams through it in steps of 8192 samples; eight of its twelve waves
+// decimate, four multiply.  Per step:
 //   1  the step's samples go to LDS (requested one step ahead)
 //   2  level l = 1 .. n_oct is decimated from level l - 1 inside LDS (x_l[n] = s sum_j h[j] x_(l-1)[2n + 20 - j], the
 //      41-tap half-band of cqt.hip: ten symmetric odd-offset pairs and the centre; samples outside a level's length are
@@ -16,20 +17,23 @@
 //      split once per sample) over the window its next sixteen frames cover.
 //   3  the sixteen frames of every octave that have become complete are multiplied -- frame t of every octave is centred
 //      on sample 512 t of the input, an octave's block lags the step by what its frame length and the decimator delays
-//      need (512 ... 20480 input samples).  A wave holds one 16-row tile of the 32 x 256 operand table in registers for
-//      the whole launch (tile w & 1, three terms: 96 VGPRs) and multiplies that tile of one octave per product phase
+//      need (512 ... 20480 input samples).  A multiplying wave holds one 16-row tile of the 32 x 256 operand table in
+//      registers for the whole launch (three terms: 96 VGPRs) and multiplies that tile of at most one octave per phase
 //      (v_mfma_f32_16x16x32_bf16, the six term pairs of weight >= 2^-24 as in cqt_bf16x3_kernel: 48 matrix instructions,
-//      two accumulation chains); the block leaves as the separate kernels' rows.
+//      two accumulation chains, operand reads one k-step ahead); the block leaves as the separate kernels' rows.
 //   4  the windows slide: the tail a level's next block still needs moves to the front (each array in a phase in which
 //      nothing else touches it).
-// Six phases (barriers) per step: the levels form two chains that run side by side -- 1, 2, 3 on the step's samples,
-// 4 ... 7 on level 3 as the previous step left it (they and their octaves are one step behind) -- then the products of
-// octaves 0 ... 2 beside level 7, then those of octaves 3 ... 6.
+// Four phases (barriers) per step.  The decimating waves run two level chains side by side -- 1, 2, 3 on the step's
+// samples, 4 ... 7 on level 3 as the previous step left it (they and their octaves are one step behind); a level's octave
+// is multiplied in the phase after the one that completed its window, by the multiplying wave of each SIMD beside that
+// SIMD's two decimating waves (a wave alone issues one vector instruction per four cycles: two keep the vector pipe busy,
+// the third brings the matrix instructions; a matrix instruction holds the vector issue for half its length, so the two
+// kinds of work overlap by about half).
 // A segment is entered 24576 samples early (the deepest octave's window and the decimators' delays: the first levels
-// computed from an empty history are wrong only in a region no stored frame reads) and left 3 steps late; segments of
+// computed from an empty history are wrong only in a region no stored frame reads) and left 4 steps late; segments of
 // ~83 steps, one per CU.  LDS 133 KiB: float32 levels 0 .. 6 (66.7 KiB), planes of levels 1 .. 7 (66.4 KiB; 16-byte
 // chunk c of a window at slot c + (c >> log2(hop / 8)): the sixteen frames of a ds_read_b128 group fall on sixteen bank
-// groups, checked by enumeration).
+// groups, checked by enumeration).  150 VGPRs: three waves per SIMD.
 #include <string.h>
 #include "common.h"
 
@@ -41,7 +45,8 @@ typedef __bf16 cf_v4bf __attribute__((ext_vector_type(4)));
 typedef __bf16 cf_v2bf __attribute__((ext_vector_type(2)));
 typedef float cf_v4f __attribute__((ext_vector_type(4)));
 
-constexpr int CF_NT = 512;               // lanes per workgroup
+constexpr int CF_NT = 512;               // lanes that decimate (waves 0 .. 7)
+constexpr int CF_BLOCK = 768;            // lanes per workgroup: + four waves that multiply (one per SIMD)
 constexpr int CF_STEP = 8192;            // input samples per step (sixteen frames of every octave)
 constexpr int CF_MAXOCT = 7;
 constexpr int CF_LEAD = 3;               // steps a segment is entered early / left late
@@ -223,7 +228,10 @@ template <int LV>
 __device__ __forceinline__ cf_v4f cf_product(const float* lds, int lane, const cf_v8bf (&areg)[3][8]) {
   constexpr int SH = cf_sh(LV), NS = CfC<LV>::SLOTS, HOP = cf_hop(LV);
   const char* pl = reinterpret_cast<const char*>(lds + CfC<LV>::OFF_PL);
-  const int n = lane & 15, kk = lane >> 4;
+  int lq = lane;
+  asm volatile("" : "+v"(lq));                   // (the operand addresses are formed per block: hoisted out of the step loop
+                                                 //  for seven levels they do not fit the registers left beside the table)
+  const int n = lq & 15, kk = lq >> 4;
   cf_v4f acc[2];
   acc[0] = cf_v4f{0.f, 0.f, 0.f, 0.f};
   acc[1] = cf_v4f{0.f, 0.f, 0.f, 0.f};
@@ -243,38 +251,23 @@ __device__ __forceinline__ cf_v4f cf_product(const float* lds, int lane, const c
       for (int q = 0; q < 4; ++q) { bh[q] = x0[q]; bh[4 + q] = x1[q]; bm[q] = m0[q]; bm[4 + q] = m1[q]; bl[q] = l0[q]; bl[4 + q] = l1[q]; }
     }
   };
-  // Two k-steps at a time, their matrix instructions alternating between the two accumulators: a wave's consecutive
-  // instructions are independent (small terms first per accumulator, the order of cqt_bf16x3_kernel).  The six operand
-  // reads of the NEXT pair are issued one behind each of the first six matrix instructions of the current pair
-  // (sched_group_barrier: the compiler's own order put every read directly in front of its use -- a wave then pays the
-  // LDS latency once per read -- and reads issued as a burst ahead of the block queue up behind the other waves').
-  cf_v8bf bh[2][2], bm[2][2], bl[2][2];
-  auto pair = [&](int g, int q) { operand(2 * g, bh[q][0], bm[q][0], bl[q][0]); operand(2 * g + 1, bh[q][1], bm[q][1], bl[q][1]); };
-  pair(0, 0);
+  // One k-step at a time: its three operand reads are issued a k-step ahead (two register sets of 12), its six matrix
+  // instructions alternate between the two accumulators (a wave's consecutive instructions are independent; per
+  // accumulator the small terms still come first within a step).  The multiplying wave is alone with its job on its SIMD's
+  // matrix pipe: what it must not do is wait for every read in front of its use.
+  cf_v8bf bh[2], bm[2], bl[2];
+  operand(0, bh[0], bm[0], bl[0]);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int q = g & 1, s = 2 * g;
-    if (g + 1 < 4) pair(g + 1, q ^ 1);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[2][s], bh[q][0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[2][s + 1], bh[q][1], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bl[q][0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bl[q][1], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bm[q][0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s + 1], bm[q][1], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bh[q][0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s + 1], bh[q][1], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bm[q][0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bm[q][1], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bh[q][0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s + 1], bh[q][1], acc[1], 0, 0, 0);
-    if (g + 1 < 4) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-    }
+  for (int s = 0; s < 8; ++s) {
+    const int q = s & 1;
+    if (s + 1 < 8) operand(s + 1, bh[q ^ 1], bm[q ^ 1], bl[q ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[2][s], bh[q], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bl[q], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bm[q], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[1][s], bh[q], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bm[q], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[0][s], bh[q], acc[1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
   return acc[0] + acc[1];
@@ -289,7 +282,7 @@ __device__ __forceinline__ void cf_slide16(float* base, int lane, int n, int shi
   if (lane < n) p[lane] = v;
 }
 
-__global__ __launch_bounds__(CF_NT) void cqt_fused_kernel(const float* __restrict__ y, const float* __restrict__ taps,
+__global__ __launch_bounds__(CF_BLOCK) void cqt_fused_kernel(const float* __restrict__ y, const float* __restrict__ taps,
                                                           const uint4* __restrict__ gsplit, float2* __restrict__ out, CfParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -313,17 +306,14 @@ __global__ __launch_bounds__(CF_NT) void cqt_fused_kernel(const float* __restric
   float hp[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) hp[i] = taps[21 + 2 * i];
-  // this wave's half of the operand table: row tile w & 1, all k-steps, three terms (96 VGPRs for the whole launch)
-  const int rt = w & 1;
-  cf_v8bf areg[3][8];
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-#pragma unroll
-    for (int ss = 0; ss < 8; ++ss) {
-      const uint4 v = gsplit[((p * 2 + rt) * 8 + ss) * 64 + lane];
-      areg[p][ss] = __builtin_bit_cast(cf_v8bf, v);
-    }
-  for (int i = tid; i < CF_LDS_FLOATS; i += CF_NT) lds[i] = 0.f;
+  // Roles: waves 0 .. 7 decimate (and slide the windows), waves 8 .. 11 multiply -- one per SIMD, so that the matrix pipe
+  // works beside the two decimating waves of its SIMD (a wave alone issues one vector instruction per four cycles: two
+  // keep the vector pipe busy, the third brings the matrix instructions).  A multiplying wave holds one 16-row tile of the
+  // operand table in registers for the whole launch (tile mw & 1, three terms: 96 VGPRs) and takes the octaves of group
+  // mw >> 1, at most one per phase.
+  const bool dec = w < 8;
+  const int mw = w - 8, rt = mw & 1, grp = mw >> 1;
+  for (int i = tid; i < CF_LDS_FLOATS; i += CF_BLOCK) lds[i] = 0.f;
 
   // raw samples of a step: lane tid owns samples 16 tid .. 16 tid + 15.  The request runs a whole step ahead, so it must not
   // end in a join of two code paths (the compiler would wait for the data there): every lane always issues the four 16-byte
@@ -395,84 +385,109 @@ __global__ __launch_bounds__(CF_NT) void cqt_fused_kernel(const float* __restric
     }
   };
   const int64_t kfirst = s0 == 0 ? 0 : -CF_LEAD;
-  // the last step: the deepest octave's block (one step behind the others: CF_DEEP) reaches thi
-  int64_t klast = (thi * 512 - s0 + cf_lag(CF_MAXOCT) + CF_STEP - 1) / CF_STEP;
+  // the last step: the deepest octave's block (one step behind the others) reaches thi; one more, because the products of
+  // levels 3 and 7 run in the first phase of the NEXT step
+  int64_t klast = (thi * 512 - s0 + cf_lag(CF_MAXOCT) + CF_STEP - 1) / CF_STEP + 1;
   if (klast < kfirst) klast = kfirst;
-  fetch(s0 + CF_STEP * (kfirst + 1));
+  if (dec) fetch(s0 + CF_STEP * (kfirst + 1));
   __syncthreads();
 #ifdef SYG_CQF_STAMP
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
 #endif
-  // The levels form two chains that run side by side, a phase each: 1 -> 2 -> 3 on this step's samples and 4 -> 5 -> 6 -> 7
-  // on level 3 as the PREVIOUS step left it (levels 4 .. 7 and their octaves are one step behind: xd).  An array slides
-  // in a phase behind its last reader and ahead of its next writer.
-  for (int64_t k = kfirst; k <= klast; ++k) {
-    const int64_t X = s0 + CF_STEP * (k + 1);
-    const int64_t xb = X - CF_STEP, xd = xb - CF_STEP;
-    // phase 0: this step's samples, even / odd apart, behind the history; level 4; planes of levels 5 .. 7 slide
-    raw_fix(X);
-    {
-      float* E = lds + CfC<0>::OFF_F32;
-      float* O = E + CfC<0>::NP;
-      const int m = cf_hist(0) / 2 + 8 * tid;
+  // (a block none of whose sixteen frames this workgroup stores -- the lead-in and the way out -- is not multiplied)
+  auto stored = [&](int o, int64_t t0) { return o < P.n_oct && t0 + 16 > tlo && t0 < thi; };
+  // Four phases (barriers) per step.  The decimating waves run two level chains side by side -- 1 -> 2 -> 3 on this step's
+  // samples, 4 -> 5 -> 6 -> 7 on level 3 as the PREVIOUS step left it (levels 4 .. 7 and their octaves are one step
+  // behind: xd) -- and slide an array in a phase behind its last reader and ahead of its next writer; the multiplying waves
+  // take a level's octave in the phase after the one that completed its window.  Two loops, one per role (in one loop the
+  // operand table of the one role and the sample registers of the other are live everywhere: 91 spills at 168 registers);
+  // both pass the same four barriers per step.
+  if (dec) {
+    for (int64_t k = kfirst; k <= klast; ++k) {
+      const int64_t X = s0 + CF_STEP * (k + 1);
+      const int64_t xb = X - CF_STEP, xd = xb - CF_STEP;
+      // phase 0: samples + level 4; the planes of levels 2 and 6 (multiplied in the previous phase) and their float32 copies
+      // (read by levels 3 and 7 there) slide
+      raw_fix(X);
+      {
+        float* E = lds + CfC<0>::OFF_F32;
+        float* O = E + CfC<0>::NP;
+        const int m = cf_hist(0) / 2 + 8 * tid;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<float2*>(E + m + 2 * q) = make_float2(raw[q][0], raw[q][2]);
-        *reinterpret_cast<float2*>(O + m + 2 * q) = make_float2(raw[q][1], raw[q][3]);
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<float2*>(E + m + 2 * q) = make_float2(raw[q][0], raw[q][2]);
+          *reinterpret_cast<float2*>(O + m + 2 * q) = make_float2(raw[q][1], raw[q][3]);
+        }
       }
-    }
-    fetch(X + CF_STEP);
-    if (P.n_oct >= 4) cf_decimate<4>(lds, tid, hp, hc, P.scale, (xd >> 4) - 32, len[4]);
-    for (int j = w; j < 9; j += 8) slide_plane(5 + j / 3, j % 3);
-    __syncthreads();
-    CQF_T(0);
-    // phase 1: levels 1 and 5; the history of level 3
-    cf_decimate<1>(lds, tid, hp, hc, P.scale, (xb >> 1) - 32, len[1]);
-    if (P.n_oct >= 5) cf_decimate<5>(lds, tid, hp, hc, P.scale, (xd >> 5) - 32, len[5]);
-    if (w >= 6) slide_f32(3, w & 1);
-    __syncthreads();
-    CQF_T(1);
-    // phase 2: levels 2 and 6; histories of levels 0 and 4
-    if (P.n_oct >= 2) cf_decimate<2>(lds, tid, hp, hc, P.scale, (xb >> 2) - 32, len[2]);
-    if (P.n_oct >= 6) cf_decimate<6>(lds, tid, hp, hc, P.scale, (xd >> 6) - 32, len[6]);
-    if (w >= 4) slide_f32((w & 2) ? 4 : 0, w & 1);
-    __syncthreads();
-    CQF_T(2);
-    // phase 3: levels 3 and 7; histories of levels 1 and 5
-    if (P.n_oct >= 3) cf_decimate<3>(lds, tid, hp, hc, P.scale, (xb >> 3) - 32, len[3]);
-    if (P.n_oct >= 7) cf_decimate<7>(lds, tid, hp, hc, P.scale, (xd >> 7) - 32, len[7]);
-    if (w >= 4) slide_f32((w & 2) ? 5 : 1, w & 1);
-    __syncthreads();
-    CQF_T(3);
-    // phase 4: octaves 0 .. 3 (octave w >> 1, row tile w & 1); histories of levels 2 and 6
-    // (a block none of whose sixteen frames this workgroup stores -- the lead-in and the way out -- is not multiplied)
-    auto stored = [&](int64_t t0) { return t0 + 16 > tlo && t0 < thi; };
-    if ((w >> 1) < P.n_oct) {
-      cf_v4f acc;
-      int64_t t0;
-      switch (w >> 1) {
-        case 0: t0 = (xb - cf_lag(1)) / 512; if (stored(t0)) { acc = cf_product<1>(lds, lane, areg); store_block(0, acc, t0); } break;
-        case 1: t0 = (xb - cf_lag(2)) / 512; if (stored(t0)) { acc = cf_product<2>(lds, lane, areg); store_block(1, acc, t0); } break;
-        case 2: t0 = (xb - cf_lag(3)) / 512; if (stored(t0)) { acc = cf_product<3>(lds, lane, areg); store_block(2, acc, t0); } break;
-        default: t0 = (xd - cf_lag(4)) / 512; if (stored(t0)) { acc = cf_product<4>(lds, lane, areg); store_block(3, acc, t0); } break;
+      fetch(X + CF_STEP);
+      if (P.n_oct >= 4) cf_decimate<4>(lds, tid, hp, hc, P.scale, (xd >> 4) - 32, len[4]);
+      for (int j = w; j < 10; j += 8) {
+        if (j < 6) slide_plane(j < 3 ? 2 : 6, j % 3); else slide_f32(j < 8 ? 2 : 6, j & 1);
       }
-    }
-    if (w >= 4) slide_f32((w & 2) ? 6 : 2, w & 1);
-    __syncthreads();
-    CQF_T(4);
-    // phase 5: octaves 4 .. 6 (waves 0 .. 5: octave 4 + (w >> 1), row tile w & 1); planes of levels 1 .. 4 slide
-    if (w < 6 && 4 + (w >> 1) < P.n_oct) {
-      cf_v4f acc;
-      int64_t t0;
-      switch (w >> 1) {
-        case 0: t0 = (xd - cf_lag(5)) / 512; if (stored(t0)) { acc = cf_product<5>(lds, lane, areg); store_block(4, acc, t0); } break;
-        case 1: t0 = (xd - cf_lag(6)) / 512; if (stored(t0)) { acc = cf_product<6>(lds, lane, areg); store_block(5, acc, t0); } break;
-        default: t0 = (xd - cf_lag(7)) / 512; if (stored(t0)) { acc = cf_product<7>(lds, lane, areg); store_block(6, acc, t0); } break;
+      __syncthreads();
+      CQF_T(0);
+      // phase 1: levels 1 and 5; planes of levels 3 and 7, float32 level 3
+      cf_decimate<1>(lds, tid, hp, hc, P.scale, (xb >> 1) - 32, len[1]);
+      if (P.n_oct >= 5) cf_decimate<5>(lds, tid, hp, hc, P.scale, (xd >> 5) - 32, len[5]);
+      if (w < 6) slide_plane(w < 3 ? 3 : 7, w % 3); else slide_f32(3, w & 1);
+      __syncthreads();
+      CQF_T(1);
+      // phase 2: levels 2 and 6; planes of level 4, float32 levels 0 and 4
+      if (P.n_oct >= 2) cf_decimate<2>(lds, tid, hp, hc, P.scale, (xb >> 2) - 32, len[2]);
+      if (P.n_oct >= 6) cf_decimate<6>(lds, tid, hp, hc, P.scale, (xd >> 6) - 32, len[6]);
+      if (w < 3) slide_plane(4, w); else if (w < 7) slide_f32(w < 5 ? 0 : 4, (w - 3) & 1);
+      __syncthreads();
+      CQF_T(2);
+      // phase 3: levels 3 and 7; planes and float32 copies of levels 1 and 5
+      if (P.n_oct >= 3) cf_decimate<3>(lds, tid, hp, hc, P.scale, (xb >> 3) - 32, len[3]);
+      if (P.n_oct >= 7) cf_decimate<7>(lds, tid, hp, hc, P.scale, (xd >> 7) - 32, len[7]);
+      for (int j = w; j < 10; j += 8) {
+        if (j < 6) slide_plane(j < 3 ? 1 : 5, j % 3); else slide_f32(j < 8 ? 1 : 5, j & 1);
       }
+      __syncthreads();
+      CQF_T(3);
     }
-    for (int j = (w + 2) & 7; j < 12; j += 8) slide_plane(1 + j / 3, j % 3);      // (waves 6 and 7, without a product, take two arrays)
-    __syncthreads();
-    CQF_T(5);
+  } else {
+    // this wave's half of the operand table: row tile mw & 1, all k-steps, three terms (96 VGPRs for the whole launch)
+    cf_v8bf areg[3][8];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int ss = 0; ss < 8; ++ss) {
+        const uint4 v = gsplit[((p * 2 + rt) * 8 + ss) * 64 + lane];
+        areg[p][ss] = __builtin_bit_cast(cf_v8bf, v);
+      }
+    for (int64_t k = kfirst; k <= klast; ++k) {
+      const int64_t X = s0 + CF_STEP * (k + 1);
+      const int64_t xb = X - CF_STEP, xd = xb - CF_STEP;
+      // phase 0: octaves 2 and 6 of the PREVIOUS step (levels 3 and 7 were completed in its last phase)
+      {
+        const int64_t t0 = grp == 0 ? (xb - CF_STEP - cf_lag(3)) / 512 : (xd - CF_STEP - cf_lag(7)) / 512;
+        if (grp == 0) { if (stored(2, t0)) store_block(2, cf_product<3>(lds, lane, areg), t0); }
+        else { if (stored(6, t0)) store_block(6, cf_product<7>(lds, lane, areg), t0); }
+      }
+      __syncthreads();
+      // phase 1: octave 3 (level 4 of phase 0)
+      if (grp == 0) {
+        const int64_t t0 = (xd - cf_lag(4)) / 512;
+        if (stored(3, t0)) store_block(3, cf_product<4>(lds, lane, areg), t0);
+      }
+      __syncthreads();
+      // phase 2: octaves 0 and 4 (levels 1 and 5 of phase 1)
+      {
+        const int64_t t0 = grp == 0 ? (xb - cf_lag(1)) / 512 : (xd - cf_lag(5)) / 512;
+        if (grp == 0) { if (stored(0, t0)) store_block(0, cf_product<1>(lds, lane, areg), t0); }
+        else { if (stored(4, t0)) store_block(4, cf_product<5>(lds, lane, areg), t0); }
+      }
+      __syncthreads();
+      // phase 3: octaves 1 and 5 (levels 2 and 6 of phase 2)
+      {
+        const int64_t t0 = grp == 0 ? (xb - cf_lag(2)) / 512 : (xd - cf_lag(6)) / 512;
+        if (grp == 0) { if (stored(1, t0)) store_block(1, cf_product<2>(lds, lane, areg), t0); }
+        else { if (stored(5, t0)) store_block(5, cf_product<6>(lds, lane, areg), t0); }
+      }
+      __syncthreads();
+    }
   }
 #ifdef SYG_CQF_STAMP
   if (tid == 0 && blockIdx.x < 256)
@@ -530,7 +545,7 @@ extern "C" int syg_cqt_fused_f32(const float* y, int64_t B, int64_t L, int64_t l
     set_error("cqt_fused: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e));
     return SYG_E_LAUNCH;
   }
-  hipLaunchKernelGGL(cqt_fused_kernel, dim3((unsigned)(P.n_seg * B)), dim3(CF_NT), lds, (hipStream_t)stream, y, taps,
+  hipLaunchKernelGGL(cqt_fused_kernel, dim3((unsigned)(P.n_seg * B)), dim3(CF_BLOCK), lds, (hipStream_t)stream, y, taps,
                      (const uint4*)gsplit, (float2*)out, P);
   SYG_CHECK_LAUNCH("cqt_fused");
   return SYG_OK;
