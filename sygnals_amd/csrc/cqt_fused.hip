@@ -77,6 +77,18 @@ template <int LV> struct CfC {
 };
 constexpr int CF_LDS_FLOATS = cf_off_pl(8);
 static_assert(cf_kept(1) == 352 && cf_kept(3) == 288 && cf_kept(7) == 256, "window arithmetic");
+// what the schedule relies on, level by level
+constexpr bool cf_level_ok(int lv) {
+  return cf_lag(lv) % 512 == 0 && cf_lag(lv) >= (127 + 32) * (1 << lv)          // a block's last frame ends inside the samples a step has
+         && cf_kept(lv) % 8 == 0 && cf_new(lv) % 8 == 0                          // whole 16-byte chunks slide and arrive
+         && 15 * cf_hop(lv) + 256 <= cf_win(lv)                                  // sixteen frames inside the window
+         && (cf_sh(lv) == 31 || (cf_new(lv) / 8) % (1 << cf_sh(lv)) == 0)        // the slide moves skewed slots by a constant
+         && (cf_sh(lv) == 31 ? cf_kept(lv) / 8 : cf_kept(lv) / 8 + ((cf_kept(lv) / 8 - 1) >> cf_sh(lv))) <= 64   // one wave slides an array
+         && cf_hist(lv < 7 ? lv : 0) / 2 <= 64 && 2 * 10 + 32 <= cf_hist(lv < 7 ? lv : 0);   // history: ten pairs behind + the 32-sample lag
+}
+static_assert(cf_level_ok(1) && cf_level_ok(2) && cf_level_ok(3) && cf_level_ok(4) && cf_level_ok(5) && cf_level_ok(6) && cf_level_ok(7),
+              "level schedule");
+static_assert(CF_STEP == 16 * 512 && CF_NT * 16 == CF_STEP, "sixteen frames per block; sixteen samples per decimating lane");
 static_assert(CF_LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 
 #ifdef SYG_CQF_STAMP
