@@ -1,6 +1,6 @@
 """Randomised shape fuzz of round 4's kernels against the float64 oracle and against the forms they must agree with
 (development aid): the tile form of the segment-sum projection (MODE 8 ... 11: two- / four-pass tables, 16 / 8 waves, with
-and without row functions, any hop / alignment), the row functions inside the frame-length 1024 / 512 / 256 kernels.
+and without row functions, any hop / alignment), the row functions inside the frame-length 1024 / 512 / 256 / 4096 kernels.
     python3 tools/fuzz_round4.py [seed [n]]"""
 import sys
 import numpy as np, torch
@@ -46,10 +46,10 @@ for it in range(N):
             assert torch.equal(sa, sb), (it, "statistics rows differ", B, L, hop, center, sr, smask)
             if cplan is not None:
                 assert torch.equal(pa, pb), (it, "contrast rows differ", B, L, hop, center, sr)
-    # ---- 1024 / 512 / 256: the rows kernels
-    nf = int(rng.choice([1024, 512, 256]))
+    # ---- 1024 / 512 / 256 / 4096: the rows kernels
+    nf = int(rng.choice([1024, 512, 256, 4096]))
     hop2 = int(rng.choice([nf // 8, nf // 4, nf // 2, 100, nf]))
-    L2 = int(rng.integers(nf if not center else 1, 9000))
+    L2 = int(rng.integers(nf if not center else 1, 9000 if nf < 4096 else 30000))
     if ops.num_frames(L2, nf, hop2, center) > 0:
         n_rows += 1
         Y2 = (rng.normal(0, 0.3, (B, L2)) * rng.random((B, 1))).astype(np.float32)
