@@ -53,7 +53,14 @@ constexpr int CF_LEAD = 3;               // steps a segment is entered early / l
 
 __host__ __device__ constexpr int cf_new(int lv) { return CF_STEP >> lv; }                     // new samples of level lv per step
 __host__ __device__ constexpr int cf_hist(int lv) { return lv == 0 ? 84 : 52; }                // float32 history in front
-__host__ __device__ constexpr int cf_np(int lv) { return ((cf_hist(lv) + cf_new(lv)) / 2 + 3) & ~3; }   // pairs (padded)
+// Level 0's even / odd arrays are read by level 1 with a lane stride of 32 bytes (eight outputs per lane): 16-byte chunk c
+// sits at c + c / 16, so that the sixteen lanes of a ds_read_b128 group fall on sixteen bank groups instead of eight
+// (float index f -> cf_sk0(f)); the other levels' readers move 16 or 8 bytes per lane and need no skew.
+__host__ __device__ constexpr int cf_sk0(int f) { return f + ((f >> 6) << 2); }
+__host__ __device__ constexpr int cf_np_plain(int lv) { return ((cf_hist(lv) + cf_new(lv)) / 2 + 3) & ~3; }
+__host__ __device__ constexpr int cf_np(int lv) {          // pairs (padded; level 0 with its skew)
+  return lv == 0 ? ((cf_sk0(cf_np_plain(0)) + 4 + 3) & ~3) : cf_np_plain(lv);
+}
 __host__ __device__ constexpr int cf_hop(int lv) { return 512 >> lv; }                         // frame hop of octave lv - 1
 // input samples an octave's frame block lags the step: a multiple of 512 >= (127 + 32) 2^lv
 __host__ __device__ constexpr int cf_lag(int lv) {
@@ -127,14 +134,17 @@ __device__ __forceinline__ void cf_decimate(float* lds, int tid, const float (&h
   const int i0 = tid * OPL;                      // first output of this lane; its centre pair is m = 10 + i0
   float ow[OPL + 20], ev[OPL];
   if (OPL == 8) {
+    // (level 1 reads level 0: skewed chunks, cf_sk0)
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(O + i0 + 4 * q);
+      const int f = i0 + 4 * q;
+      const float4 v = *reinterpret_cast<const float4*>(O + (LV == 1 ? f + ((f >> 6) << 2) : f));
       ow[4 * q] = v.x; ow[4 * q + 1] = v.y; ow[4 * q + 2] = v.z; ow[4 * q + 3] = v.w;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float2 v = *reinterpret_cast<const float2*>(E + 10 + i0 + 2 * q);
+      const int f = 10 + i0 + 2 * q;
+      const float2 v = *reinterpret_cast<const float2*>(E + (LV == 1 ? f + ((f >> 6) << 2) : f));
       ev[2 * q] = v.x; ev[2 * q + 1] = v.y;
     }
   } else if (OPL == 4) {
@@ -379,9 +389,10 @@ __global__ __launch_bounds__(CF_BLOCK) void cqt_fused_kernel(const float* __rest
     int lq = lane;
     asm volatile("" : "+v"(lq));
     float v = 0.f;
-    if (lq < h2) v = a[lq + nw2];
+    const int src = lq + nw2, sks = lv == 0 ? src + ((src >> 6) << 2) : src, skd = lv == 0 ? lq + ((lq >> 6) << 2) : lq;   // cf_sk0
+    if (lq < h2) v = a[sks];
     wave_lds_sync();
-    if (lq < h2) a[lq] = v;
+    if (lq < h2) a[skd] = v;
   };
   auto store_block = [&](int o, cf_v4f acc, int64_t t0) {       // row tile rt of octave o
     int lq = lane;
@@ -427,8 +438,9 @@ __global__ __launch_bounds__(CF_BLOCK) void cqt_fused_kernel(const float* __rest
         const int m = cf_hist(0) / 2 + 8 * tid;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          *reinterpret_cast<float2*>(E + m + 2 * q) = make_float2(raw[q][0], raw[q][2]);
-          *reinterpret_cast<float2*>(O + m + 2 * q) = make_float2(raw[q][1], raw[q][3]);
+          const int f = m + 2 * q, fs = f + ((f >> 6) << 2);           // cf_sk0
+          *reinterpret_cast<float2*>(E + fs) = make_float2(raw[q][0], raw[q][2]);
+          *reinterpret_cast<float2*>(O + fs) = make_float2(raw[q][1], raw[q][3]);
         }
       }
       fetch(X + CF_STEP);

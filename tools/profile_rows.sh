@@ -26,6 +26,6 @@ done
   f=$(ls $OUT/trace/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && head -25 "$f"
   echo "== PMC, mean per dispatch =="
-  for i in 1 2 3 4; do python3 tools/pmc_kernels.py "$OUT/pmc$i" sos_clip welch_wave decimate2_chain cqt_bf16x3 cqt_gemm stft_mel_w1024 stft2048_kernel logmel 2>/dev/null; done
+  for i in 1 2 3 4; do python3 tools/pmc_kernels.py "$OUT/pmc$i" sos_clip welch_wave cqt_fused decimate2_chain cqt_bf16x3 cqt_gemm stft_mel_w1024 stft2048_kernel logmel 2>/dev/null; done
 } > "$OUT/summary.txt"
 tail -5 "$OUT/summary.txt"
