@@ -447,3 +447,16 @@ def test_cqt_one_launch_shape():
     assert not CqtPlan(48000, 512, None, 60).one_launch_shape()
     assert not CqtPlan(32000, 512, None, 72).one_launch_shape()
     assert not CqtPlan(48000, 512, None, 80).one_launch_shape()      # 80 bins: the lowest octave is clipped to 8 filters
+
+
+def test_cqt_decimator_is_what_the_one_launch_kernel_assumes():
+    """syg_cqt_fused_f32 reads the centre tap and the ten odd-offset taps of one side (cqt_fused.hip: a symmetric half-band):
+    the filter the plan hands it is exactly that -- zero at every even offset from the centre, symmetric to the last bit
+    after the float32 rounding the device applies."""
+    from sygnals_amd._cqt import decimation_taps
+    h = decimation_taps()
+    assert h.shape == (41,)
+    assert all(h[20 + d] == 0.0 and h[20 - d] == 0.0 for d in range(2, 21, 2))
+    h32 = h.astype(np.float32)
+    assert np.array_equal(h32, h32[::-1])
+    assert abs(float(h.sum()) - 1.0) < 1e-12 and abs(float(h[20]) - 0.5) < 1e-3
